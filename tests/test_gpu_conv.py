@@ -1,0 +1,83 @@
+"""K1/K3/K12 parity: dx_conv1d (MFMA implicit-GEMM conv / linear) vs the CPU oracle's conv1d_cl.
+Tolerances: fp32 operands (v_mfma_f32_32x32x2_f32, exact fp32 products) 1e-5 abs + 1e-5 rel of the
+row scale; bf16 operands 2e-2 of the output scale (inputs rounded to 8 mantissa bits, fp32 accumulate)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import daft_exprt_cpu as O
+
+
+def _run(B, N, Cin, Cout, taps, cdtype, xdtype, ydtype, relu=False, mask=False, trans=False, gate=False, seed=0):
+    from daft_exprt import ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, N, Cin, generator=g)
+    w = torch.randn(Cout, Cin, taps, generator=g) / (Cin * taps) ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    lens = torch.randint(1, N + 1, (B,), generator=g)
+    lens[0] = N
+    ref = O.conv1d_cl(x, w, bias)
+    if relu:
+        ref = torch.relu(ref)
+    gate_t = torch.randn(B, N, Cout, generator=g) if gate else None
+    if gate:
+        ref = ref * (gate_t > 0)
+    if mask:
+        ref = ref * (torch.arange(N)[None, :, None] < lens[:, None, None])
+    dev = torch.device('cuda:0')
+    xd = x.to(dev).to(xdtype)
+    wp = ops.pack_conv_weight(w.to(dev), cdtype)
+    gd = None
+    if gate:
+        gd = gate_t.to(dev).to(ydtype)
+        if trans:
+            gd = gd.transpose(1, 2).contiguous()
+    y = ops.conv1d(xd, wp, bias.to(dev), out_dtype=ydtype, relu=relu, relu_gate=gd,
+                   mask_lengths=lens.to(dev) if mask else None, transposed_out=trans)
+    torch.cuda.synchronize()
+    y = y.float().cpu()
+    if trans:
+        y = y.transpose(1, 2)
+    err = (y - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    tol = 2e-5 * max(scale, 1.) if (cdtype == torch.float32) else 2.5e-2 * scale
+    assert err <= tol, f'max err {err:.3e} vs tol {tol:.3e} (scale {scale:.3f})'
+
+
+@pytest.mark.parametrize('taps', [1, 3])
+@pytest.mark.parametrize('shape', [(2, 37, 80, 1024), (3, 130, 128, 384), (2, 257, 1024, 128), (1, 5, 128, 80), (2, 129, 256, 256)])
+def test_conv_fp32_exact(shape, taps):
+    B, N, Cin, Cout = shape
+    _run(B, N, Cin, Cout, taps, torch.float32, torch.float32, torch.float32)
+
+
+@pytest.mark.parametrize('taps', [1, 3])
+@pytest.mark.parametrize('shape', [(2, 37, 80, 1024), (3, 130, 128, 384), (2, 257, 1024, 128), (1, 5, 128, 80)])
+def test_conv_bf16(shape, taps):
+    B, N, Cin, Cout = shape
+    _run(B, N, Cin, Cout, taps, torch.bfloat16, torch.float32, torch.bfloat16)
+    _run(B, N, Cin, Cout, taps, torch.bfloat16, torch.bfloat16, torch.float32)
+
+
+def test_conv_epilogues():
+    _run(2, 70, 128, 1024, 3, torch.float32, torch.float32, torch.float32, relu=True)
+    _run(2, 70, 128, 80, 1, torch.float32, torch.float32, torch.float32, mask=True, trans=True)
+    _run(3, 131, 1024, 128, 3, torch.float32, torch.float32, torch.float32, gate=True, mask=True)
+    _run(3, 131, 128, 1024, 3, torch.bfloat16, torch.float32, torch.bfloat16, relu=True, gate=True)
+
+
+def test_pack_transpose_flip_is_conv_data_gradient():
+    ''' dX = conv(dY, flipped/transposed W) -- checked against autograd on the oracle conv. '''
+    from daft_exprt import ops
+    g = torch.Generator().manual_seed(5)
+    B, N, Cin, Cout = 2, 45, 128, 256
+    x = torch.randn(B, N, Cin, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, 3, generator=g) / 20
+    dy = torch.randn(B, N, Cout, generator=g)
+    (O.conv1d_cl(x, w, None) * dy).sum().backward()
+    dev = torch.device('cuda:0')
+    wd = ops.pack_conv_weight(w.to(dev), torch.float32, transpose_flip=True)
+    dx = ops.conv1d(dy.to(dev), wd, None)
+    torch.cuda.synchronize()
+    assert (dx.cpu() - x.grad).abs().max().item() < 2e-5 * x.grad.abs().max().item() + 1e-5

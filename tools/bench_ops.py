@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Micro-benchmarks of individual HIP kernels on the GPU box (development aid).
+usage: python tools/bench_ops.py conv"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'ubisoft-laforge-daft-exprt_amd'))
+from daft_exprt import ops  # noqa: E402
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def bench_conv():
+    dev = torch.device('cuda:0')
+    B, N = 48, 1000
+    for (cin, cout, taps) in [(80, 1024, 3), (1024, 1024, 3), (1024, 128, 3), (128, 1024, 3), (128, 384, 1), (128, 128, 1), (128, 80, 1)]:
+        for cd, xd, yd in [(torch.bfloat16, torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32, torch.float32)]:
+            x = torch.randn(B, N, cin, device=dev).to(xd)
+            w = torch.randn(cout, cin, taps, device=dev) / (cin * taps) ** 0.5
+            wp = ops.pack_conv_weight(w, cd)
+            bias = torch.zeros(cout, device=dev)
+            out = torch.empty(B, N, cout, device=dev, dtype=yd)
+            ms = timeit(lambda: ops.conv1d(x, wp, bias, out_dtype=yd, relu=True, out=out))
+            fl = 2. * B * N * cin * cout * taps
+            print(f'conv {cin:5d}->{cout:5d} k{taps} {str(cd)[6:]:9s}: {ms:8.3f} ms  {fl / ms / 1e9:9.1f} TFLOP/s')
+
+
+if __name__ == '__main__':
+    {'conv': bench_conv}[sys.argv[1]]()

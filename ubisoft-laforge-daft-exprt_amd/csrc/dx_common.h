@@ -1,0 +1,122 @@
+// Shared device/host helpers for the Daft-Exprt gfx950 kernels.
+// Everything here targets CDNA4 (wave64, MFMA 32x32x16 bf16 / 32x32x2 f32) directly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/daft_exprt_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DX_WAVE 64
+
+// ---- error plumbing (host) ------------------------------------------------------------
+void dx_set_error(const char* fmt, ...);
+#define DX_REQUIRE(cond, code, ...)            \
+  do {                                         \
+    if (!(cond)) {                             \
+      dx_set_error(__VA_ARGS__);               \
+      return (code);                           \
+    }                                          \
+  } while (0)
+#define DX_LAUNCH_CHECK()                                                   \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      dx_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return DX_ERR_LAUNCH;                                                 \
+    }                                                                       \
+  } while (0)
+
+static inline int dx_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device helpers -------------------------------------------------------------------
+template <typename T>
+struct Vec8;
+template <>
+struct Vec8<bf16_t> { typedef bf16x8 type; };
+template <>
+struct Vec8<float> { typedef f32x8 type; };
+
+// load 8 consecutive elements of TA from global and convert to TC
+template <typename TA, typename TC>
+__device__ __forceinline__ typename Vec8<TC>::type dx_load8(const TA* p);
+
+template <>
+__device__ __forceinline__ bf16x8 dx_load8<bf16_t, bf16_t>(const bf16_t* p) {
+  return *reinterpret_cast<const bf16x8*>(p);
+}
+template <>
+__device__ __forceinline__ bf16x8 dx_load8<float, bf16_t>(const float* p) {
+  f32x4 lo = *reinterpret_cast<const f32x4*>(p);
+  f32x4 hi = *reinterpret_cast<const f32x4*>(p + 4);
+  bf16x8 r;
+  r[0] = (bf16_t)lo[0]; r[1] = (bf16_t)lo[1]; r[2] = (bf16_t)lo[2]; r[3] = (bf16_t)lo[3];
+  r[4] = (bf16_t)hi[0]; r[5] = (bf16_t)hi[1]; r[6] = (bf16_t)hi[2]; r[7] = (bf16_t)hi[3];
+  return r;
+}
+template <>
+__device__ __forceinline__ f32x8 dx_load8<float, float>(const float* p) {
+  f32x4 lo = *reinterpret_cast<const f32x4*>(p);
+  f32x4 hi = *reinterpret_cast<const f32x4*>(p + 4);
+  f32x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return r;
+}
+template <>
+__device__ __forceinline__ f32x8 dx_load8<bf16_t, float>(const bf16_t* p) {
+  bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (float)v[i];
+  return r;
+}
+
+// One K=16 step of a 32x32 output tile.  Lane l holds row/col (l & 31) and the 8 k-values
+// 8*(l>>5)..+7 of the step for both operands.  bf16: one v_mfma_f32_32x32x16_bf16.
+// fp32: eight v_mfma_f32_32x32x2_f32 (exact fp32; instruction j contracts k = j and 8+j).
+__device__ __forceinline__ void dx_mma(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void dx_mma(f32x16& acc, const f32x8& a, const f32x8& b) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+}
+
+// row index inside a 32x32 accumulator tile for register r of lane-group g = lane >> 5
+__device__ __forceinline__ int dx_acc_row(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
+
+template <typename T>
+__device__ __forceinline__ float dx_to_f32(T v) { return (float)v; }
+
+__device__ __forceinline__ float dx_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float dx_wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// Counter-based dropout RNG: one 32-bit hash per element index.  keep iff hash >= p * 2^32.
+// (Bit-parity with torch's Philox stream is not a goal -- SURVEY section 7; the forward and
+// backward passes regenerate the same mask from (seed, element index).)
+__device__ __forceinline__ uint32_t dx_hash32(uint64_t seed, uint64_t idx) {
+  uint64_t x = idx * 0x9E3779B97F4A7C15ull + seed;
+  x ^= x >> 32;
+  x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  return (uint32_t)x;
+}
+__device__ __forceinline__ bool dx_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
+  return dx_hash32(seed, idx) >= thresh;
+}
