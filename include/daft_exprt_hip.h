@@ -30,7 +30,7 @@ enum { DX_F32 = 0, DX_BF16 = 1, DX_I64 = 2 };
 enum { DX_OK = 0, DX_ERR_ARG = -1, DX_ERR_SHAPE = -2, DX_ERR_DTYPE = -3, DX_ERR_LAUNCH = -4, DX_ERR_UNSUPPORTED = -5 };
 
 /* flags of dx_conv1d */
-enum { DX_CONV_RELU = 1, DX_CONV_TRANSPOSED_OUT = 2 };
+enum { DX_CONV_RELU = 1, DX_CONV_TRANSPOSED_OUT = 2, DX_CONV_ACCUMULATE = 4 /* y += result */ };
 
 int dx_abi_version(void);
 const char* dx_last_error(void);
@@ -59,6 +59,160 @@ int dx_conv1d(const void* x, int x_dtype, long ldx, const void* w_packed, int w_
  *   transpose_flip = 1: out[tap][ci][co] = w[co][ci][taps-1-tap]         (data-gradient operand) */
 int dx_pack_conv_weight(const float* w, void* out, int out_dtype, int Cout, int Cin, int taps, int transpose_flip,
                         void* stream);
+
+/* Weight / bias gradient of dx_conv1d (and of nn.Linear with taps = 1), accumulated with fp32 atomics into
+ * dw (Cout, Cin, taps) [PyTorch layout] and db (Cout) [NULL to skip]:
+ *   dw[co][ci][tap] += sum_{b,n} dy[b, n, co] * x[b, n + tap - taps/2, ci];   db[co] += sum_{b,n} dy[b, n, co]
+ * dy (B, N, Cout) rows lddy apart, x (B, N, Cin) rows ldx apart; compute_dtype = MFMA operand type.
+ * lengths (NULL = none): rows n >= lengths[b] + 2 of dy are known to be zero and are skipped. */
+int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const void* x, int x_dtype, long ldx,
+                    int compute_dtype, float* dw, float* db, const int64_t* lengths, int B, int N, int Cin,
+                    int Cout, int taps, void* stream);
+
+/* ---- K5: LayerNorm(C) over channel-last rows fused with its neighbours (C in {128, 256, 1024}):
+ *   s = dropout_pre(x) + residual;  y = LN(s) * gamma + beta;  y = dropout_post(y);
+ *   y = film[b, :C] * y + film[b, C:];  y = 0 where n >= lengths[b]
+ * Replaces nn.LayerNorm + nn.Dropout + residual add + FiLM + masked_fill at model.py:189-191 (attention),
+ * 226-235 + 262 (FF block), 346-348/353-355/360-362 (prenet), 533-535/540-542 + 558-566 (predictor).
+ * residual / film / lengths / s_out / mean+rstd may be NULL (feature off).  s_out, mean, rstd (fp32) are what
+ * dx_layernorm_bwd needs.  Dropout masks are a counter-based hash of (seed, element index), regenerated
+ * identically by the backward kernel; p = 0 disables. */
+int dx_layernorm_fwd(const void* x, int x_dtype, const float* residual, const float* gamma, const float* beta,
+                     const float* film, long ldf, const int64_t* lengths, void* y, int y_dtype, float* s_out,
+                     float* mean, float* rstd, int B, int N, int C, float p_pre, uint64_t seed_pre,
+                     float p_post, uint64_t seed_post, void* stream);
+
+/* Backward of dx_layernorm_fwd.  dy: grad wrt y.  s_in: s_out of the forward (or x itself when there was no
+ * residual / pre-dropout).  Outputs: ds = grad wrt s (equals the residual-branch gradient); dx_pre = grad wrt x
+ * through dropout_pre (NULL when p_pre == 0: then it equals ds); dgamma, dbeta (C) and dfilm (B, 2C) are
+ * ACCUMULATED with fp32 atomics (zero them first).  relu_input != 0: the normalised tensor was relu(conv) (prenet,
+ * predictor); ds is then gated by (s_in > 0) so that it is the gradient of the conv's pre-activation. */
+int dx_layernorm_bwd(const void* dy, int dy_dtype, const void* s_in, int s_dtype, const float* mean,
+                     const float* rstd, const float* gamma, const float* beta, const float* film, long ldf,
+                     const int64_t* lengths, void* ds, void* dx_pre, int d_dtype, float* dgamma, float* dbeta,
+                     float* dfilm, long lddf, int B, int N, int C, float p_pre, uint64_t seed_pre,
+                     float p_post, uint64_t seed_post, int relu_input, void* stream);
+
+/* ---- K4: multi-head self-attention with key-padding mask, flash-style on MFMA (d_head in {16, 64}).
+ * Replaces nn.MultiheadAttention's core (model.py:182-186): S = (q/sqrt(d)) k^T, pad keys -> -inf, softmax,
+ * dropout on the probabilities, P v -- without materialising (B, H, N, N).
+ *   qkv (B, N, 3E) = in-projection output [q | k | v], dtype = MFMA operand type (DX_BF16 or DX_F32)
+ *   o   (B, N, E) same dtype;  lse (B, H, N) fp32 log-sum-exp per query (NULL at inference)
+ * Queries n >= lengths[b] are not attended (their rows are zeroed by the following masked LayerNorm). */
+int dx_attention_fwd(const void* qkv, int dtype, const int64_t* lengths, void* o, float* lse, int B, int N,
+                     int H, int E, float p_drop, uint64_t seed, void* stream);
+
+/* Backward of dx_attention_fwd: dqkv (B, N, 3E) <- d_o (B, N, E).  delta_ws: (B, H, N) fp32 workspace. */
+int dx_attention_bwd(const void* qkv, const void* o, const void* d_o, int dtype, const float* lse,
+                     const int64_t* lengths, void* dqkv, float* delta_ws, int B, int N, int H, int E,
+                     float p_drop, uint64_t seed, void* stream);
+
+/* ---- K6: out = base + sum_f conv1d(1 -> 128, k=3)(feat_f) + pos_table[n], zero where n >= lengths[b].
+ * Energy / pitch embeddings + positional add + mask of the prosody encoder (model.py:400-414); the duration /
+ * energy / pitch projections of the upsampler (model.py:618-628).  feats / ws / biases are HOST arrays of
+ * nfeat (<= 3) device pointers: feat (B, N), w (128, 1, 3), bias (128).  base, pos_table, lengths may be NULL. */
+int dx_scalar_embed_fwd(const float* base, const float* const* feats, const float* const* ws,
+                        const float* const* biases, int nfeat, const float* pos_table, const int64_t* lengths,
+                        float* out, int B, int N, int C, void* stream);
+/* dbase = dout * mask (may be NULL); dws / dbiases are accumulated with atomics. */
+int dx_scalar_embed_bwd(const float* dout, const float* const* feats, int nfeat, const int64_t* lengths,
+                        float* dbase, float* const* dws, float* const* dbiases, int B, int N, int C, void* stream);
+
+/* ---- K7/K8: out[b, n] = table[ids[b, n]] + pos_table[n] for n < lengths[b], else 0 (model.py:497-504; the
+ * positional gather replaces the host loops of PositionalEncoding.forward, model.py:132-150). */
+int dx_embed_pos_fwd(const int64_t* ids, const float* table, const float* pos_table, const int64_t* lengths,
+                     float* out, int B, int N, int C, void* stream);
+int dx_embed_pos_bwd(const int64_t* ids, const float* dout, const int64_t* lengths, float* dtable, int B, int N, int C,
+                     void* stream);
+
+/* ---- K9: out[b] = sum_n x[b, n] / lengths[b] (model.py:419) and its backward. */
+int dx_masked_mean_fwd(const float* x, const int64_t* lengths, float* out, int B, int N, int C, void* stream);
+int dx_masked_mean_bwd(const float* dy, const int64_t* lengths, float* dx, int B, int N, int C, void* stream);
+
+/* ---- K9: FiLM assembly (model.py:430-462).  g_raw / b_raw (B, W) are the gammas / betas projections, W = sum_m
+ * nb[m] * ch[m] over the 3 FiLM-ed modules (encoder, predictor, decoder; nb / ch are HOST int[3]); post (2, sum nb)
+ * or NULL.  film_m (B, nb[m], 2 ch[m]) = [post_g * g + 1 | post_b * b]. */
+int dx_film_assemble_fwd(const float* g_raw, const float* b_raw, const float* post, float* film_enc, float* film_pp,
+                         float* film_dec, const int* nb, const int* ch, int B, void* stream);
+int dx_film_assemble_bwd(const float* g_raw, const float* b_raw, const float* post, const float* dfilm_enc,
+                         const float* dfilm_pp, const float* dfilm_dec, float* dg_raw, float* db_raw, float* dpost,
+                         const int* nb, const int* ch, int B, void* stream);
+
+/* ---- K10/K14: exact-fp32 nn.Linear for the small heads (VALU, no operand rounding): FiLM projections
+ * (model.py:427-428), speaker classifier (276-283), prosody projection 256 -> 3 (568-569), range projection
+ * (634).  x (M, K), w (O, K), y (M, O); rows with (m % N) >= mask_lengths[m / N] are zero when mask_lengths != NULL.
+ * Backward: dx = (dy * relu'(y)) W * dx_scale (NULL to skip; dx_scale = -lambda implements the gradient
+ * reversal of model.py:34-38); dw / db accumulated with atomics. */
+int dx_linear_small_fwd(const float* x, const float* w, const float* bias, float* y, const int64_t* mask_lengths,
+                        int N, long M, int K, int O, int relu, void* stream);
+int dx_linear_small_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float dx_scale,
+                        float* dw, float* db, const int64_t* mask_lengths, int N, long M, int K, int O, int relu,
+                        void* stream);
+
+/* out[b] = a[b] + table[ids[b]] (speaker-embedding add, model.py:423-424); backward scatter-adds dz into dtable. */
+int dx_gather_add_fwd(const float* a, const float* table, const int64_t* ids, float* out, int B, int C, void* stream);
+int dx_gather_add_bwd(const float* dz, const int64_t* ids, float* dtable, int B, int C, void* stream);
+
+int dx_add_inplace(float* dst, const float* src, long n, void* stream);           /* dst += src */
+int dx_colsum(const void* x, int dtype, float* out, long rows, int C, void* stream); /* out[c] += sum_r x[r][c] (bias grads) */
+int dx_scale(float* x, long n, float s, void* stream);
+
+/* ---- K11: Gaussian upsampling (GaussianUpsamplingModule.forward, model.py:608-662), fp32, integer prefix sums exact.
+ * dx_gu_prepare : xp = enc + conv(energy) + conv(pitch); rin = xp + conv(dur_float); r_pre = w_range . rin + b_range;
+ *                 ranges = softplus(r_pre), 1 at l >= in_lengths[b].  r_pre / rin may be NULL (inference).
+ * dx_gu_means   : means[l] = float(d[l]) / 2 + float(sum_{j<l} d[j]) from int64 durations; totals[b] = sum_l d.
+ * dx_gu_upsample_fwd : weights (B, L, T) and out (B, T, 128).  With pos_table != NULL the decoder's positional add +
+ *                 mask (model.py:696-701) is applied: out = (x_up + pos) where t < out_lengths[b], else 0. */
+int dx_gu_prepare(const float* enc, const float* dur_float, const float* energy, const float* pitch,
+                  const int64_t* in_lengths, const float* w_dur, const float* b_dur, const float* w_en,
+                  const float* b_en, const float* w_pi, const float* b_pi, const float* w_range,
+                  const float* b_range, float* xp, float* ranges, float* r_pre, float* rin, int B, int L,
+                  int C, void* stream);
+int dx_gu_means(const int64_t* durations_int, float* means, int64_t* totals, int B, int L, void* stream);
+int dx_gu_upsample_fwd(const float* xp, const float* ranges, const float* means, const int64_t* in_lengths,
+                       const int64_t* out_lengths, const float* pos_table, float* weights, float* out, int B,
+                       int L, int T, int C, void* stream);
+/* g = grad wrt `out`.  Outputs: dxp (grad wrt xp incl. the range path), drin (grad wrt rin), dr (B, L) grad wrt r_pre.
+ * dw_ws (B, L, T) and dsum_ws (B, T) are fp32 workspaces. */
+int dx_gu_upsample_bwd(const float* g, const float* xp, const float* weights, const float* means,
+                       const float* ranges, const float* r_pre, const float* w_range,
+                       const int64_t* in_lengths, const int64_t* out_lengths, float* dw_ws, float* dsum_ws,
+                       float* dxp, float* drin, float* dr, int B, int L, int T, int C, void* stream);
+
+/* ---- K13: the 7-term training loss and its gradients in one pass (DaftExprtLoss.forward, loss.py:54-99).
+ * terms (8 floats, device): speaker, post_mult, duration, energy, pitch, mel_l1, mel_l2 (weighted), total.
+ * mel / mel_t are (B, n_mel, T).  Gradient outputs (NULL to skip) are d(total * grad_scale)/d(pred);
+ * d_post_mult is ACCUMULATED.  w_spk is the ramped adversarial weight (loss.py:22-28). */
+int dx_loss_fwd_bwd(const float* dur, const float* energy, const float* pitch, const float* dur_t,
+                    const float* energy_t, const float* pitch_t, const int64_t* in_lengths, const float* mel,
+                    const float* mel_t, const int64_t* out_lengths, const float* spk_logits,
+                    const int64_t* spk_ids, const float* post_mult, float* d_dur, float* d_energy,
+                    float* d_pitch, float* d_mel, float* d_spk_logits, float* d_post_mult, float* terms,
+                    int B, int L, int T, int n_mel, int n_spk_classes, int n_post, float w_spk, float w_post,
+                    float w_dur, float w_energy, float w_pitch, float w_mel, float grad_scale,
+                    int d_mel_transposed /* write d_mel as (B, T, n_mel) */, void* stream);
+
+/* ---- K15: torch.optim.Adam as configured at train.py:299-301 (coupled L2, bias correction, amsgrad off) over a
+ * flat fp32 buffer; clip_grad_norm_ (train.py:399) folded in: grad_norm_sq (device scalar from dx_sumsq) and
+ * clip_thresh (INFINITY = log only). */
+int dx_sumsq(const float* x, long n, float* out, void* stream);
+int dx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int step, const float* grad_norm_sq, float clip_thresh,
+                 void* stream);
+
+/* ---- K16: float -> integer frame durations on the device (DaftExprt.get_int_durations model.py:789-812 +
+ * duration_to_integer extract_features.py:69-111): optional dur_factors multiply (model.py:891), in-place
+ * thresholding at filter_length / sampling_rate / 2, fp64 cumulative times, sample/frame counting in integers.
+ * status[b]: 0 ok, 1 = the reference would raise IndexError (utterance shorter than one analysis window),
+ * 2 = the reference's scatter would fail (symbol / duration count mismatch). */
+int dx_int_durations(float* duration_preds, const float* dur_factors, int64_t* durations_int, int64_t* totals, int* status, int B, int L,
+                     double sampling_rate, int filter_length, int hop_length, int centered, void* stream);
+
+/* Inference-time prosody control (model.py:895-905, pitch_shift 814-834, pitch_multiply 836-864), in place.
+ * mode 0 = 'add', 1 = 'multiply'. */
+int dx_prosody_control(float* energy, float* pitch, const float* energy_factors, const float* pitch_factors,
+                       const int64_t* durations_int, const int64_t* speaker_ids, const float* spk_pitch_mean,
+                       const float* spk_pitch_std, int mode, int B, int L, void* stream);
 
 #ifdef __cplusplus
 }

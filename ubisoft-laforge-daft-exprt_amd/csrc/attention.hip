@@ -1,0 +1,431 @@
+// K4 -- multi-head self-attention with key-padding mask, flash-style (never materialises (B,H,N,N)).
+//
+// Reference math (nn.MultiheadAttention as called at model.py:182-186):
+//   S = (q / sqrt(d_h)) k^T, S[:, pad keys] = -inf, P = softmax(S), P = dropout(P), o = P v
+// Layout: qkv (B, N, 3E) straight out of the in-projection GEMM (q | k | v, heads contiguous d_h wide),
+// o (B, N, E).  d_h in {16, 64}.
+//
+// MFMA formulation (32x32 tiles, wave64).  A workgroup = 4 waves; each wave owns 32 query rows (forward,
+// dQ kernel) or 32 key rows (dK/dV kernel) and walks the other axis in LDS-staged tiles of 64 rows.
+//   forward :  S^T = K Q^T  (lane = one query, 16 keys in registers -> softmax statistics are per-lane
+//              scalars + one lane^32 exchange);  O^T += V^T P^T  (P^T feeds the B operand straight from
+//              registers; the running-max rescale is a per-lane scalar multiply, no shuffles).
+//   dQ      :  S^T, dP^T = V dO^T the same way;  dQ^T += K^T dS^T.
+//   dK/dV   :  S = Q K^T, dP = dO V^T (lane = one key);  dV^T += dO^T P_drop,  dK^T += Q^T dS.
+// Operands that must be read "k-major" from a row-major LDS tile (V^T, K^T, dO^T, Q^T) use the gfx950
+// LDS transpose read ds_read_b64_tr_b16 (bf16) -- two reads give a lane its 8 k-values -- or eight
+// ds_read_b32 in the exact-fp32 mode.
+// Dropout on P: counter-based hash of (seed, (b, h, query, key)), regenerated in the backward kernels.
+#include "dx_common.h"
+
+namespace {
+
+
+struct AttnArgs {
+  const void* qkv;         // (B, N, 3E)
+  void* o;                 // (B, N, E)           fwd out / bwd in
+  float* lse;              // (B, H, N)           fwd out / bwd in
+  const void* d_o;         // (B, N, E)           bwd in
+  const float* delta;      // (B, H, N)           bwd in
+  void* dqkv;              // (B, N, 3E)          bwd out
+  const int64_t* lengths;
+  int N, H, E;
+  float scale, p_drop;
+  uint64_t seed;
+};
+
+template <typename TC> struct APad;
+template <> struct APad<bf16_t> { static constexpr int value = 8; };
+template <> struct APad<float> { static constexpr int value = 4; };
+
+template <typename TC> __device__ __forceinline__ float fast_exp(float x);
+template <> __device__ __forceinline__ float fast_exp<bf16_t>(float x) { return __expf(x); }
+template <> __device__ __forceinline__ float fast_exp<float>(float x) { return expf(x); }
+
+// stage `rows` rows x DH columns of a (.., ld_g)-strided global matrix into an LDS tile (zero beyond n_lim)
+template <typename TC, int DH, int LD>
+__device__ __forceinline__ void stage_tile(TC* dst, const TC* src, long ld_g, int row0, int rows, int n_lim, int tid) {
+  constexpr int CPR = DH / 8;  // 8-element chunks per row
+  for (int c = tid; c < rows * CPR; c += 256) {
+    const int r = c / CPR, kc = (c - r * CPR) * 8;
+    typename Vec8<TC>::type v = zero8<TC>();
+    if (row0 + r < n_lim) v = *reinterpret_cast<const typename Vec8<TC>::type*>(src + (long)(row0 + r) * ld_g + kc);
+    *reinterpret_cast<typename Vec8<TC>::type*>(dst + r * LD + kc) = v;
+  }
+}
+
+__device__ __forceinline__ uint32_t athresh(float p) { return p <= 0.f ? 0u : (uint32_t)(p * 4294967296.0); }
+
+constexpr int KT = 64;  // rows of the streamed axis per LDS stage
+
+// =============================================================================== forward
+template <typename TC, int DH>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  constexpr int LD = DH + APad<TC>::value, KS = DH / 16, MT = (DH + 31) / 32, WRAP = DH >= 32 ? 32 : 16;
+  typedef typename Vec8<TC>::type frag_t;
+  __shared__ __attribute__((aligned(16))) TC Ks[KT * LD];
+  __shared__ __attribute__((aligned(16))) TC Vs[KT * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, N = a.N, E = a.E;
+  const int len = (int)a.lengths[b];
+  const int q = blockIdx.x * 128 + wave * 32 + l31;
+  const long ld_g = 3L * E;
+  const TC* base = reinterpret_cast<const TC*>(a.qkv) + (long)b * N * ld_g + h * DH;
+  TC* O = reinterpret_cast<TC*>(a.o) + (long)b * N * E + h * DH;
+  float* lse = a.lse ? a.lse + ((long)b * a.H + h) * N : nullptr;
+
+  if (blockIdx.x * 128 >= len) {  // whole tile of pad queries: their rows are zeroed after the LayerNorm anyway
+    if (q < N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = dx_acc_row(r, g);
+        if (d < DH) for (int mt = 0; mt < MT; ++mt) O[(long)q * E + mt * 32 + d] = (TC)0.f;
+      }
+      if (lse && g == 0) lse[q] = 0.f;
+    }
+    return;
+  }
+
+  frag_t qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    qf[ks] = q < N ? *reinterpret_cast<const frag_t*>(base + (long)q * ld_g + ks * 16 + g * 8) : zero8<TC>();
+
+  f32x16 oT[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oT[mt][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const uint32_t th = athresh(a.p_drop);
+  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  const uint64_t drop_row = (((uint64_t)b * a.H + h) * N + (uint64_t)q) * N;
+
+  for (int kt0 = 0; kt0 < len; kt0 += KT) {
+    stage_tile<TC, DH, LD>(Ks, base + E, ld_g, kt0, KT, N, tid);
+    stage_tile<TC, DH, LD>(Vs, base + 2 * E, ld_g, kt0, KT, N, tid);
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < KT / 32; ++sub) {
+      const int k0 = kt0 + sub * 32;
+      if (k0 < len) {
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          frag_t kf = *reinterpret_cast<const frag_t*>(&Ks[(sub * 32 + l31) * LD + ks * 16 + g * 8]);
+          dx_mma(s, kf, qf[ks]);
+        }
+        float p[16], mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + dx_acc_row(r, g);
+          p[r] = key < len ? s[r] * a.scale : -INFINITY;
+          mx = fmaxf(mx, p[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = fast_exp<TC>(m - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { p[r] = fast_exp<TC>(p[r] - m_new); rs += p[r]; }
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * alpha + rs;
+        m = m_new;
+        if (th) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            p[r] = dx_keep(a.seed, drop_row + (uint64_t)(k0 + dx_acc_row(r, g)), th) ? p[r] * inv_keep : 0.f;
+        }
+        frag_t pf[2] = {pack8<TC>(p), pack8<TC>(p + 8)};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oT[mt][r] *= alpha;
+#pragma unroll
+          for (int kstep = 0; kstep < 2; ++kstep) {
+            frag_t vf = gather8<TC, WRAP>(Vs + sub * 32 * LD, LD, kstep * 16 + 4 * g, kstep * 16 + 4 * g + 8, mt * 32, lane);
+            dx_mma(oT[mt], vf, pf[kstep]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (q < N) {
+    const float inv_l = 1.f / l;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int d0 = 8 * r4 + 4 * g;  // rows d0..d0+3 = registers 4*r4 .. 4*r4+3
+        if (mt * 32 + d0 < DH) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) O[(long)q * E + mt * 32 + d0 + t] = (TC)(oT[mt][r4 * 4 + t] * inv_l);
+        }
+      }
+    }
+    if (lse && g == 0) lse[q] = m + logf(l);
+  }
+}
+
+// =============================================================================== delta = rowsum(dO * O)
+template <typename TC>
+__global__ void attn_delta_kernel(const TC* __restrict__ o, const TC* __restrict__ d_o, float* __restrict__ delta,
+                                  int B, int N, int H, int DH) {
+  const long total = (long)B * N * H;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int h = i % H; const long bn = i / H; const int n = bn % N; const int b = bn / N;
+    const TC* po = o + bn * (long)(H * DH) + h * DH;
+    const TC* pd = d_o + bn * (long)(H * DH) + h * DH;
+    float acc = 0.f;
+    for (int d = 0; d < DH; ++d) acc += (float)po[d] * (float)pd[d];
+    delta[((long)b * H + h) * N + n] = acc;
+  }
+}
+
+// =============================================================================== backward: dQ
+template <typename TC, int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+  constexpr int LD = DH + APad<TC>::value, KS = DH / 16, MT = (DH + 31) / 32, WRAP = DH >= 32 ? 32 : 16;
+  typedef typename Vec8<TC>::type frag_t;
+  __shared__ __attribute__((aligned(16))) TC Ks[KT * LD];
+  __shared__ __attribute__((aligned(16))) TC Vs[KT * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, N = a.N, E = a.E;
+  const int len = (int)a.lengths[b];
+  const int q = blockIdx.x * 128 + wave * 32 + l31;
+  const long ld_g = 3L * E;
+  const TC* base = reinterpret_cast<const TC*>(a.qkv) + (long)b * N * ld_g + h * DH;
+  const TC* dO = reinterpret_cast<const TC*>(a.d_o) + (long)b * N * E + h * DH;
+  TC* dQ = reinterpret_cast<TC*>(a.dqkv) + (long)b * N * ld_g + h * DH;
+  const bool q_valid = q < len;
+
+  f32x16 dqT[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqT[mt][r] = 0.f;
+
+  if (blockIdx.x * 128 < len) {
+    frag_t qf[KS], dof[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[ks] = q < N ? *reinterpret_cast<const frag_t*>(base + (long)q * ld_g + ks * 16 + g * 8) : zero8<TC>();
+      dof[ks] = q < N ? *reinterpret_cast<const frag_t*>(dO + (long)q * E + ks * 16 + g * 8) : zero8<TC>();
+    }
+    const long stat = ((long)b * a.H + h) * N + q;
+    const float lse_q = q < N ? a.lse[stat] : 0.f, delta_q = q < N ? a.delta[stat] : 0.f;
+    const uint32_t th = athresh(a.p_drop);
+    const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+    const uint64_t drop_row = (((uint64_t)b * a.H + h) * N + (uint64_t)q) * N;
+
+    for (int kt0 = 0; kt0 < len; kt0 += KT) {
+      stage_tile<TC, DH, LD>(Ks, base + E, ld_g, kt0, KT, N, tid);
+      stage_tile<TC, DH, LD>(Vs, base + 2 * E, ld_g, kt0, KT, N, tid);
+      __syncthreads();
+#pragma unroll
+      for (int sub = 0; sub < KT / 32; ++sub) {
+        const int k0 = kt0 + sub * 32;
+        if (k0 < len) {
+          f32x16 s, dp;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            frag_t kf = *reinterpret_cast<const frag_t*>(&Ks[(sub * 32 + l31) * LD + ks * 16 + g * 8]);
+            frag_t vf = *reinterpret_cast<const frag_t*>(&Vs[(sub * 32 + l31) * LD + ks * 16 + g * 8]);
+            dx_mma(s, kf, qf[ks]);
+            dx_mma(dp, vf, dof[ks]);
+          }
+          float ds[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = k0 + dx_acc_row(r, g);
+            const float p = (q_valid && key < len) ? fast_exp<TC>(s[r] * a.scale - lse_q) : 0.f;
+            float kscale = 1.f;
+            if (th) kscale = dx_keep(a.seed, drop_row + (uint64_t)key, th) ? inv_keep : 0.f;
+            ds[r] = p * (dp[r] * kscale - delta_q);
+          }
+          frag_t dsf[2] = {pack8<TC>(ds), pack8<TC>(ds + 8)};
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int kstep = 0; kstep < 2; ++kstep) {
+              frag_t kT = gather8<TC, WRAP>(Ks + sub * 32 * LD, LD, kstep * 16 + 4 * g, kstep * 16 + 4 * g + 8, mt * 32, lane);
+              dx_mma(dqT[mt], kT, dsf[kstep]);
+            }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (q < N) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = mt * 32 + dx_acc_row(r, g);
+        if (d < DH) dQ[(long)q * ld_g + d] = (TC)(dqT[mt][r] * a.scale);
+      }
+  }
+}
+
+// =============================================================================== backward: dK, dV
+template <typename TC, int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+  constexpr int LD = DH + APad<TC>::value, KS = DH / 16, MT = (DH + 31) / 32, WRAP = DH >= 32 ? 32 : 16;
+  typedef typename Vec8<TC>::type frag_t;
+  __shared__ __attribute__((aligned(16))) TC Qs[KT * LD];
+  __shared__ __attribute__((aligned(16))) TC dOs[KT * LD];
+  __shared__ float lse_s[KT], delta_s[KT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, N = a.N, E = a.E;
+  const int len = (int)a.lengths[b];
+  const int key = blockIdx.x * 128 + wave * 32 + l31;
+  const long ld_g = 3L * E;
+  const TC* base = reinterpret_cast<const TC*>(a.qkv) + (long)b * N * ld_g + h * DH;
+  const TC* dO = reinterpret_cast<const TC*>(a.d_o) + (long)b * N * E + h * DH;
+  TC* dK = reinterpret_cast<TC*>(a.dqkv) + (long)b * N * ld_g + E + h * DH;
+  TC* dV = dK + E;
+  const float* lse = a.lse + ((long)b * a.H + h) * N;
+  const float* delta = a.delta + ((long)b * a.H + h) * N;
+  const bool key_valid = key < len;
+
+  f32x16 dvT[MT], dkT[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dvT[mt][r] = 0.f; dkT[mt][r] = 0.f; }
+
+  if (blockIdx.x * 128 < len) {
+    frag_t kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      kf[ks] = key < N ? *reinterpret_cast<const frag_t*>(base + E + (long)key * ld_g + ks * 16 + g * 8) : zero8<TC>();
+      vf[ks] = key < N ? *reinterpret_cast<const frag_t*>(base + 2 * E + (long)key * ld_g + ks * 16 + g * 8) : zero8<TC>();
+    }
+    const uint32_t th = athresh(a.p_drop);
+    const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+    const uint64_t drop_bh = ((uint64_t)b * a.H + h) * N;
+
+    for (int qt0 = 0; qt0 < len; qt0 += KT) {
+      stage_tile<TC, DH, LD>(Qs, base, ld_g, qt0, KT, N, tid);
+      stage_tile<TC, DH, LD>(dOs, dO, E, qt0, KT, N, tid);
+      if (tid < KT) {
+        const int qq = qt0 + tid;
+        lse_s[tid] = qq < N ? lse[qq] : 0.f;
+        delta_s[tid] = qq < N ? delta[qq] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int sub = 0; sub < KT / 32; ++sub) {
+        const int qb = qt0 + sub * 32;
+        if (qb < len) {
+          f32x16 s, dp;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            frag_t qf = *reinterpret_cast<const frag_t*>(&Qs[(sub * 32 + l31) * LD + ks * 16 + g * 8]);
+            frag_t dof = *reinterpret_cast<const frag_t*>(&dOs[(sub * 32 + l31) * LD + ks * 16 + g * 8]);
+            dx_mma(s, qf, kf[ks]);    // S[q][key]: lane = key column, registers = queries
+            dx_mma(dp, dof, vf[ks]);  // dP[q][key]
+          }
+          float pd[16], ds[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = sub * 32 + dx_acc_row(r, g);
+            const int qq = qt0 + row;
+            const float p = (key_valid && qq < len) ? fast_exp<TC>(s[r] * a.scale - lse_s[row]) : 0.f;
+            float kscale = 1.f;
+            if (th) kscale = dx_keep(a.seed, (drop_bh + (uint64_t)qq) * N + (uint64_t)key, th) ? inv_keep : 0.f;
+            pd[r] = p * kscale;
+            ds[r] = p * (dp[r] * kscale - delta_s[row]);
+          }
+          frag_t pf[2] = {pack8<TC>(pd), pack8<TC>(pd + 8)};
+          frag_t dsf[2] = {pack8<TC>(ds), pack8<TC>(ds + 8)};
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int kstep = 0; kstep < 2; ++kstep) {
+              const int kA = kstep * 16 + 4 * g;
+              frag_t doT = gather8<TC, WRAP>(dOs + sub * 32 * LD, LD, kA, kA + 8, mt * 32, lane);
+              dx_mma(dvT[mt], doT, pf[kstep]);
+              frag_t qT = gather8<TC, WRAP>(Qs + sub * 32 * LD, LD, kA, kA + 8, mt * 32, lane);
+              dx_mma(dkT[mt], qT, dsf[kstep]);
+            }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (key < N) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = mt * 32 + dx_acc_row(r, g);
+        if (d < DH) {
+          dV[(long)key * ld_g + d] = (TC)dvT[mt][r];
+          dK[(long)key * ld_g + d] = (TC)(dkT[mt][r] * a.scale);
+        }
+      }
+  }
+}
+
+template <typename TC>
+int launch_fwd(const AttnArgs& a, int B, int dh, hipStream_t s) {
+  dim3 grid(dx_cdiv(a.N, 128), a.H, B), block(256);
+  if (dh == 16) hipLaunchKernelGGL((attn_fwd_kernel<TC, 16>), grid, block, 0, s, a);
+  else if (dh == 64) hipLaunchKernelGGL((attn_fwd_kernel<TC, 64>), grid, block, 0, s, a);
+  else { dx_set_error("attention: head dim %d unsupported (16, 64)", dh); return DX_ERR_UNSUPPORTED; }
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+template <typename TC>
+int launch_bwd(const AttnArgs& a, int B, int dh, float* delta, hipStream_t s) {
+  dim3 grid(dx_cdiv(a.N, 128), a.H, B), block(256);
+  const long total = (long)B * a.N * a.H;
+  const int dgrid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL((attn_delta_kernel<TC>), dim3(dgrid), dim3(256), 0, s, (const TC*)a.o, (const TC*)a.d_o, delta, B, a.N, a.H, dh);
+  if (dh == 16) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, 16>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<TC, 16>), grid, block, 0, s, a);
+  } else if (dh == 64) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, 64>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<TC, 64>), grid, block, 0, s, a);
+  } else { dx_set_error("attention: head dim %d unsupported (16, 64)", dh); return DX_ERR_UNSUPPORTED; }
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+}  // namespace
+
+extern "C" int dx_attention_fwd(const void* qkv, int dtype, const int64_t* lengths, void* o, float* lse, int B, int N,
+                                int H, int E, float p_drop, uint64_t seed, void* stream) {
+  DX_REQUIRE(qkv && lengths && o, DX_ERR_ARG, "dx_attention_fwd: null pointer");
+  DX_REQUIRE(B > 0 && N > 0 && H > 0 && E % H == 0, DX_ERR_SHAPE, "dx_attention_fwd: bad shape B=%d N=%d H=%d E=%d", B, N, H, E);
+  DX_REQUIRE(p_drop >= 0.f && p_drop < 1.f, DX_ERR_ARG, "dx_attention_fwd: dropout p out of [0,1)");
+  const int dh = E / H;
+  AttnArgs a{qkv, o, lse, nullptr, nullptr, nullptr, lengths, N, H, E, 1.f / sqrtf((float)dh), p_drop, seed};
+  if (dtype == DX_BF16) return launch_fwd<bf16_t>(a, B, dh, (hipStream_t)stream);
+  if (dtype == DX_F32) return launch_fwd<float>(a, B, dh, (hipStream_t)stream);
+  dx_set_error("dx_attention_fwd: bad dtype %d", dtype);
+  return DX_ERR_DTYPE;
+}
+
+extern "C" int dx_attention_bwd(const void* qkv, const void* o, const void* d_o, int dtype, const float* lse,
+                                const int64_t* lengths, void* dqkv, float* delta_ws, int B, int N, int H, int E,
+                                float p_drop, uint64_t seed, void* stream) {
+  DX_REQUIRE(qkv && o && d_o && lse && lengths && dqkv && delta_ws, DX_ERR_ARG, "dx_attention_bwd: null pointer");
+  DX_REQUIRE(B > 0 && N > 0 && H > 0 && E % H == 0, DX_ERR_SHAPE, "dx_attention_bwd: bad shape");
+  const int dh = E / H;
+  AttnArgs a{qkv, const_cast<void*>(o), const_cast<float*>(lse), d_o, delta_ws, dqkv, lengths, N, H, E,
+             1.f / sqrtf((float)dh), p_drop, seed};
+  if (dtype == DX_BF16) return launch_bwd<bf16_t>(a, B, dh, delta_ws, (hipStream_t)stream);
+  if (dtype == DX_F32) return launch_bwd<float>(a, B, dh, delta_ws, (hipStream_t)stream);
+  dx_set_error("dx_attention_bwd: bad dtype %d", dtype);
+  return DX_ERR_DTYPE;
+}

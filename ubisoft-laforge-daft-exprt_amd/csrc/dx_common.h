@@ -105,6 +105,67 @@ __device__ __forceinline__ float dx_wave_max(float v) {
   return v;
 }
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// k-major gather from a row-major tile: lane gets column c = col0 + (lane & 31) % WRAP and the 8 rows
+// {kA..kA+3, kB..kB+3}.
+template <typename TC, int WRAP>
+__device__ __forceinline__ typename Vec8<TC>::type gather8(const TC* tile, int ld, int kA, int kB, int col0, int lane);
+
+template <>
+__device__ __forceinline__ bf16x8 gather8<bf16_t, 32>(const bf16_t* tile, int ld, int kA, int kB, int col0, int lane) {
+  const int i = lane & 15, half = (lane >> 4) & 1, j = i >> 2, q = i & 3;
+  const bf16_t* pa = tile + (kA + j) * ld + col0 + 16 * half + 4 * q;
+  const bf16_t* pb = tile + (kB + j) * ld + col0 + 16 * half + 4 * q;
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+template <>
+__device__ __forceinline__ bf16x8 gather8<bf16_t, 16>(const bf16_t* tile, int ld, int kA, int kB, int col0, int lane) {
+  const int i = lane & 15, j = i >> 2, q = i & 3;
+  const bf16_t* pa = tile + (kA + j) * ld + col0 + 4 * q;
+  const bf16_t* pb = tile + (kB + j) * ld + col0 + 4 * q;
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+template <>
+__device__ __forceinline__ f32x8 gather8<float, 32>(const float* tile, int ld, int kA, int kB, int col0, int lane) {
+  const int c = col0 + (lane & 31);
+  f32x8 r;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { r[t] = tile[(kA + t) * ld + c]; r[4 + t] = tile[(kB + t) * ld + c]; }
+  return r;
+}
+template <>
+__device__ __forceinline__ f32x8 gather8<float, 16>(const float* tile, int ld, int kA, int kB, int col0, int lane) {
+  const int c = col0 + (lane & 15);
+  f32x8 r;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { r[t] = tile[(kA + t) * ld + c]; r[4 + t] = tile[(kB + t) * ld + c]; }
+  return r;
+}
+
+template <typename TC>
+__device__ __forceinline__ typename Vec8<TC>::type zero8() {
+  typename Vec8<TC>::type v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (TC)0.f;
+  return v;
+}
+template <typename TC>
+__device__ __forceinline__ typename Vec8<TC>::type pack8(const float* p) {
+  typename Vec8<TC>::type v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (TC)p[e];
+  return v;
+}
+
 // Counter-based dropout RNG: one 32-bit hash per element index.  keep iff hash >= p * 2^32.
 // (Bit-parity with torch's Philox stream is not a goal -- SURVEY section 7; the forward and
 // backward passes regenerate the same mask from (seed, element index).)

@@ -1,0 +1,320 @@
+// K5 -- LayerNorm over the channel axis of channel-last rows, fused with its neighbours:
+//
+//   s = dropout_pre(x) + residual           (attention / FF output path, model.py:189-191, 226-228)
+//   y = ((s - mean) * rstd) * gamma + beta  (eps 1e-5, biased variance)
+//   y = dropout_post(y)                     (prenet / predictor: conv -> ReLU -> LN -> Dropout, model.py:341-363, 528-543)
+//   y = film_gamma[b] * y + film_beta[b]    (FiLM, model.py:230-235, 558-564)
+//   y = 0 where n >= lengths[b]             (masked_fill, model.py:259, 262, 414, 566)
+//
+// One wave per row; a lane owns C/64 channels in 16-byte groups (coalesced float4 / bf16x4 accesses);
+// statistics are fp32 wave reductions.  HBM-bound: reads x (+residual) once, writes y (+s, mean, rstd for
+// the backward pass) once.  The backward kernel walks a contiguous slab of rows of ONE utterance per
+// workgroup so that the per-channel reductions (dgamma, dbeta, dFiLM) stay in registers and cost one
+// atomic per channel per workgroup.
+#include "dx_common.h"
+
+namespace {
+
+struct LNArgs {
+  const void* x; const float* res; const float* gamma; const float* beta;
+  const float* film; long ldf;        // film row b: [gamma(C) | beta(C)], rows ldf apart
+  const int64_t* lengths;
+  void* y; float* s_out; float* mean; float* rstd;
+  int N; long rows;
+  float p_pre, p_post; uint64_t seed_pre, seed_post;
+};
+
+template <int C>
+struct Lay {
+  static constexpr int EPL = C / 64;                 // elements per lane
+  static constexpr int V = EPL >= 4 ? 4 : EPL;       // vector width
+  static constexpr int NV = EPL / V;                 // vectors per lane
+  __device__ static __forceinline__ int col(int lane, int v) { return v * 64 * V + lane * V; }
+};
+
+template <typename T, int V>
+__device__ __forceinline__ void load_vec(const T* p, float* out) {
+#pragma unroll
+  for (int i = 0; i < V; ++i) out[i] = (float)p[i];
+}
+template <>
+__device__ __forceinline__ void load_vec<float, 4>(const float* p, float* out) {
+  f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+}
+template <>
+__device__ __forceinline__ void load_vec<bf16_t, 4>(const bf16_t* p, float* out) {
+  bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  out[0] = (float)v[0]; out[1] = (float)v[1]; out[2] = (float)v[2]; out[3] = (float)v[3];
+}
+template <typename T, int V>
+__device__ __forceinline__ void store_vec(T* p, const float* in) {
+#pragma unroll
+  for (int i = 0; i < V; ++i) p[i] = (T)in[i];
+}
+template <>
+__device__ __forceinline__ void store_vec<float, 4>(float* p, const float* in) {
+  f32x4 v = {in[0], in[1], in[2], in[3]};
+  *reinterpret_cast<f32x4*>(p) = v;
+}
+template <>
+__device__ __forceinline__ void store_vec<bf16_t, 4>(bf16_t* p, const float* in) {
+  bf16x4 v = {(bf16_t)in[0], (bf16_t)in[1], (bf16_t)in[2], (bf16_t)in[3]};
+  *reinterpret_cast<bf16x4*>(p) = v;
+}
+
+__device__ __forceinline__ uint32_t drop_thresh(float p) { return p <= 0.f ? 0u : (uint32_t)(p * 4294967296.0); }
+
+template <typename TI, typename TO, int C>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
+  typedef Lay<C> L;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const int b = (int)(row / a.N), n = (int)(row - (long)b * a.N);
+  const TI* x = reinterpret_cast<const TI*>(a.x) + row * C;
+  float v[L::EPL];
+  const uint32_t th_pre = drop_thresh(a.p_pre);
+  const float sc_pre = a.p_pre > 0.f ? 1.f / (1.f - a.p_pre) : 1.f;
+#pragma unroll
+  for (int k = 0; k < L::NV; ++k) {
+    const int c0 = L::col(lane, k);
+    load_vec<TI, L::V>(x + c0, v + k * L::V);
+    if (th_pre) {
+#pragma unroll
+      for (int i = 0; i < L::V; ++i)
+        v[k * L::V + i] = dx_keep(a.seed_pre, (uint64_t)row * C + c0 + i, th_pre) ? v[k * L::V + i] * sc_pre : 0.f;
+    }
+    if (a.res) {
+      float r[L::V];
+      load_vec<float, L::V>(a.res + row * C + c0, r);
+#pragma unroll
+      for (int i = 0; i < L::V; ++i) v[k * L::V + i] += r[i];
+    }
+    if (a.s_out) store_vec<float, L::V>(a.s_out + row * C + c0, v + k * L::V);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < L::EPL; ++i) sum += v[i];
+  const float mean = dx_wave_sum(sum) * (1.f / C);
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < L::EPL; ++i) { const float d = v[i] - mean; sq += d * d; }
+  const float rstd = rsqrtf(dx_wave_sum(sq) * (1.f / C) + 1e-5f);
+  if (a.mean && lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+  const bool pad = a.lengths && n >= (int)a.lengths[b];
+  const uint32_t th_post = drop_thresh(a.p_post);
+  const float sc_post = a.p_post > 0.f ? 1.f / (1.f - a.p_post) : 1.f;
+  TO* y = reinterpret_cast<TO*>(a.y) + row * C;
+#pragma unroll
+  for (int k = 0; k < L::NV; ++k) {
+    const int c0 = L::col(lane, k);
+    float g[L::V], bt[L::V], o[L::V];
+    load_vec<float, L::V>(a.gamma + c0, g);
+    load_vec<float, L::V>(a.beta + c0, bt);
+#pragma unroll
+    for (int i = 0; i < L::V; ++i) {
+      float t = (v[k * L::V + i] - mean) * rstd * g[i] + bt[i];
+      if (th_post) t = dx_keep(a.seed_post, (uint64_t)row * C + c0 + i, th_post) ? t * sc_post : 0.f;
+      o[i] = t;
+    }
+    if (a.film) {
+      float fg[L::V], fb[L::V];
+      load_vec<float, L::V>(a.film + (long)b * a.ldf + c0, fg);
+      load_vec<float, L::V>(a.film + (long)b * a.ldf + C + c0, fb);
+#pragma unroll
+      for (int i = 0; i < L::V; ++i) o[i] = fg[i] * o[i] + fb[i];
+    }
+    if (pad) {
+#pragma unroll
+      for (int i = 0; i < L::V; ++i) o[i] = 0.f;
+    }
+    store_vec<TO, L::V>(y + c0, o);
+  }
+}
+
+struct LNBwdArgs {
+  const void* dy;            // grad wrt the kernel's output y, dtype TG, (rows, C)
+  const void* s;             // the normalised tensor's input: s_out of the forward (fp32) or the raw x (TI)
+  const float* mean; const float* rstd; const float* gamma; const float* beta;
+  const float* film; long ldf; const int64_t* lengths;
+  void* ds;                  // out: grad wrt s (dtype TD) -- also the residual gradient
+  void* dx_pre;              // out (nullable): grad wrt x before dropout_pre (dtype TD); only when p_pre > 0
+  float* dgamma; float* dbeta;          // (C) accumulated with atomics
+  float* dfilm; long lddf;              // (B, 2C) accumulated with atomics (nullable)
+  int N; int B; int rows_per_block;
+  float p_pre, p_post; uint64_t seed_pre, seed_post;
+  int relu_input;            // s = relu(conv): the returned ds is additionally gated by (s > 0)
+};
+
+// grid = (ceil(N / rows_per_block), B); 4 waves per block, wave w handles rows w, w+4, ... of the slab
+template <typename TI, typename TG, typename TD, int C>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
+  typedef Lay<C> L;
+  __shared__ float red[4][4][C];  // [wave][dgamma, dbeta, dfilm_g, dfilm_b][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int n_begin = blockIdx.x * a.rows_per_block;
+  const int n_end = min(a.N, n_begin + a.rows_per_block);
+  const int len = a.lengths ? (int)a.lengths[b] : a.N;
+  const uint32_t th_pre = drop_thresh(a.p_pre), th_post = drop_thresh(a.p_post);
+  const float sc_pre = a.p_pre > 0.f ? 1.f / (1.f - a.p_pre) : 1.f;
+  const float sc_post = a.p_post > 0.f ? 1.f / (1.f - a.p_post) : 1.f;
+
+  float gam[L::EPL], bet[L::EPL], fg[L::EPL];
+  float acc_g[L::EPL], acc_b[L::EPL], acc_fg[L::EPL], acc_fb[L::EPL];
+#pragma unroll
+  for (int k = 0; k < L::NV; ++k) {
+    const int c0 = L::col(lane, k);
+    load_vec<float, L::V>(a.gamma + c0, gam + k * L::V);
+    load_vec<float, L::V>(a.beta + c0, bet + k * L::V);
+    if (a.film) load_vec<float, L::V>(a.film + (long)b * a.ldf + c0, fg + k * L::V);
+  }
+#pragma unroll
+  for (int i = 0; i < L::EPL; ++i) { acc_g[i] = acc_b[i] = acc_fg[i] = acc_fb[i] = 0.f; if (!a.film) fg[i] = 1.f; }
+
+  for (int n = n_begin + wave; n < n_end; n += 4) {
+    const long row = (long)b * a.N + n;
+    const TG* dy = reinterpret_cast<const TG*>(a.dy) + row * C;
+    const TI* s = reinterpret_cast<const TI*>(a.s) + row * C;
+    const float mean = a.mean[row], rstd = a.rstd[row];
+    float g[L::EPL], xh[L::EPL];
+    bool pos[L::EPL];
+    const bool pad = n >= len;
+#pragma unroll
+    for (int k = 0; k < L::NV; ++k) {
+      const int c0 = L::col(lane, k);
+      load_vec<TG, L::V>(dy + c0, g + k * L::V);
+      load_vec<TI, L::V>(s + c0, xh + k * L::V);
+    }
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < L::NV; ++k) {
+#pragma unroll
+      for (int i = 0; i < L::V; ++i) {
+        const int j = k * L::V + i;
+        const int c = L::col(lane, k) + i;
+        float gy = pad ? 0.f : g[j];
+        pos[j] = xh[j] > 0.f;
+        xh[j] = (xh[j] - mean) * rstd;
+        float ln = xh[j] * gam[j] + bet[j];                 // LayerNorm output before dropout_post / FiLM
+        float keep_post = 1.f;
+        if (th_post) keep_post = dx_keep(a.seed_post, (uint64_t)row * C + c, th_post) ? sc_post : 0.f;
+        if (a.film) {                                       // y = fg * (ln * keep) + fb
+          acc_fg[j] += gy * ln * keep_post;
+          acc_fb[j] += gy;
+        }
+        gy = gy * fg[j] * keep_post;                        // grad wrt ln
+        acc_g[j] += gy * xh[j];
+        acc_b[j] += gy;
+        const float gx = gy * gam[j];
+        g[j] = gx;
+        m1 += gx;
+        m2 += gx * xh[j];
+      }
+    }
+    m1 = dx_wave_sum(m1) * (1.f / C);
+    m2 = dx_wave_sum(m2) * (1.f / C);
+    TD* ds = reinterpret_cast<TD*>(a.ds) + row * C;
+    TD* dxp = a.dx_pre ? reinterpret_cast<TD*>(a.dx_pre) + row * C : nullptr;
+#pragma unroll
+    for (int k = 0; k < L::NV; ++k) {
+      const int c0 = L::col(lane, k);
+      float o[L::V], o2[L::V];
+#pragma unroll
+      for (int i = 0; i < L::V; ++i) {
+        const int j = k * L::V + i;
+        o[i] = rstd * (g[j] - m1 - xh[j] * m2);
+        if (a.relu_input && !pos[j]) o[i] = 0.f;
+        o2[i] = o[i];
+        if (th_pre) o2[i] = dx_keep(a.seed_pre, (uint64_t)row * C + c0 + i, th_pre) ? o[i] * sc_pre : 0.f;
+      }
+      store_vec<TD, L::V>(ds + c0, o);
+      if (dxp) store_vec<TD, L::V>(dxp + c0, o2);
+    }
+  }
+  // ---- reduce the per-channel partials over the 4 waves, one atomic per channel per block
+#pragma unroll
+  for (int k = 0; k < L::NV; ++k) {
+#pragma unroll
+    for (int i = 0; i < L::V; ++i) {
+      const int j = k * L::V + i, c = L::col(lane, k) + i;
+      red[wave][0][c] = acc_g[j]; red[wave][1][c] = acc_b[j]; red[wave][2][c] = acc_fg[j]; red[wave][3][c] = acc_fb[j];
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 4 * C; idx += 256) {
+    const int which = idx / C, c = idx - which * C;
+    const float t = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+    if (which == 0) atomicAdd(a.dgamma + c, t);
+    else if (which == 1) atomicAdd(a.dbeta + c, t);
+    else if (a.dfilm) atomicAdd(a.dfilm + (long)b * a.lddf + (which == 3 ? C : 0) + c, t);
+  }
+}
+
+template <typename TI, typename TO>
+int launch_fwd(const LNArgs& a, int C, hipStream_t s) {
+  dim3 grid((unsigned)((a.rows + 3) / 4)), block(256);
+  switch (C) {
+    case 128: hipLaunchKernelGGL((ln_fwd_kernel<TI, TO, 128>), grid, block, 0, s, a); break;
+    case 256: hipLaunchKernelGGL((ln_fwd_kernel<TI, TO, 256>), grid, block, 0, s, a); break;
+    case 1024: hipLaunchKernelGGL((ln_fwd_kernel<TI, TO, 1024>), grid, block, 0, s, a); break;
+    default: dx_set_error("dx_layernorm_fwd: C=%d unsupported (128, 256, 1024)", C); return DX_ERR_UNSUPPORTED;
+  }
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+template <typename TI, typename TG, typename TD>
+int launch_bwd(const LNBwdArgs& a, int C, hipStream_t s) {
+  dim3 grid(dx_cdiv(a.N, a.rows_per_block), a.B), block(256);
+  switch (C) {
+    case 128: hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 128>), grid, block, 0, s, a); break;
+    case 256: hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 256>), grid, block, 0, s, a); break;
+    case 1024: hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 1024>), grid, block, 0, s, a); break;
+    default: dx_set_error("dx_layernorm_bwd: C=%d unsupported (128, 256, 1024)", C); return DX_ERR_UNSUPPORTED;
+  }
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+}  // namespace
+
+extern "C" int dx_layernorm_fwd(const void* x, int x_dtype, const float* residual, const float* gamma, const float* beta,
+                                const float* film, long ldf, const int64_t* lengths, void* y, int y_dtype, float* s_out,
+                                float* mean, float* rstd, int B, int N, int C, float p_pre, uint64_t seed_pre,
+                                float p_post, uint64_t seed_post, void* stream) {
+  DX_REQUIRE(x && gamma && beta && y, DX_ERR_ARG, "dx_layernorm_fwd: null pointer");
+  DX_REQUIRE(B > 0 && N > 0, DX_ERR_SHAPE, "dx_layernorm_fwd: empty shape");
+  DX_REQUIRE((mean == nullptr) == (rstd == nullptr), DX_ERR_ARG, "dx_layernorm_fwd: mean and rstd come together");
+  DX_REQUIRE(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, DX_ERR_ARG, "dx_layernorm_fwd: dropout p out of [0,1)");
+  LNArgs a{x, residual, gamma, beta, film, ldf, lengths, y, s_out, mean, rstd, N, (long)B * N, p_pre, p_post, seed_pre, seed_post};
+  hipStream_t s = (hipStream_t)stream;
+  if (x_dtype == DX_F32 && y_dtype == DX_F32) return launch_fwd<float, float>(a, C, s);
+  if (x_dtype == DX_BF16 && y_dtype == DX_BF16) return launch_fwd<bf16_t, bf16_t>(a, C, s);
+  if (x_dtype == DX_BF16 && y_dtype == DX_F32) return launch_fwd<bf16_t, float>(a, C, s);
+  if (x_dtype == DX_F32 && y_dtype == DX_BF16) return launch_fwd<float, bf16_t>(a, C, s);
+  dx_set_error("dx_layernorm_fwd: unsupported dtypes x=%d y=%d", x_dtype, y_dtype);
+  return DX_ERR_DTYPE;
+}
+
+extern "C" int dx_layernorm_bwd(const void* dy, int dy_dtype, const void* s_in, int s_dtype, const float* mean,
+                                const float* rstd, const float* gamma, const float* beta, const float* film, long ldf,
+                                const int64_t* lengths, void* ds, void* dx_pre, int d_dtype, float* dgamma, float* dbeta,
+                                float* dfilm, long lddf, int B, int N, int C, float p_pre, uint64_t seed_pre,
+                                float p_post, uint64_t seed_post, int relu_input, void* stream) {
+  DX_REQUIRE(dy && s_in && mean && rstd && gamma && beta && ds && dgamma && dbeta, DX_ERR_ARG, "dx_layernorm_bwd: null pointer");
+  DX_REQUIRE(B > 0 && N > 0, DX_ERR_SHAPE, "dx_layernorm_bwd: empty shape");
+  DX_REQUIRE((film == nullptr) == (dfilm == nullptr), DX_ERR_ARG, "dx_layernorm_bwd: film and dfilm come together");
+  // enough workgroups to fill 256 CUs, few enough that the per-channel atomics stay cheap
+  int rpb = 32;
+  while (rpb < 512 && (long)dx_cdiv(N, rpb) * B > 2048) rpb *= 2;
+  LNBwdArgs a{dy, s_in, mean, rstd, gamma, beta, film, ldf, lengths, ds, dx_pre, dgamma, dbeta, dfilm, lddf, N, B, rpb,
+              p_pre, p_post, seed_pre, seed_post, relu_input};
+  hipStream_t s = (hipStream_t)stream;
+  if (s_dtype == DX_F32 && dy_dtype == DX_F32 && d_dtype == DX_F32) return launch_bwd<float, float, float>(a, C, s);
+  if (s_dtype == DX_BF16 && dy_dtype == DX_BF16 && d_dtype == DX_BF16) return launch_bwd<bf16_t, bf16_t, bf16_t>(a, C, s);
+  if (s_dtype == DX_BF16 && dy_dtype == DX_F32 && d_dtype == DX_BF16) return launch_bwd<bf16_t, float, bf16_t>(a, C, s);
+  if (s_dtype == DX_F32 && dy_dtype == DX_BF16 && d_dtype == DX_F32) return launch_bwd<float, bf16_t, float>(a, C, s);
+  dx_set_error("dx_layernorm_bwd: unsupported dtypes s=%d dy=%d d=%d", s_dtype, dy_dtype, d_dtype);
+  return DX_ERR_DTYPE;
+}

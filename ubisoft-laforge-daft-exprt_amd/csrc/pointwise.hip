@@ -1,0 +1,426 @@
+// K6 / K7 / K8 / K9 / K10 / K14 -- the HBM-bound pointwise and tiny-GEMM pieces around the FFT blocks.
+//   dx_scalar_embed_*  : sum of 1->C k=3 convs of scalar features (+ base tensor, + positional table, + mask)
+//                        (energy/pitch embeddings model.py:402-414; duration/energy/pitch projections 618-628)
+//   dx_embed_pos_*     : symbol embedding gather + positional table + mask (model.py:497-504)
+//   dx_masked_mean_*   : sum over time / length (model.py:419)
+//   dx_film_assemble_* : gamma = post_g * g_raw + 1, beta = post_b * b_raw, split per module/block (model.py:430-462)
+//   dx_linear_small_*  : exact-fp32 nn.Linear for the small heads (FiLM projections 427-428, classifier 276-283,
+//                        predictor projection 568, range projection 634) -- VALU, no operand rounding, so that the
+//                        duration head keeps the reference's fp32 values for the integer-duration conversion.
+// All kernels are fp32, coalesced along the channel axis (C = 128 -> one float2 per lane of a wave64 row, or one
+// float per thread of a 128-thread row group).
+#include "dx_common.h"
+
+namespace {
+
+constexpr int C128 = 128;
+
+// ------------------------------------------------------------------ scalar-feature conv embedding
+struct ScalarEmbedArgs {
+  const float* base;          // (B, N, C) or null
+  const float* feat[3];       // (B, N) each
+  const float* w[3];          // (C, 1, 3) each
+  const float* bias[3];       // (C) each
+  int nfeat;
+  const float* pos;           // (max_len, C) or null
+  const int64_t* lengths;     // mask (rows n >= len -> 0) or null
+  float* out;                 // (B, N, C)
+  int N;
+  long rows;
+};
+
+__global__ __launch_bounds__(256) void scalar_embed_fwd_kernel(ScalarEmbedArgs a) {
+  // 256 threads = 2 rows x 128 channels
+  const int c = threadIdx.x & 127;
+  const long row = (long)blockIdx.x * 2 + (threadIdx.x >> 7);
+  if (row >= a.rows) return;
+  const int b = (int)(row / a.N), n = (int)(row - (long)b * a.N);
+  float v = 0.f;
+  if (!a.lengths || n < (int)a.lengths[b]) {
+    if (a.base) v = a.base[row * C128 + c];
+    for (int f = 0; f < a.nfeat; ++f) {
+      const float* ft = a.feat[f] + (long)b * a.N;
+      const float xm = n > 0 ? ft[n - 1] : 0.f, x0 = ft[n], xp = n + 1 < a.N ? ft[n + 1] : 0.f;
+      const float* w = a.w[f] + c * 3;
+      v += w[0] * xm + w[1] * x0 + w[2] * xp + a.bias[f][c];
+    }
+    if (a.pos) v += a.pos[(long)n * C128 + c];
+  }
+  a.out[row * C128 + c] = v;
+}
+
+struct ScalarEmbedBwdArgs {
+  const float* dout;          // (B, N, C)
+  const float* feat[3];
+  int nfeat;
+  const int64_t* lengths;     // the forward's mask or null
+  float* dbase;               // (B, N, C) = dout * mask, or null
+  float* dw[3];               // (C,1,3) accumulated
+  float* dbias[3];            // (C) accumulated
+  int N; int rows_per_block;
+};
+
+// grid (ceil(N / rows_per_block), B); 128 threads: thread = channel, loops over the slab's rows
+__global__ __launch_bounds__(128) void scalar_embed_bwd_kernel(ScalarEmbedBwdArgs a) {
+  const int c = threadIdx.x, b = blockIdx.y;
+  const int n0 = blockIdx.x * a.rows_per_block;
+  const int len = a.lengths ? (int)a.lengths[b] : a.N;
+  const int n1 = min(min(a.N, n0 + a.rows_per_block), a.dbase ? a.N : len);
+  float aw[3][3], ab[3];
+#pragma unroll
+  for (int f = 0; f < 3; ++f) { ab[f] = 0.f; aw[f][0] = aw[f][1] = aw[f][2] = 0.f; }
+  for (int n = n0; n < n1; ++n) {
+    const long row = (long)b * a.N + n;
+    const float g = n < len ? a.dout[row * C128 + c] : 0.f;
+    if (a.dbase) a.dbase[row * C128 + c] = g;
+    for (int f = 0; f < a.nfeat; ++f) {
+      const float* ft = a.feat[f] + (long)b * a.N;
+      const float xm = n > 0 ? ft[n - 1] : 0.f, x0 = ft[n], xp = n + 1 < a.N ? ft[n + 1] : 0.f;
+      aw[f][0] += g * xm; aw[f][1] += g * x0; aw[f][2] += g * xp; ab[f] += g;
+    }
+  }
+  for (int f = 0; f < a.nfeat; ++f) {
+    atomicAdd(a.dw[f] + c * 3 + 0, aw[f][0]);
+    atomicAdd(a.dw[f] + c * 3 + 1, aw[f][1]);
+    atomicAdd(a.dw[f] + c * 3 + 2, aw[f][2]);
+    atomicAdd(a.dbias[f] + c, ab[f]);
+  }
+}
+
+// ------------------------------------------------------------------ embedding + positional table
+__global__ __launch_bounds__(256) void embed_pos_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                            const float* __restrict__ pos, const int64_t* __restrict__ lengths,
+                                                            float* __restrict__ out, int N, long rows) {
+  const int c = threadIdx.x & 127;
+  const long row = (long)blockIdx.x * 2 + (threadIdx.x >> 7);
+  if (row >= rows) return;
+  const int b = (int)(row / N), n = (int)(row - (long)b * N);
+  float v = 0.f;
+  if (n < (int)lengths[b]) v = table[ids[row] * C128 + c] + pos[(long)n * C128 + c];
+  out[row * C128 + c] = v;
+}
+__global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
+                                                            const int64_t* __restrict__ lengths, float* __restrict__ dtable,
+                                                            int N, long rows) {
+  const int c = threadIdx.x & 127;
+  const long row = (long)blockIdx.x * 2 + (threadIdx.x >> 7);
+  if (row >= rows) return;
+  const int b = (int)(row / N), n = (int)(row - (long)b * N);
+  if (n < (int)lengths[b]) atomicAdd(dtable + ids[row] * C128 + c, dout[row * C128 + c]);
+}
+
+// ------------------------------------------------------------------ out[b] = a[b] + table[ids[b]]  (speaker embedding add, model.py:423-424)
+__global__ void gather_add_fwd_kernel(const float* __restrict__ a, const float* __restrict__ table, const int64_t* __restrict__ ids,
+                                      float* __restrict__ out, int B, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  out[i] = a[i] + table[ids[b] * C + c];
+}
+__global__ void gather_add_bwd_kernel(const float* __restrict__ dz, const int64_t* __restrict__ ids, float* __restrict__ dtable, int B, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  atomicAdd(dtable + ids[b] * C + c, dz[i]);
+}
+
+// ------------------------------------------------------------------ masked mean over time
+// grid (B); 128 threads = channels
+__global__ __launch_bounds__(128) void masked_mean_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ lengths,
+                                                              float* __restrict__ out, int N) {
+  const int c = threadIdx.x, b = blockIdx.x;
+  const int len = (int)lengths[b];
+  const float* p = x + (long)b * N * C128 + c;
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n) acc += p[(long)n * C128];  // pads are zeros (masked upstream), summed like the reference
+  out[b * C128 + c] = acc / (float)len;
+}
+__global__ __launch_bounds__(256) void masked_mean_bwd_kernel(const float* __restrict__ dy, const int64_t* __restrict__ lengths,
+                                                              float* __restrict__ dx, int N, long rows) {
+  const int c = threadIdx.x & 127;
+  const long row = (long)blockIdx.x * 2 + (threadIdx.x >> 7);
+  if (row >= rows) return;
+  const int b = (int)(row / N);
+  dx[row * C128 + c] = dy[b * C128 + c] / (float)lengths[b];
+}
+
+// ------------------------------------------------------------------ FiLM assembly
+// raw gammas / betas (B, W) with W = sum(nb_blocks_m * ch_m); film_m (B, nb_m, 2*ch_m); post (2, nblk_total) or null
+struct FilmArgs {
+  const float* g_raw; const float* b_raw; const float* post;
+  float* film[3];
+  int nb[3], ch[3];
+  int B, W, nblk;
+};
+__global__ void film_assemble_fwd_kernel(FilmArgs a) {
+  const long total = (long)a.B * a.W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / a.W);
+    int col = (int)(i - (long)b * a.W), m = 0, blk0 = 0;
+    while (col >= a.nb[m] * a.ch[m]) { col -= a.nb[m] * a.ch[m]; blk0 += a.nb[m]; ++m; }
+    const int blk = col / a.ch[m], c = col - blk * a.ch[m];
+    const float pg = a.post ? a.post[blk0 + blk] : 1.f, pb = a.post ? a.post[a.nblk + blk0 + blk] : 1.f;
+    float* dst = a.film[m] + ((long)b * a.nb[m] + blk) * 2 * a.ch[m];
+    dst[c] = pg * a.g_raw[i] + 1.f;
+    dst[a.ch[m] + c] = pb * a.b_raw[i];
+  }
+}
+struct FilmBwdArgs {
+  const float* g_raw; const float* b_raw; const float* post;
+  const float* dfilm[3];
+  float* dg_raw; float* db_raw; float* dpost;   // dpost accumulated (atomics)
+  int nb[3], ch[3];
+  int B, W, nblk;
+};
+__global__ void film_assemble_bwd_kernel(FilmBwdArgs a) {
+  const long total = (long)a.B * a.W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / a.W);
+    int col = (int)(i - (long)b * a.W), m = 0, blk0 = 0;
+    while (col >= a.nb[m] * a.ch[m]) { col -= a.nb[m] * a.ch[m]; blk0 += a.nb[m]; ++m; }
+    const int blk = col / a.ch[m], c = col - blk * a.ch[m];
+    const float* src = a.dfilm[m] + ((long)b * a.nb[m] + blk) * 2 * a.ch[m];
+    const float dg = src[c], db = src[a.ch[m] + c];
+    const float pg = a.post ? a.post[blk0 + blk] : 1.f, pb = a.post ? a.post[a.nblk + blk0 + blk] : 1.f;
+    a.dg_raw[i] = dg * pg;
+    a.db_raw[i] = db * pb;
+    if (a.dpost) {
+      // wave-level pre-reduction would be nicer; the tensor is tiny (B x 2560) so plain atomics are fine
+      atomicAdd(a.dpost + blk0 + blk, dg * a.g_raw[i]);
+      atomicAdd(a.dpost + a.nblk + blk0 + blk, db * a.b_raw[i]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ exact-fp32 small linear
+// y[m][o] = act(sum_k x[m][k] W[o][k] + bias[o]); rows m >= mask_len[b] (b = m / N) are written as zeros
+__global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               const int64_t* __restrict__ mask_len, int N, long M, int K,
+                                                               int O, int relu) {
+  const long total = M * O;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / O; const int o = (int)(i - m * O);
+    float acc = 0.f;
+    if (!mask_len || (int)(m % N) < (int)mask_len[m / N]) {
+      const f32x4* xr = reinterpret_cast<const f32x4*>(x + m * K);
+      const f32x4* wr = reinterpret_cast<const f32x4*>(w + (long)o * K);
+      for (int k = 0; k < K / 4; ++k) {
+        const f32x4 a = xr[k], bq = wr[k];
+        acc = fmaf(a[0], bq[0], acc); acc = fmaf(a[1], bq[1], acc); acc = fmaf(a[2], bq[2], acc); acc = fmaf(a[3], bq[3], acc);
+      }
+      acc += bias ? bias[o] : 0.f;
+      if (relu) acc = fmaxf(acc, 0.f);
+    }
+    y[i] = acc;
+  }
+}
+// dx[m][k] = sum_o dyg[m][o] W[o][k],  dyg = dy * (y > 0 if relu) * (row valid)
+__global__ __launch_bounds__(256) void linear_small_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                  const float* __restrict__ w, float* __restrict__ dx,
+                                                                  const int64_t* __restrict__ mask_len, int N, long M, int K,
+                                                                  int O, int relu, float scale) {
+  const long total = M * K;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / K; const int k = (int)(i - m * K);
+    float acc = 0.f;
+    if (!mask_len || (int)(m % N) < (int)mask_len[m / N]) {
+      for (int o = 0; o < O; ++o) {
+        float g = dy[m * O + o];
+        if (relu && !(y[m * O + o] > 0.f)) g = 0.f;
+        acc = fmaf(g, w[(long)o * K + k], acc);
+      }
+    }
+    dx[i] = acc * scale;
+  }
+}
+// dW[o][k] += sum_m dyg[m][o] x[m][k]; db[o] += sum_m dyg[m][o].  grid (ceil(O*K/256), mchunks)
+__global__ __launch_bounds__(256) void linear_small_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                  const float* __restrict__ x, float* __restrict__ dw,
+                                                                  float* __restrict__ db, const int64_t* __restrict__ mask_len,
+                                                                  int N, long M, int K, int O, int relu, int rows_per_chunk) {
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= (long)O * K) return;
+  const int o = (int)(idx / K), k = (int)(idx - (long)o * K);
+  const long m0 = (long)blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+  float acc = 0.f, accb = 0.f;
+  for (long m = m0; m < m1; ++m) {
+    if (mask_len && (int)(m % N) >= (int)mask_len[m / N]) continue;
+    float g = dy[m * O + o];
+    if (relu && !(y[m * O + o] > 0.f)) g = 0.f;
+    acc = fmaf(g, x[m * K + k], acc);
+    accb += g;
+  }
+  atomicAdd(dw + idx, acc);
+  if (db && k == 0) atomicAdd(db + o, accb);
+}
+
+// ------------------------------------------------------------------ misc
+__global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+// column sums of a (rows, C) matrix of type T accumulated into out (C) -- conv / linear bias gradients
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long rows, int C, int rows_per_block) {
+  const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) acc += (float)x[r * C + c];
+    atomicAdd(out + c, acc);
+  }
+}
+
+inline int grid_for(long total, int block = 256, int cap = 4096) {
+  long g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int dx_scalar_embed_fwd(const float* base, const float* const* feats, const float* const* ws,
+                                   const float* const* biases, int nfeat, const float* pos_table,
+                                   const int64_t* lengths, float* out, int B, int N, int C, void* stream) {
+  DX_REQUIRE(out && nfeat >= 0 && nfeat <= 3, DX_ERR_ARG, "dx_scalar_embed_fwd: bad arguments");
+  DX_REQUIRE(C == C128, DX_ERR_UNSUPPORTED, "dx_scalar_embed_fwd: C=%d (only 128)", C);
+  DX_REQUIRE(B > 0 && N > 0, DX_ERR_SHAPE, "dx_scalar_embed_fwd: empty shape");
+  ScalarEmbedArgs a{};
+  a.base = base; a.nfeat = nfeat; a.pos = pos_table; a.lengths = lengths; a.out = out; a.N = N; a.rows = (long)B * N;
+  for (int f = 0; f < nfeat; ++f) { a.feat[f] = feats[f]; a.w[f] = ws[f]; a.bias[f] = biases[f]; }
+  hipLaunchKernelGGL(scalar_embed_fwd_kernel, dim3((unsigned)((a.rows + 1) / 2)), dim3(256), 0, (hipStream_t)stream, a);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_scalar_embed_bwd(const float* dout, const float* const* feats, int nfeat, const int64_t* lengths,
+                                   float* dbase, float* const* dws, float* const* dbiases, int B, int N, int C,
+                                   void* stream) {
+  DX_REQUIRE(dout && nfeat >= 0 && nfeat <= 3, DX_ERR_ARG, "dx_scalar_embed_bwd: bad arguments");
+  DX_REQUIRE(C == C128, DX_ERR_UNSUPPORTED, "dx_scalar_embed_bwd: C=%d (only 128)", C);
+  ScalarEmbedBwdArgs a{};
+  a.dout = dout; a.nfeat = nfeat; a.lengths = lengths; a.dbase = dbase; a.N = N;
+  int rpb = 16;
+  while (rpb < 256 && (long)dx_cdiv(N, rpb) * B > 4096) rpb *= 2;
+  a.rows_per_block = rpb;
+  for (int f = 0; f < nfeat; ++f) { a.feat[f] = feats[f]; a.dw[f] = dws[f]; a.dbias[f] = dbiases[f]; }
+  hipLaunchKernelGGL(scalar_embed_bwd_kernel, dim3(dx_cdiv(N, rpb), B), dim3(128), 0, (hipStream_t)stream, a);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_embed_pos_fwd(const int64_t* ids, const float* table, const float* pos_table, const int64_t* lengths,
+                                float* out, int B, int N, int C, void* stream) {
+  DX_REQUIRE(ids && table && pos_table && lengths && out, DX_ERR_ARG, "dx_embed_pos_fwd: null pointer");
+  DX_REQUIRE(C == C128, DX_ERR_UNSUPPORTED, "dx_embed_pos_fwd: C=%d (only 128)", C);
+  const long rows = (long)B * N;
+  hipLaunchKernelGGL(embed_pos_fwd_kernel, dim3((unsigned)((rows + 1) / 2)), dim3(256), 0, (hipStream_t)stream, ids, table,
+                     pos_table, lengths, out, N, rows);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+extern "C" int dx_embed_pos_bwd(const int64_t* ids, const float* dout, const int64_t* lengths, float* dtable, int B,
+                                int N, int C, void* stream) {
+  DX_REQUIRE(ids && dout && lengths && dtable, DX_ERR_ARG, "dx_embed_pos_bwd: null pointer");
+  DX_REQUIRE(C == C128, DX_ERR_UNSUPPORTED, "dx_embed_pos_bwd: C=%d (only 128)", C);
+  const long rows = (long)B * N;
+  hipLaunchKernelGGL(embed_pos_bwd_kernel, dim3((unsigned)((rows + 1) / 2)), dim3(256), 0, (hipStream_t)stream, ids, dout,
+                     lengths, dtable, N, rows);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_masked_mean_fwd(const float* x, const int64_t* lengths, float* out, int B, int N, int C, void* stream) {
+  DX_REQUIRE(x && lengths && out, DX_ERR_ARG, "dx_masked_mean_fwd: null pointer");
+  DX_REQUIRE(C == C128, DX_ERR_UNSUPPORTED, "dx_masked_mean_fwd: C=%d (only 128)", C);
+  hipLaunchKernelGGL(masked_mean_fwd_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, x, lengths, out, N);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+extern "C" int dx_masked_mean_bwd(const float* dy, const int64_t* lengths, float* dx, int B, int N, int C, void* stream) {
+  DX_REQUIRE(dy && lengths && dx, DX_ERR_ARG, "dx_masked_mean_bwd: null pointer");
+  DX_REQUIRE(C == C128, DX_ERR_UNSUPPORTED, "dx_masked_mean_bwd: C=%d (only 128)", C);
+  const long rows = (long)B * N;
+  hipLaunchKernelGGL(masked_mean_bwd_kernel, dim3((unsigned)((rows + 1) / 2)), dim3(256), 0, (hipStream_t)stream, dy, lengths,
+                     dx, N, rows);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_film_assemble_fwd(const float* g_raw, const float* b_raw, const float* post, float* film_enc,
+                                    float* film_pp, float* film_dec, const int* nb, const int* ch, int B, void* stream) {
+  DX_REQUIRE(g_raw && b_raw && film_enc && film_pp && film_dec && nb && ch, DX_ERR_ARG, "dx_film_assemble_fwd: null pointer");
+  FilmArgs a{};
+  a.g_raw = g_raw; a.b_raw = b_raw; a.post = post; a.film[0] = film_enc; a.film[1] = film_pp; a.film[2] = film_dec; a.B = B;
+  for (int m = 0; m < 3; ++m) { a.nb[m] = nb[m]; a.ch[m] = ch[m]; a.W += nb[m] * ch[m]; a.nblk += nb[m]; }
+  hipLaunchKernelGGL(film_assemble_fwd_kernel, dim3(grid_for((long)B * a.W)), dim3(256), 0, (hipStream_t)stream, a);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+extern "C" int dx_film_assemble_bwd(const float* g_raw, const float* b_raw, const float* post, const float* dfilm_enc,
+                                    const float* dfilm_pp, const float* dfilm_dec, float* dg_raw, float* db_raw,
+                                    float* dpost, const int* nb, const int* ch, int B, void* stream) {
+  DX_REQUIRE(g_raw && b_raw && dfilm_enc && dfilm_pp && dfilm_dec && dg_raw && db_raw, DX_ERR_ARG, "dx_film_assemble_bwd: null pointer");
+  FilmBwdArgs a{};
+  a.g_raw = g_raw; a.b_raw = b_raw; a.post = post; a.dfilm[0] = dfilm_enc; a.dfilm[1] = dfilm_pp; a.dfilm[2] = dfilm_dec;
+  a.dg_raw = dg_raw; a.db_raw = db_raw; a.dpost = post ? dpost : nullptr; a.B = B;
+  for (int m = 0; m < 3; ++m) { a.nb[m] = nb[m]; a.ch[m] = ch[m]; a.W += nb[m] * ch[m]; a.nblk += nb[m]; }
+  hipLaunchKernelGGL(film_assemble_bwd_kernel, dim3(grid_for((long)B * a.W)), dim3(256), 0, (hipStream_t)stream, a);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_linear_small_fwd(const float* x, const float* w, const float* bias, float* y,
+                                   const int64_t* mask_lengths, int N, long M, int K, int O, int relu, void* stream) {
+  DX_REQUIRE(x && w && y, DX_ERR_ARG, "dx_linear_small_fwd: null pointer");
+  DX_REQUIRE(M > 0 && K > 0 && O > 0 && K % 4 == 0, DX_ERR_SHAPE, "dx_linear_small_fwd: bad shape M=%ld K=%d O=%d", M, K, O);
+  hipLaunchKernelGGL(linear_small_fwd_kernel, dim3(grid_for(M * O)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y,
+                     mask_lengths, N, M, K, O, relu);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+extern "C" int dx_linear_small_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float dx_scale,
+                                   float* dw, float* db, const int64_t* mask_lengths, int N, long M, int K, int O,
+                                   int relu, void* stream) {
+  DX_REQUIRE(dy && x && w && dw, DX_ERR_ARG, "dx_linear_small_bwd: null pointer");
+  DX_REQUIRE(!relu || y, DX_ERR_ARG, "dx_linear_small_bwd: relu needs the forward output y");
+  hipStream_t s = (hipStream_t)stream;
+  if (dx) hipLaunchKernelGGL(linear_small_bwd_dx_kernel, dim3(grid_for(M * K)), dim3(256), 0, s, dy, y, w, dx, mask_lengths, N, M, K, O, relu, dx_scale);
+  int rpc = 64;
+  while (rpc < 4096 && (M + rpc - 1) / rpc > 256) rpc *= 2;
+  dim3 grid(dx_cdiv(O * K, 256), (unsigned)((M + rpc - 1) / rpc));
+  hipLaunchKernelGGL(linear_small_bwd_dw_kernel, grid, dim3(256), 0, s, dy, y, x, dw, db, mask_lengths, N, M, K, O, relu, rpc);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_add_inplace(float* dst, const float* src, long n, void* stream) {
+  DX_REQUIRE(dst && src && n >= 0, DX_ERR_ARG, "dx_add_inplace: bad arguments");
+  if (n == 0) return DX_OK;
+  hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_colsum(const void* x, int dtype, float* out, long rows, int C, void* stream) {
+  DX_REQUIRE(x && out && rows > 0 && C > 0, DX_ERR_ARG, "dx_colsum: bad arguments");
+  int rpb = 64;
+  while (rpb < 8192 && (rows + rpb - 1) / rpb > 512) rpb *= 2;
+  dim3 grid(dx_cdiv(C, 256), (unsigned)((rows + rpb - 1) / rpb));
+  if (dtype == DX_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, out, rows, C, rpb);
+  else if (dtype == DX_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, rows, C, rpb);
+  else { dx_set_error("dx_colsum: bad dtype %d", dtype); return DX_ERR_DTYPE; }
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_gather_add_fwd(const float* a, const float* table, const int64_t* ids, float* out, int B, int C, void* stream) {
+  DX_REQUIRE(a && table && ids && out && B > 0 && C > 0, DX_ERR_ARG, "dx_gather_add_fwd: bad arguments");
+  hipLaunchKernelGGL(gather_add_fwd_kernel, dim3(dx_cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, a, table, ids, out, B, C);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+extern "C" int dx_gather_add_bwd(const float* dz, const int64_t* ids, float* dtable, int B, int C, void* stream) {
+  DX_REQUIRE(dz && ids && dtable && B > 0 && C > 0, DX_ERR_ARG, "dx_gather_add_bwd: bad arguments");
+  hipLaunchKernelGGL(gather_add_bwd_kernel, dim3(dx_cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, dz, ids, dtable, B, C);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}

@@ -1,0 +1,301 @@
+// K13 losses (+ their gradients), K15 Adam / gradient norm, K16 float -> integer durations.
+#include "dx_common.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = dx_wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float t = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return t;
+}
+
+// ------------------------------------------------------------------ losses (loss.py:54-99)
+// terms[0..6] = speaker, post_mult, duration, energy, pitch, mel_l1, mel_l2 (already weighted); terms[7] = total
+struct SeqLossArgs {
+  const float* pred[3]; const float* tgt[3]; float* dpred[3]; float w[3];
+  const int64_t* lengths; float* terms; int B, L; float gscale;
+};
+// grid (B, 3)
+__global__ __launch_bounds__(256) void seq_loss_kernel(SeqLossArgs a) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, f = blockIdx.y;
+  const float inv = 1.f / ((float)a.lengths[b] * (float)a.B);
+  const float* p = a.pred[f] + (long)b * a.L; const float* t = a.tgt[f] + (long)b * a.L;
+  float* dp = a.dpred[f] ? a.dpred[f] + (long)b * a.L : nullptr;
+  float acc = 0.f;
+  for (int l = threadIdx.x; l < a.L; l += 256) {
+    const float d = p[l] - t[l];
+    acc += d * d;
+    if (dp) dp[l] = a.gscale * a.w[f] * 2.f * d * inv;
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) atomicAdd(a.terms + 2 + f, a.w[f] * acc * inv);
+}
+
+// mel: pred/target (B, C, T); grid (chunks, B)
+__global__ __launch_bounds__(256) void mel_loss_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                       float* __restrict__ dpred, const int64_t* __restrict__ out_len,
+                                                       float* terms, int B, int C, int T, float w, float gscale, int dtrans) {
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  const float inv = 1.f / ((float)C * (float)out_len[b] * (float)B);
+  const long n = (long)C * T, base = (long)b * n;
+  float a1 = 0.f, a2 = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    const float d = pred[base + i] - tgt[base + i];
+    a1 += fabsf(d);
+    a2 += d * d;
+    if (dpred) dpred[dtrans ? base + (i % T) * C + i / T : base + i] = gscale * w * ((d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) + 2.f * d) * inv;
+  }
+  a1 = block_sum_256(a1, red);
+  a2 = block_sum_256(a2, red);
+  if (threadIdx.x == 0) { atomicAdd(terms + 5, w * a1 * inv); atomicAdd(terms + 6, w * a2 * inv); }
+}
+
+// speaker cross-entropy (mean over the batch) and post-multiplier L2 norm; one block
+__global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ ids,
+                                                        float* __restrict__ dlogits, int B, int S, float w_spk,
+                                                        const float* __restrict__ post, float* __restrict__ dpost, int npost,
+                                                        float w_post, float* terms, float gscale) {
+  __shared__ float red[4];
+  float ce = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* z = logits + (long)b * S;
+    float mx = -INFINITY;
+    for (int s = 0; s < S; ++s) mx = fmaxf(mx, z[s]);
+    float se = 0.f;
+    for (int s = 0; s < S; ++s) se += expf(z[s] - mx);
+    const int tgt = (int)ids[b];
+    ce += (mx + logf(se)) - z[tgt];
+    if (dlogits)
+      for (int s = 0; s < S; ++s)
+        dlogits[(long)b * S + s] = gscale * w_spk * (expf(z[s] - mx) / se - (s == tgt ? 1.f : 0.f)) / (float)B;
+  }
+  ce = block_sum_256(ce, red);
+  float sq = 0.f;
+  if (post) for (int i = threadIdx.x; i < npost; i += 256) sq += post[i] * post[i];
+  sq = block_sum_256(sq, red);
+  const float nrm = sqrtf(sq);
+  if (post && dpost) for (int i = threadIdx.x; i < npost; i += 256) dpost[i] += nrm > 0.f ? gscale * w_post * post[i] / nrm : 0.f;
+  if (threadIdx.x == 0) {
+    terms[0] = w_spk * ce / (float)B;
+    terms[1] = post ? w_post * nrm : 0.f;
+  }
+}
+__global__ void loss_total_kernel(float* terms) {
+  float t = 0.f;
+  for (int i = 0; i < 7; ++i) t += terms[i];
+  terms[7] = t;
+}
+
+// ------------------------------------------------------------------ Adam (train.py:299-301) + gradient norm (train.py:399)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) acc += x[i] * x[i];
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) atomicAdd(out, acc);
+}
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                   float wd, float bc1, float bc2_sqrt, const float* gnorm_sq, float clip) {
+  float coef = 1.f;
+  if (gnorm_sq && clip < INFINITY) coef = fminf(1.f, clip / (sqrtf(*gnorm_sq) + 1e-6f));  // clip_grad_norm_
+  const float step = lr / bc1;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    const float pi = p[i];
+    const float gi = g[i] * coef + wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = pi - step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  }
+}
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long n, float s) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) x[i] *= s;
+}
+
+// ------------------------------------------------------------------ integer durations (model.py:789-812 + extract_features.py:69-111)
+__device__ __forceinline__ long floordiv(long a, long b) { long q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
+
+// one thread per utterance; fp64 + integer arithmetic in the reference's order of operations
+__global__ void int_durations_kernel(float* __restrict__ dur, const float* __restrict__ dur_factors, int64_t* __restrict__ out, int64_t* __restrict__ totals,
+                                     int* __restrict__ status, int B, int L, double sr, int fl, int hop, int centered) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float* d = dur + (long)b * L;
+  int64_t* o = out + (long)b * L;
+  const float dmin = (float)((double)fl / sr / 2.0);   // compared in fp32, like `tensor < python_float`
+  double end_prev = 0.0, total = 0.0;
+  int nspans = 0;
+  for (int l = 0; l < L; ++l) {
+    if (dur_factors) d[l] *= dur_factors[(long)b * L + l];   // model.py:891
+    if (d[l] < dmin) d[l] = 0.f;
+    o[l] = 0;
+    if (d[l] != 0.f) {
+      const double e = end_prev + (double)d[l];
+      total = total + (e - end_prev);
+      end_prev += (double)d[l];
+      ++nspans;
+    }
+  }
+  const long nb_samples = (long)(total * sr);
+  const long nb_frames = 1 + (long)((double)(nb_samples - fl) / (double)hop);
+  const long half = fl / 2;
+  long assigned = 0;
+  int consumed = 0, l = 0, first = -1, last = -1, st = 0;
+  end_prev = 0.0;
+  while (assigned + 1 <= nb_frames) {
+    while (l < L && d[l] == 0.f) ++l;
+    if (l >= L) { st = 1; break; }                       // IndexError: pop from empty list
+    const double bg = end_prev, e = end_prev + (double)d[l];
+    end_prev += (double)d[l];
+    const long sb = (long)(bg * sr), se = (long)(e * sr);
+    long lo = floordiv(sb + 1 - half + hop - 1, hop); if (lo < 0) lo = 0;   // ceil((sb + 1 - half) / hop)
+    long hi = floordiv(se - half, hop); if (hi > nb_frames - 1) hi = nb_frames - 1;
+    const long n = hi - lo + 1 > 0 ? hi - lo + 1 : 0;
+    o[l] = n;
+    assigned += n;
+    if (first < 0) first = l;
+    last = l;
+    ++consumed; ++l;
+  }
+  if (!st && centered) {
+    const long edge = (long)((double)fl / 2.0 / (double)hop);
+    if (first < 0) st = 1;                               // IndexError: int_durations[0] on an empty list
+    else {
+      o[first] += edge;
+      if (consumed < nspans) {
+        while (l < L && d[l] == 0.f) ++l;
+        o[l] = edge; ++consumed;
+      } else o[last] += edge;
+    }
+  }
+  if (!st && consumed != nspans) st = 2;                 // shape mismatch in the reference's index_put
+  int64_t tot = 0;
+  for (int i = 0; i < L; ++i) tot += o[i];
+  totals[b] = tot;
+  status[b] = st;
+}
+
+
+// ------------------------------------------------------------------ inference-time prosody control (model.py:895-905, 814-864)
+// one wave per utterance.  mode 0 = 'add' (pitch_shift), 1 = 'multiply' (pitch_multiply)
+__global__ __launch_bounds__(64) void prosody_control_kernel(float* __restrict__ energy, float* __restrict__ pitch,
+                                                             const float* __restrict__ energy_factors,
+                                                             const float* __restrict__ pitch_factors,
+                                                             const int64_t* __restrict__ dint, const int64_t* __restrict__ spk,
+                                                             const float* __restrict__ spk_mean, const float* __restrict__ spk_std,
+                                                             int mode, int L) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float* e = energy + (long)b * L; float* p = pitch + (long)b * L;
+  const float* ef = energy_factors + (long)b * L; const float* pf = pitch_factors + (long)b * L;
+  const int64_t* di = dint + (long)b * L;
+  float sum = 0.f, cnt = 0.f;
+  for (int l = lane; l < L; l += 64) {
+    const bool z = di[l] == 0;
+    e[l] = z ? 0.f : e[l] * ef[l];
+    const float pv = z ? 0.f : p[l];
+    p[l] = pv;
+    if (pv != 0.f) { sum += pv; cnt += 1.f; }
+  }
+  if (mode == 0) {
+    const float mean = spk_mean[spk[b]], sd = spk_std[spk[b]];
+    for (int l = lane; l < L; l += 64) {
+      const float pv = p[l];
+      if (pv != 0.f) p[l] = (logf(expf(sd * pv + mean) + pf[l]) - mean) / sd;
+    }
+  } else {
+    sum = dx_wave_sum(sum); cnt = dx_wave_sum(cnt);
+    const float mean = sum / cnt;
+    for (int l = lane; l < L; l += 64) {
+      const float pv = p[l];
+      if (pv != 0.f) { const float dev = (pv - mean) * pf[l]; p[l] = pv + dev; }
+    }
+  }
+}
+
+inline int grid_for(long total, int cap = 2048) {
+  long g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int dx_loss_fwd_bwd(const float* dur, const float* energy, const float* pitch, const float* dur_t,
+                               const float* energy_t, const float* pitch_t, const int64_t* in_lengths, const float* mel,
+                               const float* mel_t, const int64_t* out_lengths, const float* spk_logits,
+                               const int64_t* spk_ids, const float* post_mult, float* d_dur, float* d_energy,
+                               float* d_pitch, float* d_mel, float* d_spk_logits, float* d_post_mult, float* terms,
+                               int B, int L, int T, int n_mel, int n_spk_classes, int n_post, float w_spk, float w_post,
+                               float w_dur, float w_energy, float w_pitch, float w_mel, float grad_scale,
+                               int d_mel_transposed, void* stream) {
+  DX_REQUIRE(dur && energy && pitch && dur_t && energy_t && pitch_t && in_lengths && mel && mel_t && out_lengths && spk_logits &&
+             spk_ids && terms, DX_ERR_ARG, "dx_loss_fwd_bwd: null pointer");
+  DX_REQUIRE(B > 0 && L > 0 && T > 0, DX_ERR_SHAPE, "dx_loss_fwd_bwd: empty shape");
+  hipStream_t s = (hipStream_t)stream;
+  hipMemsetAsync(terms, 0, 8 * sizeof(float), s);
+  SeqLossArgs a{{dur, energy, pitch}, {dur_t, energy_t, pitch_t}, {d_dur, d_energy, d_pitch}, {w_dur, w_energy, w_pitch},
+                in_lengths, terms, B, L, grad_scale};
+  hipLaunchKernelGGL(seq_loss_kernel, dim3(B, 3), dim3(256), 0, s, a);
+  int chunks = dx_cdiv(n_mel * T, 256 * 8);
+  if (chunks > 64) chunks = 64;
+  hipLaunchKernelGGL(mel_loss_kernel, dim3(chunks, B), dim3(256), 0, s, mel, mel_t, d_mel, out_lengths, terms, B, n_mel, T, w_mel, grad_scale, d_mel_transposed);
+  hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(256), 0, s, spk_logits, spk_ids, d_spk_logits, B, n_spk_classes, w_spk,
+                     post_mult, d_post_mult, n_post, w_post, terms, grad_scale);
+  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, s, terms);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_sumsq(const float* x, long n, float* out, void* stream) {
+  DX_REQUIRE(x && out && n >= 0, DX_ERR_ARG, "dx_sumsq: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipMemsetAsync(out, 0, sizeof(float), s);
+  if (n) hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, s, x, n, out);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int step, const float* grad_norm_sq, float clip_thresh,
+                            void* stream) {
+  DX_REQUIRE(p && g && m && v && n > 0 && step >= 1, DX_ERR_ARG, "dx_adam_step: bad arguments");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, (float)bc1, (float)sqrt(bc2), grad_norm_sq, clip_thresh);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_scale(float* x, long n, float s, void* stream) {
+  DX_REQUIRE(x && n >= 0, DX_ERR_ARG, "dx_scale: bad arguments");
+  if (n) hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, s);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_int_durations(float* duration_preds, const float* dur_factors, int64_t* durations_int, int64_t* totals, int* status, int B, int L,
+                                double sampling_rate, int filter_length, int hop_length, int centered, void* stream) {
+  DX_REQUIRE(duration_preds && durations_int && totals && status, DX_ERR_ARG, "dx_int_durations: null pointer");
+  DX_REQUIRE(B > 0 && L > 0 && hop_length > 0 && filter_length > 0, DX_ERR_SHAPE, "dx_int_durations: bad shape");
+  hipLaunchKernelGGL(int_durations_kernel, dim3(dx_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, duration_preds, dur_factors,
+                     durations_int, totals, status, B, L, sampling_rate, filter_length, hop_length, centered);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_prosody_control(float* energy, float* pitch, const float* energy_factors, const float* pitch_factors,
+                                  const int64_t* durations_int, const int64_t* speaker_ids, const float* spk_pitch_mean,
+                                  const float* spk_pitch_std, int mode, int B, int L, void* stream) {
+  DX_REQUIRE(energy && pitch && energy_factors && pitch_factors && durations_int, DX_ERR_ARG, "dx_prosody_control: null pointer");
+  DX_REQUIRE(mode == 1 || (speaker_ids && spk_pitch_mean && spk_pitch_std), DX_ERR_ARG, "dx_prosody_control: 'add' needs speaker stats");
+  DX_REQUIRE(mode == 0 || mode == 1, DX_ERR_UNSUPPORTED, "dx_prosody_control: pitch transform %d not implemented", mode);
+  hipLaunchKernelGGL(prosody_control_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, energy, pitch, energy_factors, pitch_factors,
+                     durations_int, speaker_ids, spk_pitch_mean, spk_pitch_std, mode, L);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}

@@ -1,0 +1,91 @@
+"""Batch construction for the trainer.
+
+`DaftExprtDataCollate` keeps the collate contract of the reference (`src/daft_exprt/data_loader.py:146-211`):
+sort by phoneme count (descending), right-zero-pad to the batch maxima, `output_lengths` follows the same
+permutation (NOT sorted by T), 13-tuple order consumed by `DaftExprt.parse_batch`.
+`SyntheticUtterances` generates the seeded synthetic utterances of SURVEY 8(d) (there are no corpora in the
+build / bench environment); the on-disk feature reader of `data_loader.py:11-137` is the next row of SURVEY 8(f).
+"""
+import numpy as np
+import torch
+
+
+class DaftExprtDataCollate():
+    def __init__(self, hparams):
+        self.hparams = hparams
+
+    def __call__(self, batch):
+        ''' batch: list of [symbols, durations_float, durations_int, symbols_energy, symbols_pitch, frames_energy,
+            frames_pitch, mel_spec (n_mel, T), speaker_id, features_dir, feature_file] '''
+        n = len(batch)
+        input_lengths, order = torch.sort(torch.LongTensor([len(x[0]) for x in batch]), dim=0, descending=True)
+        L = int(input_lengths[0])
+        T = max(x[7].size(1) for x in batch)
+        symbols = torch.zeros(n, L, dtype=torch.long)
+        durations_float = torch.zeros(n, L)
+        durations_int = torch.zeros(n, L, dtype=torch.long)
+        symbols_energy, symbols_pitch = torch.zeros(n, L), torch.zeros(n, L)
+        frames_energy, frames_pitch = torch.zeros(n, T), torch.zeros(n, T)
+        mel_specs = torch.zeros(n, self.hparams.n_mel_channels, T)
+        output_lengths, speaker_ids = torch.zeros(n, dtype=torch.long), torch.zeros(n, dtype=torch.long)
+        feature_dirs, feature_files = [], []
+        for row, src in enumerate(order.tolist()):
+            item = batch[src]
+            l, t = len(item[0]), item[7].size(1)
+            symbols[row, :l] = item[0]
+            durations_float[row, :l] = item[1]
+            durations_int[row, :l] = item[2]
+            symbols_energy[row, :l] = item[3]
+            symbols_pitch[row, :l] = item[4]
+            frames_energy[row, :t] = item[5]
+            frames_pitch[row, :t] = item[6]
+            mel_specs[row, :, :t] = item[7]
+            output_lengths[row] = t
+            speaker_ids[row] = item[8]
+            feature_dirs.append(item[9])
+            feature_files.append(item[10])
+        return symbols, durations_float, durations_int, symbols_energy, symbols_pitch, input_lengths, \
+            frames_energy, frames_pitch, mel_specs, output_lengths, speaker_ids, feature_dirs, feature_files
+
+
+class SyntheticUtterances(torch.utils.data.Dataset):
+    ''' seeded synthetic utterances with the statistics of SURVEY 8(d): L ~ U{40..160}, integer durations
+        U{0..12} trimmed so that T <= t_max, mel ~ clip(N(-5, 2), ln 1e-5, 2), 30 % unvoiced frames. '''
+    def __init__(self, hparams, n_items, seed=1234, t_min=1, t_max=1000, force_first_full=True, n_speakers=None,
+                 l_range=(40, 160)):
+        self.hp, self.n, self.seed = hparams, n_items, seed
+        self.t_min, self.t_max, self.force_first_full = t_min, t_max, force_first_full
+        self.n_speakers = n_speakers if n_speakers is not None else max(1, hparams.n_speakers - 1)
+        self.l_range = l_range
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, idx):
+        rng = np.random.RandomState((self.seed * 1000003 + idx) % (2 ** 31 - 1))
+        L = int(rng.randint(self.l_range[0], self.l_range[1] + 1))
+        d = rng.randint(0, 13, size=L).astype(np.int64)
+        if self.force_first_full and idx == 0:
+            target = self.t_max
+        else:
+            target = int(np.clip(d.sum(), max(self.t_min, L // 2), self.t_max))
+        while d.sum() > target:          # decrement the largest first
+            d[int(np.argmax(d))] -= 1
+        while d.sum() < target:
+            d[int(rng.randint(0, L))] += 1
+        T = int(d.sum())
+        dur_f = (d * float(self.hp.hop_length) / float(self.hp.sampling_rate)).astype(np.float32)
+        sym = rng.randint(1, self.hp.n_symbols, size=L).astype(np.int64)
+        voiced = (d > 0).astype(np.float32)
+        s_en, s_pi = rng.randn(L).astype(np.float32) * voiced, rng.randn(L).astype(np.float32) * voiced
+        f_en = rng.uniform(0., 60., size=T).astype(np.float32)
+        f_pi = np.where(rng.rand(T) < 0.3, 0., rng.randn(T) * 0.3 + 5.0).astype(np.float32)
+        mel = np.clip(rng.randn(self.hp.n_mel_channels, T) * 2. - 5., np.log(1e-5), 2.).astype(np.float32)
+        spk = int(rng.randint(0, self.n_speakers))
+        t = torch.from_numpy
+        return [t(sym), t(dur_f), t(d), t(s_en), t(s_pi), t(f_en), t(f_pi), t(mel), spk, 'synthetic', f'utt{idx:06d}']
+
+
+def synthetic_batch(hparams, batch_size, seed=1234, **kw):
+    ds = SyntheticUtterances(hparams, batch_size, seed=seed, **kw)
+    return DaftExprtDataCollate(hparams)([ds[i] for i in range(batch_size)])

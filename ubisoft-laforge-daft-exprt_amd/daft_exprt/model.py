@@ -1,0 +1,686 @@
+"""DaftExprt acoustic model on hand-written gfx950 kernels.
+
+Keeps the reference's Python surface (`src/daft_exprt/model.py:713-923`): `DaftExprt(hparams)`,
+`parse_batch`, `forward(inputs)` (5-tuple, `model.py:780-787`), `inference(inputs, pitch_transform,
+hparams)`, `get_int_durations`, `pitch_shift`, `pitch_multiply`, and the exact `state_dict` key set /
+shapes (checkpoint ABI) -- but none of its arithmetic runs through ATen: every tensor op of
+the hot path is an entry point of `libdaftexprt_hip.so` (include/daft_exprt_hip.h).
+
+MI355X-first structure
+  * parameters live in ONE flat fp32 buffer (views are exposed under the reference names); gradients
+    in a second flat buffer -> Adam is one kernel over 14.7 M floats and the data-parallel all-reduce
+    is a handful of large contiguous RCCL calls;
+  * the backward pass is written out by hand (no autograd graph, no per-op Python dispatch beyond the
+    kernel launches): `forward` records the few activations each kernel needs, `_backward` walks them
+    in reverse.  A single `torch.autograd.Function` node bridges to `loss.backward()` for drop-in use;
+  * MFMA operands are bf16 (or exact fp32 with `hparams.compute_dtype='fp32'`); the residual stream,
+    LayerNorm statistics, softmax, Gaussian upsampling, the small heads, losses and Adam are fp32;
+  * positional encodings, masks, the integer duration conversion and the prosody controls run on the
+    device -- the reference's per-utterance host loops (`model.py:142-148, 799-808, 822-832, 849-862`)
+    are gone.
+There is no CPU fallback: CPU tensors raise.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from daft_exprt import ops
+
+_MASK63 = (1 << 63) - 1
+
+
+def get_mask_from_lengths(lengths):
+    ''' (B,) -> (B, max(lengths)) bool, True = valid (`model.py:14-24`).  Kept for API parity; the kernels
+        take `lengths` directly and never materialise masks. '''
+    ids = torch.arange(0, int(lengths.max()), device=lengths.device)
+    return ids < lengths.unsqueeze(1)
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter table: names / shapes / init families in the reference's registration order
+# ------------------------------------------------------------------------------------------------
+def film_layout(hp):
+    ''' (nb_blocks, channels) per FiLM-ed module, projection-column order (`model.py:322-326`) '''
+    return [(hp.phoneme_encoder['nb_blocks'], hp.phoneme_encoder['hidden_embed_dim']),
+            (hp.local_prosody_predictor['nb_blocks'], hp.local_prosody_predictor['conv_channels']),
+            (hp.frame_decoder['nb_blocks'], hp.phoneme_encoder['hidden_embed_dim'])]
+
+
+def param_table(hp):
+    ''' [(name, shape, init)], init in {'xavier:<gain>', 'ones', 'zeros', 'bias:<fan_in>', 'kaiming:<fan_in>'} '''
+    T = []
+    relu, lin = math.sqrt(2.), 1.
+    n_mel, D = hp.n_mel_channels, hp.prosody_encoder['hidden_embed_dim']
+    E = hp.phoneme_encoder['hidden_embed_dim']
+
+    def conv(name, cout, cin, k, gain):
+        T.append((f'{name}.conv.weight', (cout, cin, k), f'xavier:{gain}'))
+        T.append((f'{name}.conv.bias', (cout,), f'bias:{cin * k}'))
+
+    def linear(name, out, inp, gain):
+        T.append((f'{name}.linear_layer.weight', (out, inp), f'xavier:{gain}'))
+        T.append((f'{name}.linear_layer.bias', (out,), f'bias:{inp}'))
+
+    def layer_norm(name, c):
+        T.append((f'{name}.weight', (c,), 'ones'))
+        T.append((f'{name}.bias', (c,), 'zeros'))
+
+    def fft_blocks(pre, cfg, dim):
+        for b in range(cfg['nb_blocks']):
+            a = f'{pre}.blocks.{b}.attention'
+            T.append((f'{a}.multi_head_attention.in_proj_weight', (3 * dim, dim), 'xavier:1.0'))
+            T.append((f'{a}.multi_head_attention.in_proj_bias', (3 * dim,), 'zeros'))
+            T.append((f'{a}.multi_head_attention.out_proj.weight', (dim, dim), f'kaiming:{dim}'))
+            T.append((f'{a}.multi_head_attention.out_proj.bias', (dim,), 'zeros'))
+            layer_norm(f'{a}.layer_norm', dim)
+            f = f'{pre}.blocks.{b}.feed_forward'
+            conv(f'{f}.convs.0', cfg['conv_channels'], dim, cfg['conv_kernel'], relu)
+            conv(f'{f}.convs.2', dim, cfg['conv_channels'], cfg['conv_kernel'], lin)
+            layer_norm(f'{f}.layer_norm', dim)
+
+    cfg = hp.prosody_encoder
+    C, K = cfg['conv_channels'], cfg['conv_kernel']
+    if hp.post_mult_weight != 0.:
+        T.append(('prosody_encoder.post_multipliers', (2, sum(nb for nb, _ in film_layout(hp))), 'xavier:1.0'))
+    conv('prosody_encoder.energy_embedding', D, 1, K, lin)
+    conv('prosody_encoder.pitch_embedding', D, 1, K, lin)
+    for idx, (cin, cout) in zip((0, 4, 8), ((n_mel, C), (C, C), (C, D))):
+        conv(f'prosody_encoder.convs.{idx}', cout, cin, K, relu)
+        layer_norm(f'prosody_encoder.convs.{idx + 2}', cout)
+    fft_blocks('prosody_encoder', cfg, D)
+    T.append(('prosody_encoder.spk_embedding.weight', (hp.n_speakers, D), 'xavier:1.0'))
+    nb_film = sum(nb * ch for nb, ch in film_layout(hp))
+    linear('prosody_encoder.gammas_predictor', nb_film, D, lin)
+    linear('prosody_encoder.betas_predictor', nb_film, D, lin)
+    for idx, (i, o, gain) in zip((1, 3, 5), ((D, D, relu), (D, D, relu), (D, hp.n_speakers - 1, lin))):
+        linear(f'speaker_classifier.classifier.{idx}', o, i, gain)
+    T.append(('phoneme_encoder.symbols_embedding.weight', (hp.n_symbols, E), 'xavier:1.0'))
+    fft_blocks('phoneme_encoder', hp.phoneme_encoder, E)
+    cfg = hp.local_prosody_predictor
+    for b in range(cfg['nb_blocks']):
+        cin = E if b == 0 else cfg['conv_channels']
+        for idx, ci in ((0, cin), (4, cfg['conv_channels'])):
+            conv(f'prosody_predictor.blocks.{b}.{idx}', cfg['conv_channels'], ci, cfg['conv_kernel'], relu)
+            layer_norm(f'prosody_predictor.blocks.{b}.{idx + 2}', cfg['conv_channels'])
+    linear('prosody_predictor.projection', 3, cfg['conv_channels'], lin)
+    Kg = hp.gaussian_upsampling_module['conv_kernel']
+    for nm in ('duration_projection', 'energy_projection', 'pitch_projection'):
+        conv(f'gaussian_upsampling.{nm}', E, 1, Kg, lin)
+    T.append(('gaussian_upsampling.projection.0.linear_layer.weight', (1, E), f'xavier:{relu}'))
+    T.append(('gaussian_upsampling.projection.0.linear_layer.bias', (1,), f'bias:{E}'))
+    fft_blocks('frame_decoder', hp.frame_decoder, E)
+    linear('frame_decoder.projection', n_mel, E, lin)
+    return T
+
+
+def _init_tensor(shape, init, gen):
+    kind, _, arg = init.partition(':')
+    if kind == 'ones':
+        return torch.ones(shape)
+    if kind == 'zeros':
+        return torch.zeros(shape)
+    u = torch.rand(shape, generator=gen) * 2 - 1
+    if kind == 'xavier':   # nn.init.xavier_uniform_ (model.py:64, 84, 371, 387, 482)
+        rf = int(np.prod(shape[2:])) if len(shape) > 2 else 1
+        return u * (float(arg) * math.sqrt(6. / ((shape[0] + shape[1]) * rf)))
+    return u / math.sqrt(float(arg))   # torch default Linear / Conv1d bias and kaiming(a=sqrt 5) weight bound
+
+
+class _Node(nn.Module):
+    ''' name-only container: reproduces the reference's module tree so that state_dict keys match '''
+
+
+class _Saved(object):
+    ''' bag of activations kept by the forward pass for the hand-written backward pass '''
+
+
+class _Bridge(torch.autograd.Function):
+    ''' one autograd node for the whole model: lets `loss.backward()` (reference train loop, train.py:391)
+        drive the hand-written backward pass; parameter gradients are written into the flat buffer. '''
+    @staticmethod
+    def forward(ctx, anchor, model, saved, *outs):
+        ctx.model, ctx.saved = model, saved
+        return tuple(o.view_as(o) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ctx.model._backward(ctx.saved, *grads)
+        return (None, None, None) + (None,) * len(grads)
+
+
+class DaftExprt(nn.Module):
+    def __init__(self, hparams):
+        super(DaftExprt, self).__init__()
+        hparams.frame_decoder['hidden_embed_dim'] = hparams.phoneme_encoder['hidden_embed_dim']  # model.py:675
+        self.hp = hparams
+        self.cd = torch.bfloat16 if getattr(hparams, 'compute_dtype', 'bf16') == 'bf16' else torch.float32
+        self._table = param_table(hparams)
+        gen = torch.Generator().manual_seed(int(torch.initial_seed()) & 0x7fffffff)
+        for name, shape, init in self._table:
+            node, parts = self, name.split('.')
+            for part in parts[:-1]:
+                if not hasattr(node, part):
+                    node.add_module(part, _Node())
+                node = getattr(node, part)
+            node.register_parameter(parts[-1], nn.Parameter(_init_tensor(shape, init, gen)))
+        assert [n for n, _ in self.named_parameters()] == [n for n, _, _ in self._table]
+        self._flat = self._gflat = None
+        self._packed, self._packed_version, self._param_version = {}, -1, 0
+        self.always_repack = True   # safe default for external optimizers; the fused trainer turns it off
+        self._anchor = None
+        self._step_id, self._site = 0, 0
+        self._pos = None
+        self.n_params = sum(int(np.prod(s)) for _, s, _ in self._table)
+        self._gemm_weights = [n for n, s, _ in self._table if
+                              (n.endswith('conv.weight') and s[1] > 1) or n.endswith('in_proj_weight') or
+                              n.endswith('out_proj.weight') or n == 'frame_decoder.projection.linear_layer.weight']
+        self._flatten()
+
+    # ------------------------------------------------------------------ flat parameter / gradient storage
+    def _apply(self, fn, *args, **kwargs):
+        out = super(DaftExprt, self)._apply(fn, *args, **kwargs)
+        self._flatten()
+        return out
+
+    def _flatten(self):
+        params = self._params = dict(self.named_parameters())
+        dev = next(iter(params.values())).device
+        flat = torch.empty(self.n_params, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        off = 0
+        self._P, self._G, self._offsets = {}, {}, {}
+        for name, shape, _ in self._table:
+            n = int(np.prod(shape))
+            p = params[name]
+            flat[off: off + n].copy_(p.data.reshape(-1).float())
+            p.data = flat[off: off + n].view(shape)
+            p.grad = gflat[off: off + n].view(shape)
+            self._P[name], self._G[name], self._offsets[name] = p.data, p.grad, (off, n)
+            off += n
+        self._flat, self._gflat = flat, gflat
+        self._pos = None
+        self.mark_updated()
+
+    def flat_parameters(self):
+        return self._flat
+
+    def flat_gradients(self):
+        return self._gflat
+
+    def mark_updated(self):
+        ''' call after the parameters changed outside of this module (optimizer step) '''
+        self._param_version += 1
+
+    def zero_grad(self, set_to_none=False):
+        if self._gflat is None:
+            return super(DaftExprt, self).zero_grad(set_to_none)
+        self._gflat.zero_()
+        for name, p in self._params.items():   # an external optimizer may have dropped the views
+            if p.grad is None or p.grad.data_ptr() != self._G[name].data_ptr():
+                p.grad = self._G[name]
+
+    def load_state_dict(self, state_dict, strict=True):
+        out = super(DaftExprt, self).load_state_dict(state_dict, strict)
+        self.mark_updated()
+        return out
+
+    # ------------------------------------------------------------------ device-side constants
+    def _pos_table(self):
+        ''' sinusoid table of `PositionalEncoding.__init__` (`model.py:123-130`), built with the same torch
+            ops so that it is bit-identical, uploaded once. '''
+        if self._pos is None:
+            dim, max_len = self.hp.phoneme_encoder['hidden_embed_dim'], 5000
+            pos = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+            div = torch.exp(torch.arange(0, dim, 2).float() * (-np.log(10000.) / dim))
+            table = torch.zeros(max_len, dim)
+            table[:, 0::2] = torch.sin(pos * div)
+            table[:, 1::2] = torch.cos(pos * div)
+            self._pos = table.to(self._flat.device)
+        return self._pos
+
+    def _weights(self, need_dgrad):
+        ''' MFMA-operand copies of the GEMM weights (compute dtype; forward and data-gradient packings) '''
+        stale = self._packed_version != self._param_version or self.always_repack
+        if stale:
+            for name in self._gemm_weights:
+                w = self._P[name]
+                self._packed[name] = ops.pack_conv_weight(w, self.cd, out=self._packed.get(name))
+            self._packed_version = self._param_version
+            self._dgrad_version = -1
+        if need_dgrad and getattr(self, '_dgrad_version', -1) != self._packed_version:
+            for name in self._gemm_weights:
+                if name == 'prosody_encoder.convs.0.conv.weight':
+                    continue   # the mel input needs no gradient
+                self._packed['T:' + name] = ops.pack_conv_weight(self._P[name], self.cd, transpose_flip=True,
+                                                                 out=self._packed.get('T:' + name))
+            self._dgrad_version = self._packed_version
+        return self._packed
+
+    def _seed(self):
+        self._site += 1
+        return (int(self.hp.seed) * 0x9E3779B1 + self._step_id * 0x85EBCA77 + self._site * 0xC2B2AE3D) & _MASK63
+
+    # ------------------------------------------------------------------ reference surface
+    def parse_batch(self, gpu, batch):
+        ''' `model.py:727-753`: H2D (non-blocking) + dtype casts; same tuple orders '''
+        dev = torch.device('cuda', gpu) if isinstance(gpu, int) else torch.device(gpu)
+        symbols, durations_float, durations_int, symbols_energy, symbols_pitch, input_lengths, \
+            frames_energy, frames_pitch, mel_specs, output_lengths, speaker_ids, feature_dirs, feature_files = batch
+        f = lambda t: t.to(dev, non_blocking=True).float().contiguous()
+        i = lambda t: t.to(dev, non_blocking=True).long().contiguous()
+        inputs = (i(symbols), f(durations_float), i(durations_int), f(symbols_energy), f(symbols_pitch), i(input_lengths),
+                  f(frames_energy), f(frames_pitch), f(mel_specs), i(output_lengths), i(speaker_ids))
+        targets = (inputs[1], inputs[3], inputs[4], inputs[8], inputs[10])
+        return inputs, targets, (feature_dirs, feature_files)
+
+    def forward(self, inputs):
+        ''' `model.py:755-787` (teacher-forced).  Returns (speaker_preds, [post_multipliers, enc_film, pp_film,
+            dec_film], [dur, energy, pitch, input_lengths], [mel (B, n_mel, T), output_lengths], weights). '''
+        train = self.training
+        need_grad = train and torch.is_grad_enabled()
+        with torch.no_grad():
+            outs, saved = self._forward(inputs, train, need_grad)
+        spk, films, (dur, energy, pitch), mel, weights = outs
+        input_lengths, output_lengths = inputs[5].detach(), inputs[9].detach()
+        post = self._P['prosody_encoder.post_multipliers'] if self.hp.post_mult_weight != 0. else 1.
+        if need_grad:
+            if self._anchor is None or self._anchor.device != mel.device:
+                self._anchor = torch.zeros(1, device=mel.device, requires_grad=True)
+            post_param = self._params.get('prosody_encoder.post_multipliers')
+            spk, dur, energy, pitch, mel = _Bridge.apply(self._anchor, self, saved, spk, dur, energy, pitch, mel)
+            post = post_param if post_param is not None else 1.
+        return spk, [post, films[0], films[1], films[2]], [dur, energy, pitch, input_lengths], \
+            [mel, output_lengths], weights
+
+    # ------------------------------------------------------------------ forward building blocks
+    def _fft_block_fwd(self, W, pre, x, film, lengths, cfg, train, save):
+        P, cd = self._P, self.cd
+        a_pre, f_pre = f'{pre}.attention', f'{pre}.feed_forward'
+        p_attn = cfg['attn_dropout'] if train else 0.
+        p_conv = cfg['conv_dropout'] if train else 0.
+        s = _Saved() if save else None
+        seeds = [self._seed() for _ in range(3)]
+        qkv = ops.conv1d(x, W[f'{a_pre}.multi_head_attention.in_proj_weight'], P[f'{a_pre}.multi_head_attention.in_proj_bias'],
+                         out_dtype=cd)
+        o, lse = ops.attention_fwd(qkv, lengths, cfg['attn_nb_heads'], p_attn, seeds[0], need_lse=save)
+        proj = ops.conv1d(o, W[f'{a_pre}.multi_head_attention.out_proj.weight'], P[f'{a_pre}.multi_head_attention.out_proj.bias'],
+                          out_dtype=torch.float32)
+        a, s1, mean1, rstd1 = ops.layernorm_fwd(proj, P[f'{a_pre}.layer_norm.weight'], P[f'{a_pre}.layer_norm.bias'], residual=x,
+                                                lengths=lengths, save=save, save_s=save, p_pre=p_attn, seed_pre=seeds[1])
+        h = ops.conv1d(a, W[f'{f_pre}.convs.0.conv.weight'], P[f'{f_pre}.convs.0.conv.bias'], out_dtype=cd, relu=True)
+        z = ops.conv1d(h, W[f'{f_pre}.convs.2.conv.weight'], P[f'{f_pre}.convs.2.conv.bias'], out_dtype=torch.float32)
+        u, s2, mean2, rstd2 = ops.layernorm_fwd(z, P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'], residual=a,
+                                                film=film, lengths=lengths, save=save, save_s=save, p_pre=p_conv, seed_pre=seeds[2])
+        if save:
+            s.pre, s.cfg, s.x, s.film, s.lengths = pre, cfg, x, film, lengths
+            s.qkv, s.o, s.lse, s.s1, s.mean1, s.rstd1, s.a, s.h, s.s2, s.mean2, s.rstd2 = qkv, o, lse, s1, mean1, rstd1, a, h, s2, mean2, rstd2
+            s.seeds, s.p_attn, s.p_conv = seeds, p_attn, p_conv
+        return u, s
+
+    def _conv_ln_fwd(self, W, conv_name, ln_name, x, p_drop, out_dtype, save, film=None, lengths=None):
+        ''' conv k3 -> ReLU -> LayerNorm -> Dropout [-> FiLM -> mask]  (prenet `model.py:341-363`, predictor 528-566) '''
+        P = self._P
+        cout = P[f'{conv_name}.conv.weight'].shape[0]
+        c_dtype = torch.float32 if (self.cd == torch.float32 or cout == 128) else self.cd   # wide tensors in the MFMA operand type
+        c = ops.conv1d(x, W[f'{conv_name}.conv.weight'], P[f'{conv_name}.conv.bias'], relu=True, out_dtype=c_dtype)
+        seed = self._seed()
+        y, _, mean, rstd = ops.layernorm_fwd(c, P[f'{ln_name}.weight'], P[f'{ln_name}.bias'], film=film, lengths=lengths,
+                                             out_dtype=out_dtype, save=save, p_post=p_drop, seed_post=seed)
+        s = None
+        if save:
+            s = _Saved()
+            s.conv_name, s.ln_name, s.x, s.c, s.mean, s.rstd, s.p, s.seed, s.film, s.lengths = \
+                conv_name, ln_name, x, c, mean, rstd, p_drop, seed, film, lengths
+        return y, s
+
+    def _prosody_encoder_fwd(self, W, frames_energy, frames_pitch, mel_specs, speaker_ids, output_lengths, train, save):
+        ''' `model.py:391-464` '''
+        P, hp, cfg, pre = self._P, self.hp, self.hp.prosody_encoder, 'prosody_encoder'
+        p_conv = cfg['conv_dropout'] if train else 0.
+        s = _Saved()
+        x = mel_specs.transpose(1, 2).contiguous()   # (B, T, n_mel) channel-last view of the input batch
+        wide = self.cd
+        l1, s.c1 = self._conv_ln_fwd(W, f'{pre}.convs.0', f'{pre}.convs.2', x, p_conv, wide, save)
+        l2, s.c2 = self._conv_ln_fwd(W, f'{pre}.convs.4', f'{pre}.convs.6', l1, p_conv, wide, save)
+        l3, s.c3 = self._conv_ln_fwd(W, f'{pre}.convs.8', f'{pre}.convs.10', l2, p_conv, torch.float32, save)
+        x0 = ops.scalar_embed_fwd([frames_energy, frames_pitch],
+                                  [P[f'{pre}.energy_embedding.conv.weight'], P[f'{pre}.pitch_embedding.conv.weight']],
+                                  [P[f'{pre}.energy_embedding.conv.bias'], P[f'{pre}.pitch_embedding.conv.bias']],
+                                  base=l3, pos_table=self._pos_table(), lengths=output_lengths)
+        s.blocks = []
+        for blk in range(cfg['nb_blocks']):
+            x0, sb = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x0, None, output_lengths, cfg, train, save)
+            s.blocks.append(sb)
+        emb = ops.masked_mean_fwd(x0, output_lengths)
+        z = ops.gather_add_fwd(emb, P[f'{pre}.spk_embedding.weight'], speaker_ids)
+        g_raw = ops.linear_small_fwd(z, P[f'{pre}.gammas_predictor.linear_layer.weight'], P[f'{pre}.gammas_predictor.linear_layer.bias'])
+        b_raw = ops.linear_small_fwd(z, P[f'{pre}.betas_predictor.linear_layer.weight'], P[f'{pre}.betas_predictor.linear_layer.bias'])
+        layout = film_layout(hp)
+        nb, ch = [n for n, _ in layout], [c for _, c in layout]
+        post = P[f'{pre}.post_multipliers'] if hp.post_mult_weight != 0. else None
+        films = ops.film_assemble_fwd(g_raw, b_raw, post, nb, ch)
+        s.T, s.z, s.g_raw, s.b_raw, s.nb, s.ch, s.post = x0.shape[1], z, g_raw, b_raw, nb, ch, post
+        s.frames_energy, s.frames_pitch, s.speaker_ids, s.output_lengths = frames_energy, frames_pitch, speaker_ids, output_lengths
+        return emb, films, s
+
+    def _classifier_fwd(self, emb):
+        ''' `model.py:285-292`; the gradient reversal is an identity here and a sign flip in `_backward` '''
+        P, pre = self._P, 'speaker_classifier.classifier'
+        h1 = ops.linear_small_fwd(emb, P[f'{pre}.1.linear_layer.weight'], P[f'{pre}.1.linear_layer.bias'], relu=True)
+        h2 = ops.linear_small_fwd(h1, P[f'{pre}.3.linear_layer.weight'], P[f'{pre}.3.linear_layer.bias'], relu=True)
+        logits = ops.linear_small_fwd(h2, P[f'{pre}.5.linear_layer.weight'], P[f'{pre}.5.linear_layer.bias'])
+        return logits, (emb, h1, h2)
+
+    def _phoneme_encoder_fwd(self, W, symbols, film, input_lengths, train, save):
+        ''' `model.py:490-509` '''
+        cfg, pre = self.hp.phoneme_encoder, 'phoneme_encoder'
+        x = ops.embed_pos_fwd(symbols, self._P[f'{pre}.symbols_embedding.weight'], self._pos_table(), input_lengths)
+        blocks = []
+        for blk in range(cfg['nb_blocks']):
+            x, sb = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x, film[:, blk, :], input_lengths, cfg, train, save)
+            blocks.append(sb)
+        return x, blocks
+
+    def _predictor_fwd(self, W, enc, film, input_lengths, train, save):
+        ''' `model.py:549-575` (nb_blocks = 1 in every published config; more blocks chain the same pattern) '''
+        cfg, pre, P = self.hp.local_prosody_predictor, 'prosody_predictor', self._P
+        p = cfg['conv_dropout'] if train else 0.
+        x, saved = enc, []
+        for blk in range(cfg['nb_blocks']):
+            x, s1 = self._conv_ln_fwd(W, f'{pre}.blocks.{blk}.0', f'{pre}.blocks.{blk}.2', x, p, self.cd, save)
+            last = blk == cfg['nb_blocks'] - 1
+            x, s2 = self._conv_ln_fwd(W, f'{pre}.blocks.{blk}.4', f'{pre}.blocks.{blk}.6', x, p, torch.float32 if last else self.cd,
+                                      save, film=film[:, blk, :], lengths=input_lengths if last else None)
+            saved.append((s1, s2))
+        L = x.shape[1]
+        y = ops.linear_small_fwd(x, P[f'{pre}.projection.linear_layer.weight'], P[f'{pre}.projection.linear_layer.bias'],
+                                 mask_lengths=input_lengths, N=L)
+        return y, (saved, x, y)
+
+    def _gu_params(self):
+        P, pre = self._P, 'gaussian_upsampling'
+        return {'w_dur': P[f'{pre}.duration_projection.conv.weight'], 'b_dur': P[f'{pre}.duration_projection.conv.bias'],
+                'w_en': P[f'{pre}.energy_projection.conv.weight'], 'b_en': P[f'{pre}.energy_projection.conv.bias'],
+                'w_pi': P[f'{pre}.pitch_projection.conv.weight'], 'b_pi': P[f'{pre}.pitch_projection.conv.bias'],
+                'w_range': P[f'{pre}.projection.0.linear_layer.weight'], 'b_range': P[f'{pre}.projection.0.linear_layer.bias']}
+
+    def _upsample_fwd(self, enc, durations_float, durations_int, energies, pitch, input_lengths, output_lengths, T, save):
+        ''' `model.py:608-662` + the decoder's positional add and mask (`model.py:696-701`) '''
+        GP = self._gu_params()
+        xp, ranges, r_pre, rin = ops.gu_prepare(enc, durations_float, energies, pitch, input_lengths, GP, save=save)
+        means, totals = ops.gu_means(durations_int)
+        dec_in, weights = ops.gu_upsample_fwd(xp, ranges, means, input_lengths, T, output_lengths, self._pos_table())
+        s = None
+        if save:
+            s = _Saved()
+            s.xp, s.ranges, s.r_pre, s.rin, s.means, s.weights = xp, ranges, r_pre, rin, means, weights
+            s.durations_float, s.energies, s.pitch, s.input_lengths, s.output_lengths = durations_float, energies, pitch, input_lengths, output_lengths
+        return dec_in, weights, totals, s
+
+    def _decoder_fwd(self, W, x, film, output_lengths, train, save):
+        ''' `model.py:689-710` (positional add + mask already applied by the upsampling kernel) '''
+        cfg, pre, P = self.hp.frame_decoder, 'frame_decoder', self._P
+        blocks = []
+        for blk in range(cfg['nb_blocks']):
+            x, sb = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x, film[:, blk, :], output_lengths, cfg, train, save)
+            blocks.append(sb)
+        mel = ops.conv1d(x, W[f'{pre}.projection.linear_layer.weight'], P[f'{pre}.projection.linear_layer.bias'],
+                         out_dtype=torch.float32, mask_lengths=output_lengths, transposed_out=True)
+        return mel, (blocks, x)
+
+    def _forward(self, inputs, train, save):
+        symbols, durations_float, durations_int, symbols_energy, symbols_pitch, input_lengths, \
+            frames_energy, frames_pitch, mel_specs, output_lengths, speaker_ids = inputs
+        ops.H.require_gpu(symbols, mel_specs)
+        self._step_id += 1
+        self._site = 0
+        W = self._weights(need_dgrad=save)
+        S = _Saved() if save else None
+        emb, films, s_pe = self._prosody_encoder_fwd(W, frames_energy, frames_pitch, mel_specs, speaker_ids, output_lengths, train, save)
+        logits, s_cls = self._classifier_fwd(emb)
+        enc, s_enc = self._phoneme_encoder_fwd(W, symbols, films[0], input_lengths, train, save)
+        y, s_pp = self._predictor_fwd(W, enc, films[1], input_lengths, train, save)
+        T = mel_specs.shape[2]
+        dec_in, weights, _, s_gu = self._upsample_fwd(enc, durations_float, durations_int, symbols_energy, symbols_pitch,
+                                                      input_lengths, output_lengths, T, save)
+        mel, s_dec = self._decoder_fwd(W, dec_in, films[2], output_lengths, train, save)
+        dur, energy, pitch = y[:, :, 0].contiguous(), y[:, :, 1].contiguous(), y[:, :, 2].contiguous()
+        if save:
+            S.pe, S.cls, S.enc, S.pp, S.gu, S.dec, S.films, S.symbols, S.input_lengths, S.enc_out, S.x_mel = \
+                s_pe, s_cls, s_enc, s_pp, s_gu, s_dec, films, symbols, input_lengths, enc, mel_specs
+        return (logits, films, (dur, energy, pitch), mel, weights), S
+
+    # ------------------------------------------------------------------ backward building blocks
+    def _fft_block_bwd(self, W, s, du, dfilm):
+        ''' du: grad wrt the block output (fp32).  Returns grad wrt the block input. dfilm: (B, 2C) view or None '''
+        P, G, cd = self._P, self._G, self.cd
+        a_pre, f_pre = f'{s.pre}.attention', f'{s.pre}.feed_forward'
+        ds2, dz = ops.layernorm_bwd(du, s.s2, s.mean2, s.rstd2, P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'],
+                                    G[f'{f_pre}.layer_norm.weight'], G[f'{f_pre}.layer_norm.bias'], film=s.film, dfilm=dfilm,
+                                    lengths=s.lengths, p_pre=s.p_conv, seed_pre=s.seeds[2])
+        da = ds2
+        ops.conv1d_wgrad(dz, s.h, G[f'{f_pre}.convs.2.conv.weight'], G[f'{f_pre}.convs.2.conv.bias'], cd, s.lengths)
+        dh = ops.conv1d(dz, W[f'T:{f_pre}.convs.2.conv.weight'], None, out_dtype=cd, relu_gate=s.h)
+        ops.conv1d_wgrad(dh, s.a, G[f'{f_pre}.convs.0.conv.weight'], G[f'{f_pre}.convs.0.conv.bias'], cd, s.lengths)
+        ops.conv1d(dh, W[f'T:{f_pre}.convs.0.conv.weight'], None, out=da, accumulate=True)
+        ds1, dproj = ops.layernorm_bwd(da, s.s1, s.mean1, s.rstd1, P[f'{a_pre}.layer_norm.weight'], P[f'{a_pre}.layer_norm.bias'],
+                                       G[f'{a_pre}.layer_norm.weight'], G[f'{a_pre}.layer_norm.bias'], lengths=s.lengths,
+                                       p_pre=s.p_attn, seed_pre=s.seeds[1])
+        dx = ds1
+        mha = f'{a_pre}.multi_head_attention'
+        ops.conv1d_wgrad(dproj, s.o, G[f'{mha}.out_proj.weight'], G[f'{mha}.out_proj.bias'], cd, s.lengths)
+        d_o = ops.conv1d(dproj, W[f'T:{mha}.out_proj.weight'], None, out_dtype=cd)
+        dqkv = ops.attention_bwd(s.qkv, s.o, d_o, s.lse, s.lengths, s.cfg['attn_nb_heads'], s.p_attn, s.seeds[0])
+        ops.conv1d_wgrad(dqkv, s.x, G[f'{mha}.in_proj_weight'], G[f'{mha}.in_proj_bias'], cd, s.lengths)
+        ops.conv1d(dqkv, W[f'T:{mha}.in_proj_weight'], None, out=dx, accumulate=True)
+        return dx
+
+    def _conv_ln_bwd(self, W, s, dy, dfilm=None, need_dx=True, dx_out=None, lengths_hint=None):
+        ''' backward of `_conv_ln_fwd`; returns grad wrt its input (dtype = the input's) '''
+        P, G = self._P, self._G
+        dc, _ = ops.layernorm_bwd(dy, s.c, s.mean, s.rstd, P[f'{s.ln_name}.weight'], P[f'{s.ln_name}.bias'],
+                                  G[f'{s.ln_name}.weight'], G[f'{s.ln_name}.bias'], film=s.film, dfilm=dfilm, lengths=s.lengths,
+                                  d_dtype=s.c.dtype, p_post=s.p, seed_post=s.seed, relu_input=True)
+        ops.conv1d_wgrad(dc, s.x, G[f'{s.conv_name}.conv.weight'], G[f'{s.conv_name}.conv.bias'], self.cd, lengths_hint)
+        if not need_dx:
+            return None
+        if dx_out is not None:
+            return ops.conv1d(dc, W[f'T:{s.conv_name}.conv.weight'], None, out=dx_out, accumulate=True)
+        return ops.conv1d(dc, W[f'T:{s.conv_name}.conv.weight'], None, out_dtype=s.x.dtype)
+
+    def _backward(self, S, d_spk, d_dur, d_energy, d_pitch, d_mel, d_mel_is_bt=False, section_done=None):
+        ''' hand-written backward pass: accumulates every parameter gradient into the flat gradient buffer.
+            d_mel: (B, n_mel, T) like the output, or (B, T, n_mel) when d_mel_is_bt.
+            section_done(name): called as soon as every gradient of a top-level module is final, in reverse
+            registration order (frame_decoder first) -- the data-parallel reducer launches that slice's all-reduce. '''
+        done = section_done or (lambda name: None)
+        hp, P, G = self.hp, self._P, self._G
+        W = self._packed
+        dev = S.enc_out.device
+        B, L = S.symbols.shape
+        zeros = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        layout = film_layout(hp)
+        dfilms = [zeros(B, nb, 2 * ch) for nb, ch in layout]
+        # ---- decoder
+        blocks, dec_x = S.dec
+        pre = 'frame_decoder'
+        if d_mel is None:
+            d_dec = zeros(*dec_x.shape)
+        else:
+            d_mel_bt = d_mel if d_mel_is_bt else d_mel.transpose(1, 2).contiguous()
+            wname = f'{pre}.projection.linear_layer'
+            ops.conv1d_wgrad(d_mel_bt, dec_x, G[f'{wname}.weight'], G[f'{wname}.bias'], self.cd, S.gu.output_lengths)
+            d_dec = ops.conv1d(d_mel_bt, W[f'T:{wname}.weight'], None, out_dtype=torch.float32)
+        for blk in reversed(range(len(blocks))):
+            d_dec = self._fft_block_bwd(W, blocks[blk], d_dec, dfilms[2][:, blk, :])
+        done('frame_decoder')
+        # ---- Gaussian upsampling (ground-truth durations / energy / pitch: no gradient into the predictor here)
+        g = S.gu
+        GP = self._gu_params()
+        dxp, drin, dr = ops.gu_upsample_bwd(d_dec, g.xp, g.weights, g.means, g.ranges, g.r_pre, GP['w_range'], g.input_lengths,
+                                            g.output_lengths)
+        gu = 'gaussian_upsampling'
+        ops.linear_small_bwd(dr.unsqueeze(2), None, g.rin, GP['w_range'], G[f'{gu}.projection.0.linear_layer.weight'],
+                             G[f'{gu}.projection.0.linear_layer.bias'], need_dx=False)
+        ops.scalar_embed_bwd(drin, [g.durations_float], [G[f'{gu}.duration_projection.conv.weight']],
+                             [G[f'{gu}.duration_projection.conv.bias']])
+        ops.scalar_embed_bwd(dxp, [g.energies, g.pitch],
+                             [G[f'{gu}.energy_projection.conv.weight'], G[f'{gu}.pitch_projection.conv.weight']],
+                             [G[f'{gu}.energy_projection.conv.bias'], G[f'{gu}.pitch_projection.conv.bias']])
+        d_enc = dxp
+        done('gaussian_upsampling')
+        # ---- local prosody predictor
+        saved_pp, pp_x, pp_y = S.pp
+        if d_dur is not None:
+            dy = torch.stack((d_dur, d_energy, d_pitch), dim=2).contiguous()
+            ppn = 'prosody_predictor'
+            dx = ops.linear_small_bwd(dy, None, pp_x, P[f'{ppn}.projection.linear_layer.weight'],
+                                      G[f'{ppn}.projection.linear_layer.weight'], G[f'{ppn}.projection.linear_layer.bias'],
+                                      mask_lengths=S.input_lengths, N=L)
+            for blk in reversed(range(len(saved_pp))):
+                s1, s2 = saved_pp[blk]
+                dx = self._conv_ln_bwd(W, s2, dx, dfilm=dfilms[1][:, blk, :])
+                if blk == 0:
+                    self._conv_ln_bwd(W, s1, dx, dx_out=d_enc)
+                else:
+                    dx = self._conv_ln_bwd(W, s1, dx)
+        done('prosody_predictor')
+        # ---- phoneme encoder
+        for blk in reversed(range(len(S.enc))):
+            d_enc = self._fft_block_bwd(W, S.enc[blk], d_enc, dfilms[0][:, blk, :])
+        ops.embed_pos_bwd(S.symbols, d_enc, S.input_lengths, G['phoneme_encoder.symbols_embedding.weight'])
+        done('phoneme_encoder')
+        # ---- speaker classifier (+ gradient reversal, model.py:27-38)
+        pe = S.pe
+        emb, h1, h2 = S.cls
+        cl = 'speaker_classifier.classifier'
+        if d_spk is not None:
+            d_h2 = ops.linear_small_bwd(d_spk.contiguous(), None, h2, P[f'{cl}.5.linear_layer.weight'], G[f'{cl}.5.linear_layer.weight'],
+                                        G[f'{cl}.5.linear_layer.bias'])
+            d_h1 = ops.linear_small_bwd(d_h2, h2, h1, P[f'{cl}.3.linear_layer.weight'], G[f'{cl}.3.linear_layer.weight'],
+                                        G[f'{cl}.3.linear_layer.bias'], relu=True)
+            d_emb = ops.linear_small_bwd(d_h1, h1, emb, P[f'{cl}.1.linear_layer.weight'], G[f'{cl}.1.linear_layer.weight'],
+                                         G[f'{cl}.1.linear_layer.bias'], relu=True, dx_scale=-float(hp.lambda_reversal))
+        else:
+            d_emb = zeros(*emb.shape)
+        done('speaker_classifier')
+        # ---- FiLM head
+        pre = 'prosody_encoder'
+        dpost = G[f'{pre}.post_multipliers'] if pe.post is not None else None
+        dg_raw, db_raw = ops.film_assemble_bwd(pe.g_raw, pe.b_raw, pe.post, dfilms, dpost, pe.nb, pe.ch)
+        dz = ops.linear_small_bwd(dg_raw, None, pe.z, P[f'{pre}.gammas_predictor.linear_layer.weight'],
+                                  G[f'{pre}.gammas_predictor.linear_layer.weight'], G[f'{pre}.gammas_predictor.linear_layer.bias'])
+        dz2 = ops.linear_small_bwd(db_raw, None, pe.z, P[f'{pre}.betas_predictor.linear_layer.weight'],
+                                   G[f'{pre}.betas_predictor.linear_layer.weight'], G[f'{pre}.betas_predictor.linear_layer.bias'])
+        ops.add_(dz, dz2)
+        ops.gather_add_bwd(dz, pe.speaker_ids, G[f'{pre}.spk_embedding.weight'])
+        ops.add_(d_emb, dz)
+        # ---- prosody encoder trunk
+        dx = ops.masked_mean_bwd(d_emb, pe.output_lengths, pe.T)
+        for blk in reversed(range(len(pe.blocks))):
+            dx = self._fft_block_bwd(W, pe.blocks[blk], dx, None)
+        dl3 = ops.scalar_embed_bwd(dx, [pe.frames_energy, pe.frames_pitch],
+                                   [G[f'{pre}.energy_embedding.conv.weight'], G[f'{pre}.pitch_embedding.conv.weight']],
+                                   [G[f'{pre}.energy_embedding.conv.bias'], G[f'{pre}.pitch_embedding.conv.bias']],
+                                   lengths=pe.output_lengths, need_dbase=True)
+        dl2 = self._conv_ln_bwd(W, pe.c3, dl3, lengths_hint=pe.output_lengths)
+        dl1 = self._conv_ln_bwd(W, pe.c2, dl2, lengths_hint=pe.output_lengths)
+        self._conv_ln_bwd(W, pe.c1, dl1, need_dx=False, lengths_hint=pe.output_lengths)
+        done('prosody_encoder')
+
+    # ------------------------------------------------------------------ fused training step (no autograd graph)
+    SECTIONS = ('prosody_encoder', 'speaker_classifier', 'phoneme_encoder', 'prosody_predictor', 'gaussian_upsampling',
+                'frame_decoder')
+
+    def section_slices(self):
+        ''' {top-level module: (offset, numel)} in the flat parameter / gradient buffers (registration order) '''
+        out = {}
+        for name, _, _ in self._table:
+            off, n = self._offsets[name]
+            sec = name.split('.')[0]
+            lo, cnt = out.get(sec, (off, 0))
+            out[sec] = (lo, cnt + n)
+        return out
+
+    @torch.no_grad()
+    def forward_backward(self, inputs, targets, loss_weights, grad_scale=1., section_done=None):
+        ''' forward + 7-term loss + hand-written backward in one call: the body of `train.py:377-391` without an
+            autograd graph or host sync.  Gradients accumulate into `flat_gradients()`.  Returns the (8,) device
+            tensor [speaker, post_mult, duration, energy, pitch, mel_l1, mel_l2, total] (unscaled). '''
+        (logits, films, (dur, energy, pitch), mel, weights), S = self._forward(inputs, True, True)
+        dur_t, energy_t, pitch_t, mel_t, spk_ids = targets
+        B, n_mel, T = mel.shape
+        g = {'d_dur': torch.empty_like(dur), 'd_energy': torch.empty_like(energy), 'd_pitch': torch.empty_like(pitch),
+             'd_mel': torch.empty((B, T, n_mel), dtype=torch.float32, device=mel.device), 'd_spk': torch.empty_like(logits)}
+        post = self._P['prosody_encoder.post_multipliers'] if self.hp.post_mult_weight != 0. else None
+        d_post = self._G['prosody_encoder.post_multipliers'] if post is not None else None
+        terms = ops.loss_fwd_bwd(dur, energy, pitch, dur_t, energy_t, pitch_t, inputs[5], mel, mel_t, inputs[9], logits, spk_ids,
+                                 post, loss_weights, grads=g, d_post_mult=d_post, grad_scale=grad_scale, d_mel_transposed=True)
+        self._backward(S, g['d_spk'], g['d_dur'], g['d_energy'], g['d_pitch'], g['d_mel'], d_mel_is_bt=True,
+                       section_done=section_done)
+        self.last_outputs = (logits, films, (dur, energy, pitch), mel, weights)
+        return terms
+
+    # ------------------------------------------------------------------ inference (`model.py:789-923`)
+    def get_int_durations(self, duration_preds, hparams, dur_factors=None):
+        ''' `model.py:789-812` on the device: thresholds `duration_preds` in place, returns (duration_preds, durations_int).
+            Raises IndexError like the reference when an utterance is shorter than one analysis window. '''
+        dint, totals, status = ops.int_durations(duration_preds, hparams, dur_factors)
+        st = status.cpu()
+        if bool((st == 1).any()):
+            raise IndexError('list index out of range')   # extract_features.py:90 / 104
+        if bool((st == 2).any()):
+            raise RuntimeError('shape mismatch: durations and non-zero symbols differ in number')   # model.py:808
+        self._last_totals = totals
+        return duration_preds, dint
+
+    def _speaker_stats(self, hparams, device):
+        n = max(int(k.split(' ')[1]) for k in hparams.stats if k.startswith('spk ')) + 1 if hparams.stats else 0
+        mean, std = torch.zeros(max(n, 1)), torch.ones(max(n, 1))
+        for k, v in hparams.stats.items():
+            if k.startswith('spk '):
+                mean[int(k.split(' ')[1])], std[int(k.split(' ')[1])] = v['pitch']['mean'], v['pitch']['std']
+        return mean.to(device), std.to(device)
+
+    def pitch_shift(self, pitch_preds, pitch_factors, hparams, speaker_ids):
+        ''' `model.py:814-834` (in place) '''
+        mean, std = self._speaker_stats(hparams, pitch_preds.device)
+        ones = torch.ones_like(pitch_preds)
+        ops.prosody_control(ones.clone(), pitch_preds, ones, pitch_factors.contiguous(), torch.ones_like(pitch_preds, dtype=torch.long),
+                            0, speaker_ids, mean, std)
+        return pitch_preds
+
+    def pitch_multiply(self, pitch_preds, pitch_factors):
+        ''' `model.py:836-864` (in place) '''
+        ones = torch.ones_like(pitch_preds)
+        ops.prosody_control(ones.clone(), pitch_preds, ones, pitch_factors.contiguous(), torch.ones_like(pitch_preds, dtype=torch.long), 1)
+        return pitch_preds
+
+    @torch.no_grad()
+    def inference(self, inputs, pitch_transform, hparams):
+        ''' `model.py:866-923` '''
+        symbols, dur_factors, energy_factors, pitch_factors, input_lengths, \
+            energy_refs, pitch_refs, mel_spec_refs, ref_lengths, speaker_ids = inputs
+        if pitch_transform not in ('add', 'multiply'):
+            raise NotImplementedError
+        ops.H.require_gpu(symbols, mel_spec_refs)
+        self._site = 0
+        W = self._weights(need_dgrad=False)
+        _, films, _ = self._prosody_encoder_fwd(W, energy_refs, pitch_refs, mel_spec_refs, speaker_ids, ref_lengths, False, False)
+        enc, _ = self._phoneme_encoder_fwd(W, symbols, films[0], input_lengths, False, False)
+        y, _ = self._predictor_fwd(W, enc, films[1], input_lengths, False, False)
+        dur, energy, pitch = y[:, :, 0].contiguous(), y[:, :, 1].contiguous(), y[:, :, 2].contiguous()
+        dur, dur_int = self.get_int_durations(dur, hparams, dur_factors.contiguous())
+        if pitch_transform == 'add':
+            mean, std = self._speaker_stats(hparams, dur.device)
+            ops.prosody_control(energy, pitch, energy_factors.contiguous(), pitch_factors.contiguous(), dur_int, 0, speaker_ids, mean, std)
+        else:
+            ops.prosody_control(energy, pitch, energy_factors.contiguous(), pitch_factors.contiguous(), dur_int, 1)
+        output_lengths = self._last_totals
+        T = int(output_lengths.max())   # the one host sync of the synthesis path: sizes the output
+        dec_in, weights, _, _ = self._upsample_fwd(enc, dur, dur_int, energy, pitch, input_lengths, output_lengths, T, False)
+        assert dec_in.size(1) == T   # model.py:914
+        mel, _ = self._decoder_fwd(W, dec_in, films[2], output_lengths, False, False)
+        return [dur, dur_int, energy, pitch, input_lengths], [mel, output_lengths], weights

@@ -1,36 +1,330 @@
-"""Thin Python wrappers over the C ABI: allocate outputs with torch (device memory plumbing),
-pass raw pointers + the current stream.  One function per kernel family."""
+"""Thin Python wrappers over the C ABI (include/daft_exprt_hip.h): allocate outputs with torch
+(device-memory plumbing only), pass raw pointers + the current HIP stream.  One function per entry point."""
+import ctypes
+
 import torch
 
 from daft_exprt import _hip as H
 
+_INF = float('inf')
 
-def pack_conv_weight(w, dtype, transpose_flip=False):
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * max(1, len(tensors)))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def _int_array(vals):
+    return (ctypes.c_int * len(vals))(*vals)
+
+
+# ----------------------------------------------------------------------------- conv / linear on MFMA
+def pack_conv_weight(w, dtype, transpose_flip=False, out=None):
     ''' fp32 (Cout, Cin, taps) or (Cout, Cin) -> packed MFMA operand, see dx_pack_conv_weight '''
     H.require_gpu(w)
-    w = w.contiguous()
     cout, cin = w.shape[0], w.shape[1]
     taps = w.shape[2] if w.dim() == 3 else 1
     shape = (taps, cin, cout) if transpose_flip else (taps, cout, cin)
-    out = torch.empty(shape, dtype=dtype, device=w.device)
+    if out is None:
+        out = torch.empty(shape, dtype=dtype, device=w.device)
+    assert w.is_contiguous()
     H.check(H.lib().dx_pack_conv_weight(H.ptr(w), H.ptr(out), H.dt(out), cout, cin, taps, int(transpose_flip), H.stream()))
     return out
 
 
 def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, mask_lengths=None,
-           transposed_out=False, out=None):
+           transposed_out=False, out=None, accumulate=False):
     ''' x (B, N, Cin) [last dim contiguous]; w_packed (taps, Cout, Cin) -> (B, N, Cout) or (B, Cout, N) '''
     H.require_gpu(x, w_packed)
     B, N, Cin = x.shape
     taps, Cout, Cin_w = w_packed.shape
     assert Cin_w == Cin, (Cin_w, Cin)
-    assert x.stride(2) == 1 and x.stride(0) == N * x.stride(1)
+    assert x.stride(2) == 1 and (B == 1 or x.stride(0) == N * x.stride(1))
     out_dtype = out_dtype or x.dtype
     if out is None:
+        assert not accumulate
         out = torch.empty((B, Cout, N) if transposed_out else (B, N, Cout), dtype=out_dtype, device=x.device)
-    flags = (H.CONV_RELU if relu else 0) | (H.CONV_TRANSPOSED_OUT if transposed_out else 0)
-    ldy = out.stride(1)
+    flags = (H.CONV_RELU if relu else 0) | (H.CONV_TRANSPOSED_OUT if transposed_out else 0) | (4 if accumulate else 0)
     H.check(H.lib().dx_conv1d(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(bias),
-                              H.ptr(out), H.dt(out), ldy, H.ptr(relu_gate), H.dt(relu_gate) if relu_gate is not None else 0,
+                              H.ptr(out), H.dt(out), out.stride(1), H.ptr(relu_gate),
+                              H.dt(relu_gate) if relu_gate is not None else 0,
                               H.ptr(mask_lengths), B, N, Cin, Cout, taps, flags, H.stream()))
     return out
+
+
+def conv1d_wgrad(dy, x, dw, db, compute_dtype, lengths=None):
+    ''' dw (Cout, Cin, taps) / (Cout, Cin) fp32 and db (Cout) are ACCUMULATED. dy (B,N,Cout), x (B,N,Cin). '''
+    B, N, Cout = dy.shape
+    Cin = x.shape[2]
+    taps = dw.shape[2] if dw.dim() == 3 else 1
+    assert dw.shape[0] == Cout and dw.shape[1] == Cin and dy.stride(2) == 1 and x.stride(2) == 1
+    H.check(H.lib().dx_conv1d_wgrad(H.ptr(dy), H.dt(dy), dy.stride(1), H.ptr(x), H.dt(x), x.stride(1),
+                                    H._DT[compute_dtype], H.ptr(dw), H.ptr(db), H.ptr(lengths), B, N, Cin, Cout, taps,
+                                    H.stream()))
+
+
+# ----------------------------------------------------------------------------- LayerNorm (+ residual, dropout, FiLM, mask)
+def layernorm_fwd(x, gamma, beta, residual=None, film=None, lengths=None, out_dtype=torch.float32, save=False,
+                  save_s=False, p_pre=0., seed_pre=0, p_post=0., seed_post=0):
+    B, N, C = x.shape
+    assert x.is_contiguous()
+    y = torch.empty((B, N, C), dtype=out_dtype, device=x.device)
+    mean = rstd = s_out = None
+    if save:
+        mean = torch.empty(B * N, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+    if save_s:
+        s_out = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
+    ldf = film.stride(0) if film is not None else 0
+    H.check(H.lib().dx_layernorm_fwd(H.ptr(x), H.dt(x), H.ptr(residual), H.ptr(gamma), H.ptr(beta), H.ptr(film), ldf,
+                                     H.ptr(lengths), H.ptr(y), H.dt(y), H.ptr(s_out), H.ptr(mean), H.ptr(rstd), B, N, C,
+                                     float(p_pre), int(seed_pre), float(p_post), int(seed_post), H.stream()))
+    return y, s_out, mean, rstd
+
+
+def layernorm_bwd(dy, s_in, mean, rstd, gamma, beta, dgamma, dbeta, film=None, dfilm=None, lengths=None,
+                  d_dtype=torch.float32, p_pre=0., seed_pre=0, p_post=0., seed_post=0, relu_input=False):
+    ''' returns (ds, dx_pre); dx_pre is ds itself when there is no pre-dropout. dgamma/dbeta/dfilm accumulate. '''
+    B, N, C = dy.shape
+    ds = torch.empty((B, N, C), dtype=d_dtype, device=dy.device)
+    dx_pre = torch.empty_like(ds) if p_pre > 0. else None
+    ldf = film.stride(0) if film is not None else 0
+    lddf = dfilm.stride(0) if dfilm is not None else 0
+    H.check(H.lib().dx_layernorm_bwd(H.ptr(dy), H.dt(dy), H.ptr(s_in), H.dt(s_in), H.ptr(mean), H.ptr(rstd), H.ptr(gamma),
+                                     H.ptr(beta), H.ptr(film), ldf, H.ptr(lengths), H.ptr(ds), H.ptr(dx_pre), H.dt(ds),
+                                     H.ptr(dgamma), H.ptr(dbeta), H.ptr(dfilm), lddf, B, N, C, float(p_pre), int(seed_pre),
+                                     float(p_post), int(seed_post), int(relu_input), H.stream()))
+    return ds, (dx_pre if dx_pre is not None else ds)
+
+
+# ----------------------------------------------------------------------------- attention
+def attention_fwd(qkv, lengths, nb_heads, p_drop=0., seed=0, need_lse=True):
+    B, N, E3 = qkv.shape
+    E = E3 // 3
+    assert qkv.is_contiguous()
+    o = torch.empty((B, N, E), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, nb_heads, N), dtype=torch.float32, device=qkv.device) if need_lse else None
+    H.check(H.lib().dx_attention_fwd(H.ptr(qkv), H.dt(qkv), H.ptr(lengths), H.ptr(o), H.ptr(lse), B, N, nb_heads, E,
+                                     float(p_drop), int(seed), H.stream()))
+    return o, lse
+
+
+def attention_bwd(qkv, o, d_o, lse, lengths, nb_heads, p_drop=0., seed=0):
+    B, N, E3 = qkv.shape
+    E = E3 // 3
+    assert d_o.is_contiguous() and d_o.dtype == qkv.dtype
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, nb_heads, N), dtype=torch.float32, device=qkv.device)
+    H.check(H.lib().dx_attention_bwd(H.ptr(qkv), H.ptr(o), H.ptr(d_o), H.dt(qkv), H.ptr(lse), H.ptr(lengths), H.ptr(dqkv),
+                                     H.ptr(delta), B, N, nb_heads, E, float(p_drop), int(seed), H.stream()))
+    return dqkv
+
+
+# ----------------------------------------------------------------------------- pointwise / small heads
+def scalar_embed_fwd(feats, ws, biases, base=None, pos_table=None, lengths=None):
+    B, N = feats[0].shape
+    out = torch.empty((B, N, 128), dtype=torch.float32, device=feats[0].device)
+    H.check(H.lib().dx_scalar_embed_fwd(H.ptr(base), _ptr_array(feats), _ptr_array(ws), _ptr_array(biases), len(feats),
+                                        H.ptr(pos_table), H.ptr(lengths), H.ptr(out), B, N, 128, H.stream()))
+    return out
+
+
+def scalar_embed_bwd(dout, feats, dws, dbiases, lengths=None, need_dbase=False):
+    B, N, C = dout.shape
+    dbase = torch.empty_like(dout) if need_dbase else None
+    H.check(H.lib().dx_scalar_embed_bwd(H.ptr(dout), _ptr_array(feats), len(feats), H.ptr(lengths), H.ptr(dbase),
+                                        _ptr_array(dws), _ptr_array(dbiases), B, N, C, H.stream()))
+    return dbase
+
+
+def embed_pos_fwd(ids, table, pos_table, lengths):
+    B, N = ids.shape
+    out = torch.empty((B, N, 128), dtype=torch.float32, device=ids.device)
+    H.check(H.lib().dx_embed_pos_fwd(H.ptr(ids), H.ptr(table), H.ptr(pos_table), H.ptr(lengths), H.ptr(out), B, N, 128, H.stream()))
+    return out
+
+
+def embed_pos_bwd(ids, dout, lengths, dtable):
+    B, N = ids.shape
+    H.check(H.lib().dx_embed_pos_bwd(H.ptr(ids), H.ptr(dout), H.ptr(lengths), H.ptr(dtable), B, N, 128, H.stream()))
+
+
+def masked_mean_fwd(x, lengths):
+    B, N, C = x.shape
+    out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    H.check(H.lib().dx_masked_mean_fwd(H.ptr(x), H.ptr(lengths), H.ptr(out), B, N, C, H.stream()))
+    return out
+
+
+def masked_mean_bwd(dy, lengths, N):
+    B, C = dy.shape
+    dx = torch.empty((B, N, C), dtype=torch.float32, device=dy.device)
+    H.check(H.lib().dx_masked_mean_bwd(H.ptr(dy), H.ptr(lengths), H.ptr(dx), B, N, C, H.stream()))
+    return dx
+
+
+def film_assemble_fwd(g_raw, b_raw, post, nb, ch):
+    B = g_raw.shape[0]
+    films = [torch.empty((B, nb[m], 2 * ch[m]), dtype=torch.float32, device=g_raw.device) for m in range(3)]
+    H.check(H.lib().dx_film_assemble_fwd(H.ptr(g_raw), H.ptr(b_raw), H.ptr(post), H.ptr(films[0]), H.ptr(films[1]),
+                                         H.ptr(films[2]), _int_array(nb), _int_array(ch), B, H.stream()))
+    return films
+
+
+def film_assemble_bwd(g_raw, b_raw, post, dfilms, dpost, nb, ch):
+    B = g_raw.shape[0]
+    dg, db = torch.empty_like(g_raw), torch.empty_like(b_raw)
+    H.check(H.lib().dx_film_assemble_bwd(H.ptr(g_raw), H.ptr(b_raw), H.ptr(post), H.ptr(dfilms[0]), H.ptr(dfilms[1]),
+                                         H.ptr(dfilms[2]), H.ptr(dg), H.ptr(db), H.ptr(dpost), _int_array(nb), _int_array(ch),
+                                         B, H.stream()))
+    return dg, db
+
+
+def linear_small_fwd(x, w, bias, relu=False, mask_lengths=None, N=1):
+    K = x.shape[-1]
+    M = x.numel() // K
+    O = w.shape[0]
+    assert x.is_contiguous() and w.is_contiguous()
+    y = torch.empty(x.shape[:-1] + (O,), dtype=torch.float32, device=x.device)
+    H.check(H.lib().dx_linear_small_fwd(H.ptr(x), H.ptr(w), H.ptr(bias), H.ptr(y), H.ptr(mask_lengths), N, M, K, O, int(relu), H.stream()))
+    return y
+
+
+def linear_small_bwd(dy, y, x, w, dw, db, relu=False, mask_lengths=None, N=1, need_dx=True, dx_scale=1.):
+    K = x.shape[-1]
+    M = x.numel() // K
+    O = w.shape[0]
+    assert dy.is_contiguous() and x.is_contiguous()
+    dx = torch.empty_like(x) if need_dx else None
+    H.check(H.lib().dx_linear_small_bwd(H.ptr(dy), H.ptr(y), H.ptr(x), H.ptr(w), H.ptr(dx), float(dx_scale), H.ptr(dw), H.ptr(db),
+                                        H.ptr(mask_lengths), N, M, K, O, int(relu), H.stream()))
+    return dx
+
+
+def gather_add_fwd(a, table, ids):
+    B, C = a.shape
+    out = torch.empty_like(a)
+    H.check(H.lib().dx_gather_add_fwd(H.ptr(a), H.ptr(table), H.ptr(ids), H.ptr(out), B, C, H.stream()))
+    return out
+
+
+def gather_add_bwd(dz, ids, dtable):
+    B, C = dz.shape
+    H.check(H.lib().dx_gather_add_bwd(H.ptr(dz), H.ptr(ids), H.ptr(dtable), B, C, H.stream()))
+
+
+def add_(dst, src):
+    assert dst.is_contiguous() and src.is_contiguous() and dst.numel() == src.numel()
+    H.check(H.lib().dx_add_inplace(H.ptr(dst), H.ptr(src), dst.numel(), H.stream()))
+    return dst
+
+
+def colsum_(x, out):
+    C = x.shape[-1]
+    H.check(H.lib().dx_colsum(H.ptr(x), H.dt(x), H.ptr(out), x.numel() // C, C, H.stream()))
+
+
+# ----------------------------------------------------------------------------- Gaussian upsampling
+def gu_prepare(enc, dur_float, energy, pitch, in_lengths, P, save=False):
+    ''' P: dict with w_dur, b_dur, w_en, b_en, w_pi, b_pi, w_range, b_range '''
+    B, L, C = enc.shape
+    dev = enc.device
+    xp = torch.empty((B, L, C), dtype=torch.float32, device=dev)
+    ranges = torch.empty((B, L), dtype=torch.float32, device=dev)
+    r_pre = torch.empty((B, L), dtype=torch.float32, device=dev) if save else None
+    rin = torch.empty((B, L, C), dtype=torch.float32, device=dev) if save else None
+    H.check(H.lib().dx_gu_prepare(H.ptr(enc), H.ptr(dur_float), H.ptr(energy), H.ptr(pitch), H.ptr(in_lengths),
+                                  H.ptr(P['w_dur']), H.ptr(P['b_dur']), H.ptr(P['w_en']), H.ptr(P['b_en']), H.ptr(P['w_pi']),
+                                  H.ptr(P['b_pi']), H.ptr(P['w_range']), H.ptr(P['b_range']), H.ptr(xp), H.ptr(ranges),
+                                  H.ptr(r_pre), H.ptr(rin), B, L, C, H.stream()))
+    return xp, ranges, r_pre, rin
+
+
+def gu_means(durations_int):
+    B, L = durations_int.shape
+    means = torch.empty((B, L), dtype=torch.float32, device=durations_int.device)
+    totals = torch.empty((B,), dtype=torch.int64, device=durations_int.device)
+    H.check(H.lib().dx_gu_means(H.ptr(durations_int), H.ptr(means), H.ptr(totals), B, L, H.stream()))
+    return means, totals
+
+
+def gu_upsample_fwd(xp, ranges, means, in_lengths, T, out_lengths=None, pos_table=None):
+    B, L, C = xp.shape
+    weights = torch.empty((B, L, T), dtype=torch.float32, device=xp.device)
+    out = torch.empty((B, T, C), dtype=torch.float32, device=xp.device)
+    H.check(H.lib().dx_gu_upsample_fwd(H.ptr(xp), H.ptr(ranges), H.ptr(means), H.ptr(in_lengths), H.ptr(out_lengths),
+                                       H.ptr(pos_table), H.ptr(weights), H.ptr(out), B, L, T, C, H.stream()))
+    return out, weights
+
+
+def gu_upsample_bwd(g, xp, weights, means, ranges, r_pre, w_range, in_lengths, out_lengths):
+    B, L, C = xp.shape
+    T = weights.shape[2]
+    dev = xp.device
+    dw_ws = torch.empty((B, L, T), dtype=torch.float32, device=dev)
+    dsum_ws = torch.empty((B, T), dtype=torch.float32, device=dev)
+    dxp, drin = torch.empty_like(xp), torch.empty_like(xp)
+    dr = torch.empty((B, L), dtype=torch.float32, device=dev)
+    H.check(H.lib().dx_gu_upsample_bwd(H.ptr(g), H.ptr(xp), H.ptr(weights), H.ptr(means), H.ptr(ranges), H.ptr(r_pre),
+                                       H.ptr(w_range), H.ptr(in_lengths), H.ptr(out_lengths), H.ptr(dw_ws), H.ptr(dsum_ws),
+                                       H.ptr(dxp), H.ptr(drin), H.ptr(dr), B, L, T, C, H.stream()))
+    return dxp, drin, dr
+
+
+# ----------------------------------------------------------------------------- loss / optimizer / durations
+def loss_fwd_bwd(dur, energy, pitch, dur_t, energy_t, pitch_t, in_lengths, mel, mel_t, out_lengths, spk_logits, spk_ids,
+                 post_mult, weights, grads=None, d_post_mult=None, grad_scale=1., d_mel_transposed=False):
+    ''' weights = (w_spk, w_post, w_dur, w_energy, w_pitch, w_mel). grads: None or dict of output tensors
+        (d_dur, d_energy, d_pitch, d_mel, d_spk).  Returns the (8,) device tensor of loss terms. '''
+    B, L = dur.shape
+    n_mel, T = mel.shape[1], mel.shape[2]
+    terms = torch.empty(8, dtype=torch.float32, device=dur.device)
+    g = grads or {}
+    assert mel.is_contiguous() and mel_t.is_contiguous()
+    H.check(H.lib().dx_loss_fwd_bwd(H.ptr(dur), H.ptr(energy), H.ptr(pitch), H.ptr(dur_t), H.ptr(energy_t), H.ptr(pitch_t),
+                                    H.ptr(in_lengths), H.ptr(mel), H.ptr(mel_t), H.ptr(out_lengths), H.ptr(spk_logits),
+                                    H.ptr(spk_ids), H.ptr(post_mult), H.ptr(g.get('d_dur')), H.ptr(g.get('d_energy')),
+                                    H.ptr(g.get('d_pitch')), H.ptr(g.get('d_mel')), H.ptr(g.get('d_spk')), H.ptr(d_post_mult),
+                                    H.ptr(terms), B, L, T, n_mel, spk_logits.shape[1],
+                                    post_mult.numel() if post_mult is not None else 0, *[float(w) for w in weights],
+                                    float(grad_scale), int(d_mel_transposed), H.stream()))
+    return terms
+
+
+def sumsq(x, out=None):
+    out = out if out is not None else torch.empty(1, dtype=torch.float32, device=x.device)
+    H.check(H.lib().dx_sumsq(H.ptr(x), x.numel(), H.ptr(out), H.stream()))
+    return out
+
+
+def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, grad_norm_sq=None, clip_thresh=_INF):
+    H.check(H.lib().dx_adam_step(H.ptr(p), H.ptr(g), H.ptr(m), H.ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
+                                 float(eps), float(weight_decay), int(step), H.ptr(grad_norm_sq), float(clip_thresh), H.stream()))
+
+
+def scale_(x, s):
+    H.check(H.lib().dx_scale(H.ptr(x), x.numel(), float(s), H.stream()))
+
+
+def int_durations(duration_preds, hparams, dur_factors=None):
+    ''' in-place thresholding of duration_preds; returns (durations_int, totals, status) device tensors '''
+    B, L = duration_preds.shape
+    dev = duration_preds.device
+    assert duration_preds.is_contiguous()
+    dint = torch.empty((B, L), dtype=torch.int64, device=dev)
+    totals = torch.empty((B,), dtype=torch.int64, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    H.check(H.lib().dx_int_durations(H.ptr(duration_preds), H.ptr(dur_factors), H.ptr(dint), H.ptr(totals), H.ptr(status), B, L,
+                                     float(hparams.sampling_rate), int(hparams.filter_length), int(hparams.hop_length),
+                                     int(bool(hparams.centered)), H.stream()))
+    return dint, totals, status
+
+
+def prosody_control(energy, pitch, energy_factors, pitch_factors, durations_int, mode, speaker_ids=None, spk_mean=None,
+                    spk_std=None):
+    B, L = energy.shape
+    H.check(H.lib().dx_prosody_control(H.ptr(energy), H.ptr(pitch), H.ptr(energy_factors), H.ptr(pitch_factors),
+                                       H.ptr(durations_int), H.ptr(speaker_ids), H.ptr(spk_mean), H.ptr(spk_std), int(mode),
+                                       B, L, H.stream()))

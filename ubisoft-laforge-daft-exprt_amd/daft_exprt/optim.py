@@ -1,0 +1,66 @@
+"""Fused Adam over the model's flat parameter buffer (one kernel for all 14.7 M parameters).
+
+Same arithmetic as `torch.optim.Adam(params, betas, eps, weight_decay, amsgrad=False)` as configured by the
+reference trainer (`src/daft_exprt/train.py:299-301`): coupled L2 (`g += wd * p`), bias correction,
+`denom = sqrt(v_hat) + eps`; `clip_grad_norm_` (`train.py:399`) is folded into the same launch.
+`state_dict()` / `load_state_dict()` speak torch.optim.Adam's checkpoint format (per-parameter `exp_avg`,
+`exp_avg_sq`, `step`) so optimizer states round-trip with reference checkpoints (`train.py:73-78, 122-128`).
+"""
+import numpy as np
+import torch
+
+from daft_exprt import ops
+
+
+class FusedAdam(object):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=1e-6, grad_clip_thresh=float('inf')):
+        self.model = model
+        flat = model.flat_parameters()
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.grad_norm_sq = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self.step_count = 0
+        self.grad_clip_thresh = grad_clip_thresh
+        self.param_groups = [{'lr': lr, 'betas': tuple(betas), 'eps': eps, 'weight_decay': weight_decay, 'amsgrad': False,
+                              'params': list(range(len(model._table)))}]
+
+    def step(self):
+        ''' returns the device scalar sum(grad^2) (sqrt = the gradient norm the reference logs) '''
+        g = self.param_groups[0]
+        self.step_count += 1
+        flat, gflat = self.model.flat_parameters(), self.model.flat_gradients()
+        ops.sumsq(gflat, self.grad_norm_sq)
+        ops.adam_step(flat, gflat, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'], g['eps'], g['weight_decay'],
+                      self.step_count, self.grad_norm_sq, self.grad_clip_thresh)
+        self.model.mark_updated()
+        return self.grad_norm_sq
+
+    def zero_grad(self, set_to_none=False):
+        self.model.zero_grad()
+
+    def state_dict(self):
+        state = {}
+        for idx, (name, shape, _) in enumerate(self.model._table):
+            off, n = self.model._offsets[name]
+            state[idx] = {'step': torch.tensor(float(self.step_count)), 'exp_avg': self.exp_avg[off: off + n].view(shape).clone(),
+                          'exp_avg_sq': self.exp_avg_sq[off: off + n].view(shape).clone()}
+        groups = [{k: v for k, v in self.param_groups[0].items()}]
+        return {'state': state if self.step_count else {}, 'param_groups': groups}
+
+    def load_state_dict(self, sd):
+        for k in ('lr', 'betas', 'eps', 'weight_decay'):
+            if k in sd['param_groups'][0]:
+                self.param_groups[0][k] = sd['param_groups'][0][k]
+        self.param_groups[0]['betas'] = tuple(self.param_groups[0]['betas'])
+        steps = set()
+        for idx, (name, shape, _) in enumerate(self.model._table):
+            st = sd['state'].get(idx)
+            if st is None:
+                continue
+            off, n = self.model._offsets[name]
+            self.exp_avg[off: off + n].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[off: off + n].copy_(st['exp_avg_sq'].reshape(-1))
+            steps.add(int(float(st['step'])))
+        if steps:
+            assert len(steps) == 1, 'per-parameter step counts differ'
+            self.step_count = steps.pop()

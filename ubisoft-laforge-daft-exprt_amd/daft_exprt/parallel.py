@@ -1,0 +1,67 @@
+"""Single-node data parallelism: one process per MI355X, RCCL (torch.distributed backend "nccl") over xGMI.
+
+What the reference does (`src/daft_exprt/train.py:246-251, 293, 391`): wraps the model in
+DistributedDataParallel, which broadcasts rank-0 parameters once and all-reduces ~4 gradient buckets
+(<= 25 MiB) on EVERY micro-batch backward (no `no_sync()`).
+
+What this build does instead, with the same mathematics (sum of per-rank mean gradients / world):
+  * parameters and gradients are two flat fp32 buffers, so a "bucket" is a contiguous slice -- no
+    flatten/unflatten copies;
+  * the hand-written backward reports each top-level module as soon as its gradients are final
+    (frame_decoder -> gaussian_upsampling -> prosody_predictor -> phoneme_encoder -> speaker_classifier ->
+    prosody_encoder); the reducer immediately issues an asynchronous all-reduce for that slice, which RCCL runs
+    on its own stream while the remaining backward kernels keep the compute stream busy;
+  * with gradient accumulation only the LAST micro-batch communicates (one 58.9 MB all-reduce per optimizer
+    step instead of one per micro-batch);
+  * the 1/world mean is folded into the loss gradient scale, so no extra pass over the gradients.
+xGMI is point-to-point (7 links per GPU): a few large messages per step (3.4-30 MB) keep every link busy;
+tiny sections are merged with their neighbour so that nothing below ~1 MB goes out on its own.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradReducer(object):
+    def __init__(self, model, process_group=None, min_bucket_elems=1 << 18):
+        self.model, self.group = model, process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        slices = model.section_slices()
+        # buckets in backward order (reverse registration order); merge small sections into the next one
+        order = [s for s in reversed(model.SECTIONS) if s in slices]
+        self.buckets, pending = [], None
+        for sec in order:
+            off, n = slices[sec]
+            if pending is not None:
+                off, n = off, n + pending[1]     # sections are adjacent: pending sits right after this one
+                assert off + n == pending[0] + pending[1]
+            if n < min_bucket_elems and sec != order[-1]:
+                pending = (off, n)
+                continue
+            self.buckets.append((sec, off, n))
+            pending = None
+        self._ready_after = {sec: (off, n) for sec, off, n in self.buckets}
+        self._works = []
+
+    def broadcast_parameters(self, src=0):
+        ''' rank-0 parameters to everyone, once (DDP constructor semantics, train.py:293) '''
+        if self.world > 1:
+            dist.broadcast(self.model.flat_parameters(), src=src, group=self.group)
+            self.model.mark_updated()
+
+    def section_done(self, name):
+        ''' backward hook: launch the all-reduce of the bucket closed by this section '''
+        if self.world == 1 or name not in self._ready_after:
+            return
+        off, n = self._ready_after[name]
+        g = self.model.flat_gradients()[off: off + n]
+        self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    def all_reduce_now(self):
+        ''' non-overlapped variant (used when gradients were produced through the autograd bridge) '''
+        if self.world > 1:
+            dist.all_reduce(self.model.flat_gradients(), op=dist.ReduceOp.SUM, group=self.group)

@@ -1,0 +1,248 @@
+"""Trainer of the MI355X-native Daft-Exprt.
+
+Keeps the reference trainer's surface (`src/daft_exprt/train.py`): `update_learning_rate`, `save_checkpoint` /
+`load_checkpoint` (same checkpoint dict keys, `train.py:73-78`; `module.`-prefixed state dicts accepted),
+`train(gpu, hparams, log_file)`, `launch_training(...)` and the CLI flags `--data_set_dir --config_file
+--benchmark_dir --log_file --world_size --rank --multiprocessing_distributed --master` (`train.py:612-634`).
+
+Step loop = `train.py:368-401, 475-494` with the device work restructured for MI355X:
+  * `model.forward_backward` (forward + fused 7-term loss + hand-written backward, no autograd graph);
+  * gradient all-reduce over RCCL/xGMI overlapped with backward, once per optimizer step (`parallel.GradReducer`);
+  * one fused Adam kernel over the flat parameter buffer, `clip_grad_norm_` folded in (`optim.FusedAdam`);
+  * loss terms / gradient norm stay on the device and are fetched once per logged step (the reference does
+    8 `.item()` syncs per micro-batch, `loss.py:102-104`, `train.py:382`);
+  * the NaN check that guards logging is made rank-consistent (the reference's rank-local check can deadlock
+    its barrier).
+Validation figures / benchmark-sentence synthesis (MFA, librosa, Griffin-Lim) are outside the accelerated path.
+"""
+import argparse
+import json
+import logging
+import math
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from daft_exprt.data_loader import DaftExprtDataCollate, SyntheticUtterances
+from daft_exprt.hparams import HyperParams
+from daft_exprt.loss import DaftExprtLoss, KEYS
+from daft_exprt.model import DaftExprt
+from daft_exprt.optim import FusedAdam
+from daft_exprt.parallel import GradReducer
+
+_logger = logging.getLogger(__name__)
+FEATURES_HPARAMS = ['centered', 'cutoff', 'f0_interval', 'filter_length', 'hop_length', 'language', 'mel_fmax', 'mel_fmin',
+                    'min_clipping', 'max_f0', 'min_f0', 'n_mel_channels', 'order', 'sampling_rate', 'symbols', 'uv_cost',
+                    'uv_interval']   # extract_features.py:26-28
+
+
+def update_learning_rate(hparams, iteration):
+    ''' linear warm-up from `initial_learning_rate` to `max_learning_rate`, then inverse-sqrt decay (`train.py:139-151`) '''
+    lo, hi, warm = hparams.initial_learning_rate, hparams.max_learning_rate, hparams.warmup_steps
+    if iteration < warm:
+        return (hi - lo) / warm * iteration + lo
+    return iteration ** -0.5 * hi / warm ** -0.5
+
+
+def save_checkpoint(model, optimizer, hparams, learning_rate, iteration, best_val_loss=None, filepath=None):
+    ''' same dict as `train.py:73-78`; state_dict keys carry the `module.` prefix when trained data-parallel so that
+        reference consumers (`synthesize.py:43`, `fine_tune.py:40`) strip it as usual '''
+    os.makedirs(os.path.dirname(filepath), exist_ok=True)
+    _logger.info(f'Saving model and optimizer state at iteration "{iteration}" to "{filepath}"')
+    prefix = 'module.' if getattr(hparams, 'multiprocessing_distributed', False) else ''
+    state = {prefix + k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    config = {k: v for k, v in vars(hparams).items()}
+    torch.save({'iteration': iteration, 'learning_rate': learning_rate, 'best_val_loss': best_val_loss,
+                'state_dict': state, 'optimizer': optimizer.state_dict(), 'config_params': config}, filepath)
+
+
+def load_checkpoint(checkpoint_path, gpu, model, optimizer, hparams):
+    ''' `train.py:81-136`: feature-extraction hyper-parameters must match (assert), other differences are warnings '''
+    assert os.path.isfile(checkpoint_path), _logger.error(f'Checkpoint "{checkpoint_path}" does not exist')
+    _logger.info(f'Loading checkpoint "{checkpoint_path}"')
+    ckpt = torch.load(checkpoint_path, map_location='cpu', weights_only=False)
+    hp_ckpt = HyperParams(verbose=False, **ckpt['config_params'])
+    for param in list(vars(hparams)):
+        mine, theirs = getattr(hparams, param), getattr(hp_ckpt, param, None)
+        if param in FEATURES_HPARAMS:
+            assert mine == theirs, _logger.error(f'Parameter "{param}" is different between current config and the one used '
+                                                 f'in checkpoint -- Was {theirs} in checkpoint and now is {mine}')
+        elif not hasattr(hp_ckpt, param):
+            _logger.warning(f'Parameter "{param}" exists in the current training config but did not exist in checkpoint config')
+        elif mine != theirs:
+            _logger.warning(f'Parameter "{param}" has changed -- Was {theirs} in checkpoint and now is {mine}')
+    state = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in ckpt['state_dict'].items()}
+    try:
+        model.load_state_dict(state)
+    except RuntimeError as e:
+        _logger.error(f'Error when trying to load the checkpoint -- "{e}"\n')
+    if len(ckpt['optimizer']['param_groups']) != len(optimizer.param_groups):
+        _logger.warning('The optimizer in the loaded checkpoint does not have the same number of parameters '
+                        'as the blank optimizer -- Creating a new optimizer.')
+    else:
+        optimizer.load_state_dict(ckpt['optimizer'])
+    _logger.info(f'Loaded checkpoint "{checkpoint_path}" from iteration "{ckpt["iteration"]}"\n')
+    return model, optimizer, ckpt['iteration'], ckpt['learning_rate'], ckpt['best_val_loss']
+
+
+class Trainer(object):
+    ''' the device-side body of one optimizer step (`train.py:368-401`) for one rank '''
+    def __init__(self, model, hparams, world_size=1):
+        self.model, self.hp, self.world = model, hparams, world_size
+        self.criterion = DaftExprtLoss(0, hparams)
+        self.optimizer = FusedAdam(model, betas=hparams.betas, eps=hparams.epsilon, weight_decay=hparams.weight_decay,
+                                   grad_clip_thresh=hparams.grad_clip_thresh)
+        self.reducer = GradReducer(model) if world_size > 1 else None
+        if self.reducer is not None:
+            self.reducer.broadcast_parameters()
+        model.always_repack = False   # parameters only change through self.optimizer
+        self.terms = None
+
+    def step(self, micro_batches, iteration):
+        ''' micro_batches: list of (inputs, targets) already on the device (len = accumulation_steps).
+            Returns (terms (8,) device tensor summed over micro-batches / accumulation_steps, grad_norm_sq device scalar). '''
+        hp, model = self.hp, self.model
+        accum = len(micro_batches)
+        lr = update_learning_rate(hp, iteration)
+        self.optimizer.param_groups[0]['lr'] = lr
+        weights = self.criterion.weights(iteration)
+        scale = 1. / (accum * self.world)   # loss / accumulation_steps (train.py:379) and the DDP mean over ranks
+        total = None
+        for k, (inputs, targets) in enumerate(micro_batches):
+            hook = self.reducer.section_done if (self.reducer is not None and k == accum - 1) else None
+            terms = model.forward_backward(inputs, targets, weights, grad_scale=scale, section_done=hook)
+            total = terms if total is None else total + terms
+        if self.reducer is not None:
+            self.reducer.wait()
+        gnorm_sq = self.optimizer.step()
+        model.zero_grad()
+        self.terms = total / accum
+        return self.terms, gnorm_sq
+
+
+def validate(gpu, model, criterion, val_loader, hparams):
+    ''' `train.py:193-233` (scores only; figures are out of scope) '''
+    val_loss, n = 0., 0
+    indiv = {k: 0. for k in KEYS[2:]}
+    model.eval()
+    with torch.no_grad():
+        for batch in val_loader:
+            inputs, targets, _ = model.parse_batch(gpu, batch)
+            loss, terms = criterion(model(inputs), targets, iteration=0)
+            val_loss += float(loss)
+            for k in indiv:
+                indiv[k] += terms[k]
+            n += 1
+    model.train()
+    return val_loss / max(n, 1), {k: v / max(n, 1) for k, v in indiv.items()}
+
+
+def _loaders(hparams, rank, world):
+    ''' training batches: on-disk features when `training_files` exists, else the seeded synthetic utterances '''
+    collate = DaftExprtDataCollate(hparams)
+    if os.path.isfile(str(hparams.training_files)):
+        raise NotImplementedError('on-disk feature reader: SURVEY 8(f) row 1 (next round); use synthetic data')
+    n_items = getattr(hparams, 'synthetic_items', hparams.batch_size * hparams.accumulation_steps * world * 8)
+    ds = SyntheticUtterances(hparams, n_items, seed=hparams.seed, force_first_full=False)
+    idx = list(range(rank, n_items, world))   # DistributedSampler(shuffle=False) striding (data_loader.py:232)
+    subset = torch.utils.data.Subset(ds, idx)
+    return torch.utils.data.DataLoader(subset, batch_size=hparams.batch_size, shuffle=False, drop_last=True, collate_fn=collate,
+                                       num_workers=0)
+
+
+def train(gpu, hparams, log_file):
+    ''' one rank of the training job (`train.py:236-494`) '''
+    world = getattr(hparams, 'world_size', 1)
+    distributed = getattr(hparams, 'multiprocessing_distributed', False) and world > 1
+    if distributed:
+        hparams.rank = hparams.rank * hparams.ngpus_per_node + gpu
+        dist.init_process_group(backend=hparams.dist_backend, init_method=hparams.dist_url, world_size=world, rank=hparams.rank)
+    rank = getattr(hparams, 'rank', 0)
+    logging.basicConfig(handlers=[logging.StreamHandler(), logging.FileHandler(log_file)],
+                        format='%(asctime)s [%(levelname)s] %(message)s', datefmt='%Y-%m-%d %H:%M:%S',
+                        level=logging.INFO if rank == 0 else logging.ERROR)
+    torch.cuda.set_device(gpu)
+    torch.manual_seed(hparams.seed)
+    model = DaftExprt(hparams).cuda(gpu)
+    model.train()
+    trainer = Trainer(model, hparams, world if distributed else 1)
+    iteration, best_val_loss = 1, float('inf')
+    if hparams.checkpoint != '':
+        model, trainer.optimizer, iteration, _, best_val_loss = load_checkpoint(hparams.checkpoint, gpu, model, trainer.optimizer, hparams)
+        iteration += 1
+    loader = _loaders(hparams, rank, world if distributed else 1)
+    _logger.info(f'Batch size: {hparams.batch_size * hparams.accumulation_steps * (world if distributed else 1):_}')
+    metrics_path = os.path.join(os.path.dirname(log_file), 'metrics.jsonl')
+    start = time.time()
+    model.zero_grad()
+    micro = []
+    while iteration <= hparams.nb_iterations:
+        for batch in loader:
+            inputs, targets, _ = model.parse_batch(gpu, batch)
+            micro.append((inputs, targets))
+            if len(micro) < hparams.accumulation_steps:
+                continue
+            terms, gnorm_sq = trainer.step(micro, iteration)
+            micro = []
+            values = torch.cat((terms, gnorm_sq.sqrt())).tolist()   # one D2H copy per optimizer step
+            tot_loss, grad_norm = values[7], values[8]
+            nan = torch.tensor([0. if math.isfinite(tot_loss) else 1.], device=f'cuda:{gpu}')
+            if distributed:
+                dist.all_reduce(nan)   # rank-consistent NaN decision (see module docstring)
+            if float(nan) == 0. and rank == 0:
+                duration = time.time() - start
+                lr = trainer.optimizer.param_groups[0]['lr']
+                _logger.info(f'Train loss [{iteration}]: {tot_loss:.6f} Grad Norm {grad_norm:.6f} {duration:.2f}s/it (LR {lr:.6f})')
+                with open(metrics_path, 'a') as f:   # scalar names of DaftExprtLogger.log_training (logger.py:26-32)
+                    rec = {'iteration': iteration, 'DaftExprt.optimization/grad_norm': grad_norm,
+                           'DaftExprt.optimization/learning_rate': lr, 'DaftExprt.optimization/duration': duration,
+                           'DaftExprt.training/loss': tot_loss}
+                    rec.update({f'DaftExprt.training/{k}': v for k, v in zip(KEYS, values[:7])})
+                    f.write(json.dumps(rec) + '\n')
+            if iteration % hparams.iters_per_checkpoint == 0:
+                if rank == 0:
+                    path = os.path.join(hparams.output_directory, 'checkpoints', f'DaftExprt_{iteration}')
+                    save_checkpoint(model, trainer.optimizer, hparams, trainer.optimizer.param_groups[0]['lr'], iteration, best_val_loss, path)
+                if distributed:
+                    dist.barrier()
+            iteration += 1
+            start = time.time()
+            if iteration > hparams.nb_iterations:
+                break
+    if distributed:
+        dist.destroy_process_group()
+
+
+def launch_training(data_set_dir, config_file, benchmark_dir, log_file, world_size=1, rank=0,
+                    multiprocessing_distributed=True, master='tcp://localhost:54321'):
+    ''' `train.py:497-610`: rebuild HyperParams from the JSON config, one process per GPU '''
+    with open(config_file) as f:
+        config = json.load(f)
+    hparams = HyperParams(verbose=False, **config)
+    ngpus = torch.cuda.device_count()
+    hparams.data_set_dir, hparams.config_file, hparams.benchmark_dir = data_set_dir, config_file, benchmark_dir
+    hparams.rank, hparams.ngpus_per_node, hparams.dist_url = rank, ngpus, master.replace('localhost', '127.0.0.1')
+    hparams.multiprocessing_distributed = multiprocessing_distributed
+    hparams.world_size = ngpus * world_size if multiprocessing_distributed else 1
+    torch.manual_seed(hparams.seed)
+    if multiprocessing_distributed and hparams.world_size > 1:
+        torch.multiprocessing.spawn(train, nprocs=ngpus, args=(hparams, log_file))
+    else:
+        train(0, hparams, log_file)
+
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--data_set_dir', type=str, required=True)
+    parser.add_argument('--config_file', type=str, required=True)
+    parser.add_argument('--benchmark_dir', type=str, required=True)
+    parser.add_argument('--log_file', type=str, required=True)
+    parser.add_argument('--world_size', type=int, default=1)
+    parser.add_argument('--rank', type=int, default=0)
+    parser.add_argument('--multiprocessing_distributed', action='store_true')
+    parser.add_argument('--master', type=str, default='tcp://localhost:54321')
+    args = parser.parse_args()
+    launch_training(args.data_set_dir, args.config_file, args.benchmark_dir, args.log_file, args.world_size, args.rank,
+                    args.multiprocessing_distributed, args.master)
