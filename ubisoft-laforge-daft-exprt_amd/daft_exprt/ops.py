@@ -8,6 +8,26 @@ from daft_exprt import _hip as H
 
 _INF = float('inf')
 
+# Optional per-kernel timing probe used by bench.py: {family: [(start_event, end_event, padded_flops, N), ...]}.
+# Events are recorded on torch's current stream, which is the stream every kernel is launched on.
+PROBE = None
+
+
+class _Probe(object):
+    def __init__(self, family, flops, n_axis):
+        self.family, self.flops, self.n_axis = family, flops, n_axis
+
+    def __enter__(self):
+        if PROBE is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+
+    def __exit__(self, *exc):
+        if PROBE is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            PROBE.setdefault(self.family, []).append((self.start, end, self.flops, self.n_axis))
+
 
 def _ptr_array(tensors):
     arr = (ctypes.c_void_p * max(1, len(tensors)))()
@@ -47,7 +67,8 @@ def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, m
         assert not accumulate
         out = torch.empty((B, Cout, N) if transposed_out else (B, N, Cout), dtype=out_dtype, device=x.device)
     flags = (H.CONV_RELU if relu else 0) | (H.CONV_TRANSPOSED_OUT if transposed_out else 0) | (4 if accumulate else 0)
-    H.check(H.lib().dx_conv1d(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(bias),
+    with _Probe('conv_gemm', 2. * B * N * Cin * Cout * taps, N):
+      H.check(H.lib().dx_conv1d(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(bias),
                               H.ptr(out), H.dt(out), out.stride(1), H.ptr(relu_gate),
                               H.dt(relu_gate) if relu_gate is not None else 0,
                               H.ptr(mask_lengths), B, N, Cin, Cout, taps, flags, H.stream()))
@@ -60,7 +81,8 @@ def conv1d_wgrad(dy, x, dw, db, compute_dtype, lengths=None):
     Cin = x.shape[2]
     taps = dw.shape[2] if dw.dim() == 3 else 1
     assert dw.shape[0] == Cout and dw.shape[1] == Cin and dy.stride(2) == 1 and x.stride(2) == 1
-    H.check(H.lib().dx_conv1d_wgrad(H.ptr(dy), H.dt(dy), dy.stride(1), H.ptr(x), H.dt(x), x.stride(1),
+    with _Probe('conv_wgrad', 2. * B * N * Cin * Cout * taps, N):
+      H.check(H.lib().dx_conv1d_wgrad(H.ptr(dy), H.dt(dy), dy.stride(1), H.ptr(x), H.dt(x), x.stride(1),
                                     H._DT[compute_dtype], H.ptr(dw), H.ptr(db), H.ptr(lengths), B, N, Cin, Cout, taps,
                                     H.stream()))
 
