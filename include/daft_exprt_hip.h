@@ -48,17 +48,25 @@ const char* dx_last_error(void);
  *            (the ReLU derivative when this call is the data-gradient of a conv that fed a ReLU)
  *   mask_lengths NULL, or int64 (B): rows n >= mask_lengths[b] are written as zeros
  *            (masked_fill of model.py:259,262,569,707)
+ *   skip_lengths NULL, or int64 (B): padding early-out -- 128-row tiles that start at n0 >= skip_lengths[b] + 2 are
+ *            written as zeros without touching the MFMA pipe (rows past length + conv halo never reach a valid
+ *            output)
  * Positions outside [0, N) are zero padding (N = the batch's max length).  Cin % 8 == 0.
  */
 int dx_conv1d(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const float* bias,
               void* y, int y_dtype, long ldy, const void* relu_gate, int gate_dtype, const int64_t* mask_lengths,
-              int B, int N, int Cin, int Cout, int taps, int flags, void* stream);
+              const int64_t* skip_lengths, int B, int N, int Cin, int Cout, int taps, int flags, void* stream);
 
 /* Pack an fp32 (Cout, Cin, taps) PyTorch conv / (Cout, Cin) linear weight for dx_conv1d.
  *   transpose_flip = 0: out[tap][co][ci] = w[co][ci][tap]                (forward operand)
  *   transpose_flip = 1: out[tap][ci][co] = w[co][ci][taps-1-tap]         (data-gradient operand) */
 int dx_pack_conv_weight(const float* w, void* out, int out_dtype, int Cout, int Cin, int taps, int transpose_flip,
                         void* stream);
+/* Every GEMM weight of the model in one launch.  descs_dev: DEVICE array of n records
+ * {const float* w; void* out; int Cout, Cin, taps, transpose_flip; long begin;} (dx_pack_desc_size() bytes each, begin =
+ * running sum of Cout*Cin*taps); total_elems = sum of all element counts. */
+int dx_pack_desc_size(void);
+int dx_pack_conv_weights_batched(const void* descs_dev, int n, long total_elems, int out_dtype, void* stream);
 
 /* Weight / bias gradient of dx_conv1d (and of nn.Linear with taps = 1), accumulated with fp32 atomics into
  * dw (Cout, Cin, taps) [PyTorch layout] and db (Cout) [NULL to skip]:
@@ -76,11 +84,12 @@ int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const void* x, int 
  * 226-235 + 262 (FF block), 346-348/353-355/360-362 (prenet), 533-535/540-542 + 558-566 (predictor).
  * residual / film / lengths / s_out / mean+rstd may be NULL (feature off).  s_out, mean, rstd (fp32) are what
  * dx_layernorm_bwd needs.  Dropout masks are a counter-based hash of (seed, element index), regenerated
- * identically by the backward kernel; p = 0 disables. */
+ * identically by the backward kernel; p = 0 disables.  skip_lengths (NULL = off): rows n >= skip_lengths[b] + 2 are
+ * written as zeros without being read (padding early-out, same rule as dx_conv1d). */
 int dx_layernorm_fwd(const void* x, int x_dtype, const float* residual, const float* gamma, const float* beta,
-                     const float* film, long ldf, const int64_t* lengths, void* y, int y_dtype, float* s_out,
-                     float* mean, float* rstd, int B, int N, int C, float p_pre, uint64_t seed_pre,
-                     float p_post, uint64_t seed_post, void* stream);
+                     const float* film, long ldf, const int64_t* lengths, const int64_t* skip_lengths, void* y,
+                     int y_dtype, void* y_lp /* optional bf16 copy of y */, float* s_out, float* mean, float* rstd, int B, int N, int C, float p_pre,
+                     uint64_t seed_pre, float p_post, uint64_t seed_post, void* stream);
 
 /* Backward of dx_layernorm_fwd.  dy: grad wrt y.  s_in: s_out of the forward (or x itself when there was no
  * residual / pre-dropout).  Outputs: ds = grad wrt s (equals the residual-branch gradient); dx_pre = grad wrt x
@@ -89,8 +98,9 @@ int dx_layernorm_fwd(const void* x, int x_dtype, const float* residual, const fl
  * predictor); ds is then gated by (s_in > 0) so that it is the gradient of the conv's pre-activation. */
 int dx_layernorm_bwd(const void* dy, int dy_dtype, const void* s_in, int s_dtype, const float* mean,
                      const float* rstd, const float* gamma, const float* beta, const float* film, long ldf,
-                     const int64_t* lengths, void* ds, void* dx_pre, int d_dtype, float* dgamma, float* dbeta,
-                     float* dfilm, long lddf, int B, int N, int C, float p_pre, uint64_t seed_pre,
+                     const int64_t* lengths, const int64_t* skip_lengths, void* ds, void* dx_pre,
+                     void* dx_pre_lp /* optional bf16 copy of dx_pre (of ds when p_pre == 0) */, int d_dtype,
+                     float* dgamma, float* dbeta, float* dfilm, long lddf, int B, int N, int C, float p_pre, uint64_t seed_pre,
                      float p_post, uint64_t seed_post, int relu_input, void* stream);
 
 /* ---- K4: multi-head self-attention with key-padding mask, flash-style on MFMA (d_head in {16, 64}).

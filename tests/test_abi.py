@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_argument_errors_are_reported_not_ub():
     lib = H.lib()
-    rc = lib.dx_conv1d(None, 0, 8, None, 1, None, None, 0, 8, None, 0, None, 1, 1, 8, 8, 3, 0, None)
+    rc = lib.dx_conv1d(None, 0, 8, None, 1, None, None, 0, 8, None, 0, None, None, 1, 1, 8, 8, 3, 0, None)
     assert rc == -1 and b'null' in lib.dx_last_error()
-    rc = lib.dx_conv1d(8, 0, 8, 8, 1, None, 8, 0, 8, None, 0, None, 1, 1, 12, 8, 3, 0, None)
+    rc = lib.dx_conv1d(8, 0, 8, 8, 1, None, 8, 0, 8, None, 0, None, None, 1, 1, 12, 8, 3, 0, None)
     assert rc == -2 and b'multiples of 8' in lib.dx_last_error()

@@ -1,0 +1,112 @@
+"""Kernel-level checks that the golden/oracle parity tests cannot give: dropout is ON here.
+  * forward and backward kernels regenerate the SAME dropout mask (adjoint / directional-derivative identities);
+  * the keep rate is 1 - p; masked-out entries are exactly zero and kept entries are scaled by 1/(1-p)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _attn_inputs(B, N, H, E, seed, dtype):
+    g = torch.Generator().manual_seed(seed)
+    qkv = (torch.randn(B, N, 3 * E, generator=g) * 0.7).to(DEV).to(dtype)
+    lens = torch.randint(N // 2, N + 1, (B,), generator=g)
+    lens[0] = N
+    return qkv, lens.to(DEV)
+
+
+@pytest.mark.parametrize('H', [8, 2])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_attention_dropout_mask_is_shared_by_forward_and_backward(H, dtype):
+    from daft_exprt import ops
+    B, N, E, p, seed = 3, 150, 128, 0.3, 12345
+    qkv, lens = _attn_inputs(B, N, H, E, 1, dtype)
+    o, lse = ops.attention_fwd(qkv, lens, H, p, seed)
+    valid = (torch.arange(N, device=DEV)[None, :] < lens[:, None]).unsqueeze(2)
+    d_o = (torch.randn(B, N, E, device=DEV) * valid).to(dtype)
+    dqkv = ops.attention_bwd(qkv, o, d_o, lse, lens, H, p, seed).float()
+    tol = 2e-3 if dtype == torch.float32 else 6e-2
+    # (1) O is linear in V for a fixed mask:  <dO, O(V)> == <dV, V>
+    lhs = float((d_o.float() * o.float() * valid).sum())
+    rhs = float((dqkv[:, :, 2 * E:] * qkv[:, :, 2 * E:].float()).sum())
+    assert abs(lhs - rhs) <= tol * max(abs(lhs), 1.), (lhs, rhs)
+    # (2) directional derivative wrt q and k (central differences, same seed -> same mask)
+    if dtype == torch.float32:
+        g = torch.Generator().manual_seed(2)
+        d = torch.zeros_like(qkv)
+        d[:, :, : 2 * E] = torch.randn(B, N, 2 * E, generator=g).to(DEV)
+        eps = 2e-3
+        f = lambda t: float((ops.attention_fwd(t, lens, H, p, seed)[0].double() * d_o.double() * valid).sum())
+        num = (f(qkv + eps * d) - f(qkv - eps * d)) / (2 * eps)
+        ana = float((dqkv.double() * d.double()).sum())
+        assert abs(num - ana) <= 2e-2 * max(abs(ana), 1.), (num, ana)
+    # (3) a different seed gives a different output; p = 0 gives the deterministic one
+    o2, _ = ops.attention_fwd(qkv, lens, H, p, seed + 1)
+    assert float((o2.float() - o.float()).abs().max()) > 1e-3
+
+
+def test_attention_dropout_keep_rate():
+    ''' with v = 1 every output equals sum_j P_drop[i, j] = (kept probability mass) / (1 - p): its mean over queries is 1 '''
+    from daft_exprt import ops
+    B, N, H, E, p = 4, 512, 8, 128, 0.1
+    qkv, lens = _attn_inputs(B, N, H, E, 3, torch.float32)
+    qkv[:, :, : 2 * E] = 0.          # uniform attention: P = 1/len for every valid key
+    qkv[:, :, 2 * E:] = 1.
+    lens[:] = N
+    o, _ = ops.attention_fwd(qkv, lens, H, p, 777)
+    m = float(o.mean())
+    assert abs(m - 1.) < 5e-3, m          # E[keep]/(1-p) = 1; std of a 512-key average ~ 0.015 / sqrt(#queries)
+    per_q = o[:, :, 0]
+    assert float(per_q.std()) > 1e-3      # dropout really happened
+
+
+@pytest.mark.parametrize('C', [128, 256, 1024])
+def test_layernorm_dropout_forward_backward_consistency(C):
+    from daft_exprt import ops
+    B, N = 3, 70
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(B, N, C, generator=g).to(DEV)
+    res = torch.randn(B, N, C, generator=g).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    film = torch.randn(B, 2 * C, generator=g).to(DEV)
+    lens = torch.tensor([70, 33, 51], device=DEV)
+    kw = dict(p_pre=0.2, seed_pre=11, p_post=0.3, seed_post=22)
+    run = lambda xx: ops.layernorm_fwd(xx, gamma, beta, residual=res, film=film, lengths=lens, save=True, save_s=True, **kw)
+    y, s, mean, rstd = run(x)
+    dy = torch.randn(B, N, C, generator=g).to(DEV)
+    dgam, dbet, dfilm = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(B, 2 * C, device=DEV)
+    ds, dx = ops.layernorm_bwd(dy, s, mean, rstd, gamma, beta, dgam, dbet, film=film, dfilm=dfilm, lengths=lens, **kw)
+    d = torch.randn(B, N, C, generator=g).to(DEV)
+    eps = 1e-2
+    f = lambda t: float((run(t)[0].double() * dy.double()).sum())
+    num = (f(x + eps * d) - f(x - eps * d)) / (2 * eps)
+    ana = float((dx.double() * d.double()).sum())
+    assert abs(num - ana) <= 2e-2 * max(abs(ana), 1.), (num, ana)
+    # post-dropout keep rate on the valid rows (FiLM beta makes dropped entries equal film_beta, so test without FiLM)
+    y2, _, _, _ = ops.layernorm_fwd(x, gamma, beta, p_post=0.3, seed_post=5)
+    zeros = float((y2 == 0).float().mean())
+    assert abs(zeros - 0.3) < 0.02, zeros
+
+
+def test_wgrad_matches_autograd_all_dtype_pairs():
+    from daft_exprt import ops
+    from oracle import daft_exprt_cpu as O
+    g = torch.Generator().manual_seed(9)
+    B, N, Cin, Cout = 5, 300, 128, 256
+    lens = torch.tensor([300, 120, 255, 7, 64])
+    x = torch.randn(B, N, Cin, generator=g)
+    dy = torch.randn(B, N, Cout, generator=g) * (torch.arange(N)[None, :, None] < (lens[:, None, None] + 2))
+    for taps in (1, 3):
+        w = (torch.randn(Cout, Cin, taps, generator=g) / 10).requires_grad_(True)
+        b = torch.zeros(Cout, requires_grad=True)
+        (O.conv1d_cl(x, w, b) * dy).sum().backward()
+        for cd, dyt, xt, tol in ((torch.float32, torch.float32, torch.float32, 2e-5), (torch.bfloat16, torch.bfloat16, torch.float32, 2e-2),
+                                 (torch.bfloat16, torch.float32, torch.bfloat16, 2e-2), (torch.bfloat16, torch.bfloat16, torch.bfloat16, 2e-2)):
+            dw = torch.zeros(Cout, Cin, taps, device=DEV) if taps == 3 else torch.zeros(Cout, Cin, device=DEV)
+            db = torch.zeros(Cout, device=DEV)
+            ops.conv1d_wgrad(dy.to(DEV).to(dyt), x.to(DEV).to(xt), dw, db, cd, lens.to(DEV))
+            ref = w.grad if taps == 3 else w.grad[:, :, 0]
+            assert float((dw.cpu() - ref).abs().max()) <= tol * float(ref.abs().max()), (taps, cd, dyt, xt)
+            assert float((db.cpu() - b.grad).abs().max()) <= tol * float(b.grad.abs().max()) + 1e-4, (taps, cd)
+        w.grad = None

@@ -41,4 +41,25 @@ def bench_conv():
 
 
 if __name__ == '__main__':
-    {'conv': bench_conv}[sys.argv[1]]()
+    if sys.argv[1] == 'conv':
+        bench_conv()
+
+
+def bench_wgrad():
+    dev = torch.device('cuda:0')
+    B, N = 48, 1000
+    lens = torch.randint(250, 1001, (B,), device=dev)
+    lens[0] = N
+    for (cin, cout, taps, dyd, xd) in [(128, 1024, 3, torch.bfloat16, torch.float32), (1024, 128, 3, torch.float32, torch.bfloat16),
+                                       (1024, 1024, 3, torch.bfloat16, torch.bfloat16), (128, 384, 1, torch.bfloat16, torch.float32)]:
+        x = torch.randn(B, N, cin, device=dev).to(xd)
+        dy = torch.randn(B, N, cout, device=dev).to(dyd)
+        dw = torch.zeros(cout, cin, taps, device=dev) if taps > 1 else torch.zeros(cout, cin, device=dev)
+        db = torch.zeros(cout, device=dev)
+        ms = timeit(lambda: ops.conv1d_wgrad(dy, x, dw, db, torch.bfloat16, lens))
+        fl = 2. * float(lens.sum()) * cin * cout * taps
+        print(f'wgrad {cin:5d}->{cout:5d} k{taps}: {ms:8.3f} ms  {fl / ms / 1e9:9.1f} TFLOP/s (valid rows)')
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'wgrad':
+    bench_wgrad()

@@ -97,9 +97,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) oT[mt][r] = 0.f;
   float m = -INFINITY, l = 0.f;
-  const uint32_t th = athresh(a.p_drop);
+  const uint32_t th = athresh(a.p_drop), th16 = th >> 16;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-  const uint64_t drop_row = (((uint64_t)b * a.H + h) * N + (uint64_t)q) * N;
+  const uint32_t drop_key = dx_key32(a.seed, (uint32_t)(b * a.H + h)), drop_row = (uint32_t)q * (uint32_t)N;
 
   for (int kt0 = 0; kt0 < len; kt0 += KT) {
     stage_tile<TC, DH, LD>(Ks, base + E, ld_g, kt0, KT, N, tid);
@@ -133,10 +133,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         rs += __shfl_xor(rs, 32, 64);
         l = l * alpha + rs;
         m = m_new;
-        if (th) {
+        if (th) {   // one hash decides two keys (16 bits each): key pair (2e, 2e+1) -> hash of the even key
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            p[r] = dx_keep(a.seed, drop_row + (uint64_t)(k0 + dx_acc_row(r, g)), th) ? p[r] * inv_keep : 0.f;
+          for (int r = 0; r < 16; r += 2) {
+            const uint32_t hsh = dx_mix32((drop_row + (uint32_t)(k0 + dx_acc_row(r, g))) * 0x9E3779B1u + drop_key);
+            p[r] = (hsh & 0xffffu) >= th16 ? p[r] * inv_keep : 0.f;
+            p[r + 1] = (hsh >> 16) >= th16 ? p[r + 1] * inv_keep : 0.f;
+          }
         }
         frag_t pf[2] = {pack8<TC>(p), pack8<TC>(p + 8)};
 #pragma unroll
@@ -217,9 +220,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     }
     const long stat = ((long)b * a.H + h) * N + q;
     const float lse_q = q < N ? a.lse[stat] : 0.f, delta_q = q < N ? a.delta[stat] : 0.f;
-    const uint32_t th = athresh(a.p_drop);
+    const uint32_t th = athresh(a.p_drop), th16 = th >> 16;
     const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-    const uint64_t drop_row = (((uint64_t)b * a.H + h) * N + (uint64_t)q) * N;
+    const uint32_t drop_key = dx_key32(a.seed, (uint32_t)(b * a.H + h)), drop_row = (uint32_t)q * (uint32_t)N;
 
     for (int kt0 = 0; kt0 < len; kt0 += KT) {
       stage_tile<TC, DH, LD>(Ks, base + E, ld_g, kt0, KT, N, tid);
@@ -241,12 +244,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
           }
           float ds[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = k0 + dx_acc_row(r, g);
-            const float p = (q_valid && key < len) ? fast_exp<TC>(s[r] * a.scale - lse_q) : 0.f;
-            float kscale = 1.f;
-            if (th) kscale = dx_keep(a.seed, drop_row + (uint64_t)key, th) ? inv_keep : 0.f;
-            ds[r] = p * (dp[r] * kscale - delta_q);
+          for (int r = 0; r < 16; r += 2) {
+            const int key = k0 + dx_acc_row(r, g);   // registers r, r+1 hold keys key, key+1 (same hash, see forward)
+            float ks0 = 1.f, ks1 = 1.f;
+            if (th) {
+              const uint32_t hsh = dx_mix32((drop_row + (uint32_t)key) * 0x9E3779B1u + drop_key);
+              ks0 = (hsh & 0xffffu) >= th16 ? inv_keep : 0.f;
+              ks1 = (hsh >> 16) >= th16 ? inv_keep : 0.f;
+            }
+            const float p0 = (q_valid && key < len) ? fast_exp<TC>(s[r] * a.scale - lse_q) : 0.f;
+            const float p1 = (q_valid && key + 1 < len) ? fast_exp<TC>(s[r + 1] * a.scale - lse_q) : 0.f;
+            ds[r] = p0 * (dp[r] * ks0 - delta_q);
+            ds[r + 1] = p1 * (dp[r + 1] * ks1 - delta_q);
           }
           frag_t dsf[2] = {pack8<TC>(ds), pack8<TC>(ds + 8)};
 #pragma unroll
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 
 // =============================================================================== backward: dK, dV
 template <typename TC, int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   constexpr int LD = DH + APad<TC>::value, KS = DH / 16, MT = (DH + 31) / 32, WRAP = DH >= 32 ? 32 : 16;
   typedef typename Vec8<TC>::type frag_t;
   __shared__ __attribute__((aligned(16))) TC Qs[KT * LD];
@@ -306,9 +315,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
       kf[ks] = key < N ? *reinterpret_cast<const frag_t*>(base + E + (long)key * ld_g + ks * 16 + g * 8) : zero8<TC>();
       vf[ks] = key < N ? *reinterpret_cast<const frag_t*>(base + 2 * E + (long)key * ld_g + ks * 16 + g * 8) : zero8<TC>();
     }
-    const uint32_t th = athresh(a.p_drop);
+    const uint32_t th = athresh(a.p_drop), th16 = th >> 16;
     const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-    const uint64_t drop_bh = ((uint64_t)b * a.H + h) * N;
+    const uint32_t drop_key = dx_key32(a.seed, (uint32_t)(b * a.H + h));
 
     for (int qt0 = 0; qt0 < len; qt0 += KT) {
       stage_tile<TC, DH, LD>(Qs, base, ld_g, qt0, KT, N, tid);
@@ -340,7 +349,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
             const int qq = qt0 + row;
             const float p = (key_valid && qq < len) ? fast_exp<TC>(s[r] * a.scale - lse_s[row]) : 0.f;
             float kscale = 1.f;
-            if (th) kscale = dx_keep(a.seed, (drop_bh + (uint64_t)qq) * N + (uint64_t)key, th) ? inv_keep : 0.f;
+            if (th) {   // same decision as the forward: the hash of the even key of the pair, low / high 16 bits
+              const uint32_t hsh = dx_mix32(((uint32_t)qq * (uint32_t)N + (uint32_t)(key & ~1)) * 0x9E3779B1u + drop_key);
+              kscale = ((key & 1) ? (hsh >> 16) : (hsh & 0xffffu)) >= th16 ? inv_keep : 0.f;
+            }
             pd[r] = p * kscale;
             ds[r] = p * (dp[r] * kscale - delta_s[row]);
           }

@@ -9,6 +9,8 @@
 // reads), and every tap reuses the same activation tile at a row offset -- no im2col is materialised.
 // Each wave owns a 64 x 64 sub-tile = 2 x 2 MFMA 32x32 accumulators (64 VGPRs).
 // Operand type TC: bf16 (v_mfma_f32_32x32x16_bf16) or fp32 (v_mfma_f32_32x32x2_f32, exact fp32 mode).
+#include <stdlib.h>
+
 #include "dx_common.h"
 
 namespace {
@@ -25,25 +27,105 @@ struct ConvArgs {
   void* y; long ldy;
   const void* gate;
   const int64_t* mask_len;
-  int N, Cin, Cout, flags;
+  const int64_t* skip_len;
+  int N, Cin, Cout, flags, B;
 };
 
+template <typename T, int V> struct VecN;
+template <> struct VecN<float, 8> { typedef f32x8 type; };
+template <> struct VecN<bf16_t, 8> { typedef bf16x8 type; };
+
+template <typename T>
+__device__ __forceinline__ typename VecN<T, 8>::type raw_load8(const T* p);
+template <>
+__device__ __forceinline__ f32x8 raw_load8<float>(const float* p) {
+  f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+  f32x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return r;
+}
+template <>
+__device__ __forceinline__ bf16x8 raw_load8<bf16_t>(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+template <typename TS, typename TD>
+__device__ __forceinline__ typename Vec8<TD>::type cvt8(const typename VecN<TS, 8>::type& v) {
+  typename Vec8<TD>::type r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (TD)v[e];
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float* v);
+template <>
+__device__ __forceinline__ void store8<float>(float* p, const float* v) {
+  f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+  *reinterpret_cast<f32x4*>(p) = lo;
+  *reinterpret_cast<f32x4*>(p + 4) = hi;
+}
+template <>
+__device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (bf16_t)v[e];
+  *reinterpret_cast<bf16x8*>(p) = r;
+}
+
+// Pipeline: the global loads of K-chunk k+1 are issued into registers (raw element type, converted only when they are
+// written to LDS) BEFORE the MFMAs of chunk k, so HBM/L2 latency hides under the matrix work; one LDS buffer, two
+// barriers per chunk.  Epilogue: accumulators are staged through LDS (reusing the operand buffers) 64 rows at a time
+// and leave as whole 16-byte row segments (16 lanes cover a 128-channel row) -- the MFMA C layout would otherwise
+// emit 64 two-byte stores per lane.
 template <typename TA, typename TC, typename TO, typename TG, int TAPS>
 __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvArgs p) {
   constexpr int HALO = TAPS / 2;
   constexpr int AROWS = BM + TAPS - 1;
   constexpr int LDS_K = BK + Pad<TC>::value;
+  constexpr int A_CH = AROWS * (BK / 8), A_PT = (A_CH + NTHREADS - 1) / NTHREADS;
+  constexpr int W_PT = TAPS * BN * (BK / 8) / NTHREADS;
+  constexpr int STG_LD = BN + 4;
+  constexpr int OPER_BYTES = (AROWS + TAPS * BN) * LDS_K * (int)sizeof(TC), STG_BYTES = 64 * STG_LD * 4;
   typedef typename Vec8<TC>::type frag_t;
-  __shared__ __attribute__((aligned(16))) TC As[AROWS * LDS_K];
-  __shared__ __attribute__((aligned(16))) TC Ws[TAPS * BN * LDS_K];
+  typedef typename VecN<TA, 8>::type raw_t;
+  __shared__ __attribute__((aligned(16))) char smem[OPER_BYTES > STG_BYTES ? OPER_BYTES : STG_BYTES];
+  TC* As = reinterpret_cast<TC*>(smem);
+  TC* Ws = As + AROWS * LDS_K;
+  float* stage = reinterpret_cast<float*>(smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, g = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int n0 = blockIdx.x * BM, b = blockIdx.y, co0 = blockIdx.z * BN;
+  // XCD-aware mapping (workgroup L runs on XCD L % 8): the Cout/128 workgroups that share one activation tile run
+  // back to back on the same XCD, so the tile is fetched from HBM once and re-read from that XCD's L2
+  const int ztiles = dx_cdiv(p.Cout, BN), ptiles = dx_cdiv(p.N, BM);
+  const int Lid = blockIdx.x, jj = Lid >> 3;
+  const int pt = (Lid & 7) + 8 * (jj / ztiles);
+  if (pt >= ptiles * p.B) return;
+  const int n0 = (pt % ptiles) * BM, b = pt / ptiles, co0 = (jj % ztiles) * BN;
   const int N = p.N, Cin = p.Cin, Cout = p.Cout;
   const TA* X = reinterpret_cast<const TA*>(p.x) + (size_t)b * N * p.ldx;
   const TC* W = reinterpret_cast<const TC*>(p.w);
+  const bool relu = p.flags & DX_CONV_RELU, trans = p.flags & DX_CONV_TRANSPOSED_OUT, accum = p.flags & DX_CONV_ACCUMULATE;
+  const int len = p.mask_len ? (int)p.mask_len[b] : N;
+  TO* Y = reinterpret_cast<TO*>(p.y);
+  const TG* G = reinterpret_cast<const TG*>(p.gate);
+  const bool vec_out = !trans && (Cout % 8 == 0) && (p.ldy % 8 == 0);
+
+  // padding early-out: a tile that starts past length + conv halo cannot reach a valid output -> zeros, no MFMA
+  if (p.skip_len && n0 >= (int)p.skip_len[b] + 2) {
+    if (accum) return;
+    if (vec_out) {
+      float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int c = tid; c < BM * (BN / 8); c += NTHREADS) {
+        const int n = n0 + (c >> 4), co = co0 + (c & 15) * 8;
+        if (n < N && co < Cout) store8<TO>(Y + ((size_t)b * N + n) * p.ldy + co, z);
+      }
+    } else {
+      for (int c = tid; c < BM * BN; c += NTHREADS) {
+        const int n = n0 + (trans ? c % BM : c / BN), co = co0 + (trans ? c / BM : c % BN);
+        if (n < N && co < Cout) Y[trans ? ((size_t)b * Cout + co) * p.ldy + n : ((size_t)b * N + n) * p.ldy + co] = (TO)0.f;
+      }
+    }
+    return;
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -53,29 +135,48 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  for (int k0 = 0; k0 < Cin; k0 += BK) {
-    // ---- stage the haloed activation tile
-    for (int c = tid; c < AROWS * (BK / 8); c += NTHREADS) {
+  raw_t ra[A_PT];
+  frag_t rw[W_PT];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int t = 0; t < A_PT; ++t) {
+      const int c = tid + t * NTHREADS;
       const int r = c >> 2, kc = (c & 3) * 8;
       const int n = n0 + r - HALO, ci = k0 + kc;
-      frag_t v;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (TC)0.f;
-      if (n >= 0 && n < N && ci < Cin) v = dx_load8<TA, TC>(X + (size_t)n * p.ldx + ci);
-      *reinterpret_cast<frag_t*>(&As[r * LDS_K + kc]) = v;
+      for (int e = 0; e < 8; ++e) ra[t][e] = (TA)0.f;
+      if (c < A_CH && n >= 0 && n < N && ci < Cin) ra[t] = raw_load8<TA>(X + (size_t)n * p.ldx + ci);
     }
-    // ---- stage the weight tile
-    for (int c = tid; c < TAPS * BN * (BK / 8); c += NTHREADS) {
+#pragma unroll
+    for (int t = 0; t < W_PT; ++t) {
+      const int c = tid + t * NTHREADS;
       const int tap = c / (BN * 4), rem = c - tap * (BN * 4);
       const int row = rem >> 2, kc = (rem & 3) * 8;
       const int co = co0 + row, ci = k0 + kc;
-      frag_t v;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (TC)0.f;
-      if (co < Cout && ci < Cin) v = *reinterpret_cast<const frag_t*>(W + ((size_t)tap * Cout + co) * Cin + ci);
-      *reinterpret_cast<frag_t*>(&Ws[(tap * BN + row) * LDS_K + kc]) = v;
+      rw[t] = zero8<TC>();
+      if (co < Cout && ci < Cin) rw[t] = *reinterpret_cast<const frag_t*>(W + ((size_t)tap * Cout + co) * Cin + ci);
     }
-    __syncthreads();
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int t = 0; t < A_PT; ++t) {
+      const int c = tid + t * NTHREADS;
+      if (c < A_CH) *reinterpret_cast<frag_t*>(&As[(c >> 2) * LDS_K + (c & 3) * 8]) = cvt8<TA, TC>(ra[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < W_PT; ++t) {
+      const int c = tid + t * NTHREADS;
+      const int tap = c / (BN * 4), rem = c - tap * (BN * 4);
+      *reinterpret_cast<frag_t*>(&Ws[(tap * BN + (rem >> 2)) * LDS_K + (rem & 3) * 8]) = rw[t];
+    }
+  };
+
+  fetch(0);
+  commit();
+  __syncthreads();
+  for (int k0 = 0; k0 < Cin; k0 += BK) {
+    const bool more = k0 + BK < Cin;
+    if (more) fetch(k0 + BK);
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
 #pragma unroll
@@ -94,13 +195,62 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvArgs p) {
       }
     }
     __syncthreads();
+    if (more) {
+      commit();
+      __syncthreads();
+    }
   }
 
-  // ---- epilogue: bias, ReLU, ReLU-derivative gate, length mask, store
-  const bool relu = p.flags & DX_CONV_RELU, trans = p.flags & DX_CONV_TRANSPOSED_OUT, accum = p.flags & DX_CONV_ACCUMULATE;
-  const int len = p.mask_len ? (int)p.mask_len[b] : N;
-  TO* Y = reinterpret_cast<TO*>(p.y);
-  const TG* G = reinterpret_cast<const TG*>(p.gate);
+  // ---- epilogue
+  if (vec_out) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      // phase 1: bias + ReLU in the MFMA layout, accumulators -> LDS stage (64 rows x 128 channels, fp32)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cl = wn * 64 + j * 32 + l31, co = co0 + cl;
+        const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + bv;
+          if (relu) v = fmaxf(v, 0.f);
+          stage[(wm * 32 + dx_acc_row(r, g)) * STG_LD + cl] = v;
+        }
+      }
+      __syncthreads();
+      // phase 2: whole 16-byte row segments: gate, mask, accumulate, store
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int sr = (tid >> 4) + pass * 16;                     // stage row 0..63
+        const int n = n0 + (sr >> 5) * 64 + i * 32 + (sr & 31), cl = (tid & 15) * 8, co = co0 + cl;
+        if (n < N && co < Cout) {
+          float v[8];
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(&stage[sr * STG_LD + cl]);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(&stage[sr * STG_LD + cl + 4]);
+          v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+          const size_t off = ((size_t)b * N + n) * p.ldy + co;
+          if (G) {
+            const typename VecN<TG, 8>::type gv = raw_load8<TG>(G + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = ((float)gv[e] > 0.f) ? v[e] : 0.f;
+          }
+          if (n >= len) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+          }
+          if (accum) {
+            const typename VecN<TO, 8>::type old = raw_load8<TO>(Y + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
+          }
+          store8<TO>(Y + off, v);
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // scalar path: transposed output (mel projection) or channel counts that are not multiples of 8
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int co = co0 + wn * 64 + j * 32 + l31;
@@ -126,7 +276,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvArgs p) {
 
 template <typename TA, typename TC, typename TO, typename TG>
 int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
-  dim3 grid(dx_cdiv(a.N, BM), B, dx_cdiv(a.Cout, BN)), block(NTHREADS);
+  const long ptiles = (long)dx_cdiv(a.N, BM) * B;
+  dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * dx_cdiv(a.Cout, BN))), block(NTHREADS);
   if (taps == 1)
     hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1>), grid, block, 0, s, a);
   else
@@ -145,26 +296,51 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
 // layout; both MFMA operands need "8 consecutive positions for one channel", which the LDS transpose read
 // (ds_read_b64_tr_b16, gather8) delivers without a software transpose; all taps reuse the same X tile at a row
 // offset.  Wave (wm, wn) accumulates 64 co x 32 ci x taps = 2*taps MFMA 32x32 tiles.
-constexpr int WG_CO = 128, WG_CI = 64, WG_P = 32;
+constexpr int WG_CO = 128, WG_CI = 64;
+#ifndef DX_WG_P
+#define DX_WG_P 128
+#endif
+constexpr int WG_P = DX_WG_P;
 
 struct WgradArgs {
   const void* dy; long lddy; const void* x; long ldx;
   float* dw; float* db; const int64_t* lengths;
   int B, N, Cin, Cout, nsplit, tiles_ci;
+  int map;
+  int debug;   // development ablation switches (DX_WGRAD_DEBUG): 1 = no atomics, 2 = no gathers/MFMA, 4 = no bias sums
 };
 
+// The (utterance, 64-position chunk) work items of a workgroup form one flat sequence; the global loads of item k+1
+// are issued into registers (raw element types) before the MFMAs of item k and converted when written to LDS.
 template <typename TA, typename TB, typename TC, int TAPS>
 __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradArgs p) {
   constexpr int HALO = TAPS / 2, XROWS = WG_P + TAPS - 1;
-  constexpr int LDA = WG_CO + Pad<TC>::value, LDB = WG_CI + Pad<TC>::value;
+  // row strides = 16 banks (mod 64) apart: the 4 rows x 2 halves x 4 chunks touched by one 32-lane group of a
+  // transpose read (ds_read_b64_tr_b16) then fall on 64 distinct banks
+  constexpr int LDA = WG_CO + 4 * Pad<TC>::value, LDB = WG_CI + 4 * Pad<TC>::value;
+  constexpr int A_PT = WG_P * (WG_CO / 8) / NTHREADS;
+  constexpr int B_CH = XROWS * (WG_CI / 8), B_PT = (B_CH + NTHREADS - 1) / NTHREADS;
   typedef typename Vec8<TC>::type frag_t;
+  typedef typename VecN<TA, 8>::type rawa_t;
+  typedef typename VecN<TB, 8>::type rawb_t;
   __shared__ __attribute__((aligned(16))) TC dYs[WG_P * LDA];
   __shared__ __attribute__((aligned(16))) TC Xs[XROWS * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile = blockIdx.x, co0 = (tile / p.tiles_ci) * WG_CO, ci0 = (tile % p.tiles_ci) * WG_CI;
+  // Work items = (batch slice, output tile), tile fastest.  map 1: XCD-aware -- workgroup L runs on XCD L % 8 (observed
+  // dispatch order), and each XCD is given a CONTIGUOUS range of work items so that the tiles of one batch slice
+  // (they re-read the same dY / X rows) share that XCD's L2.  map 0: plain order.
+  const int ntiles = dx_cdiv(p.Cout, WG_CO) * p.tiles_ci;
+  const int total = ntiles * p.nsplit;
+  int w = blockIdx.x;
+  if (p.map == 1) {
+    const int q = total >> 3, r = total & 7, xcd = w & 7, j = w >> 3;   // bijective for any total (guide T1)
+    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int split = w / ntiles, tile = w % ntiles;
+  const int co0 = (tile / p.tiles_ci) * WG_CO, ci0 = (tile % p.tiles_ci) * WG_CI;
   const int N = p.N, Cin = p.Cin, Cout = p.Cout;
-  const int b_begin = (int)((long)p.B * blockIdx.y / p.nsplit), b_end = (int)((long)p.B * (blockIdx.y + 1) / p.nsplit);
+  const int b_end = (int)((long)p.B * (split + 1) / p.nsplit);
 
   f32x16 acc[TAPS][2];
 #pragma unroll
@@ -173,52 +349,103 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradArgs p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
-  float bsum = 0.f;
-  const bool do_bias = p.db && ci0 == 0 && tid < WG_CO;
+  // bias gradient = dY^T . 1: one extra MFMA per k-step against an all-ones B fragment (only in the ci0 == 0 tiles,
+  // only in the wn == 0 waves) instead of a serial LDS column-sum loop
+  const bool do_bias = p.db && ci0 == 0 && wn == 0 && !(p.debug & 4);
+  f32x16 bacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bacc[i][r] = 0.f;
+  frag_t ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (TC)1.f;
 
-  for (int b = b_begin; b < b_end; ++b) {
-    const TA* dY = reinterpret_cast<const TA*>(p.dy) + (size_t)b * N * p.lddy;
-    const TB* X = reinterpret_cast<const TB*>(p.x) + (size_t)b * N * p.ldx;
-    // rows beyond len + halo carry exactly-zero gradients (masked upstream): skip them
-    const int nlim = p.lengths ? min(N, (int)p.lengths[b] + 2) : N;
-    for (int n0 = 0; n0 < nlim; n0 += WG_P) {
-      for (int c = tid; c < WG_P * (WG_CO / 8); c += NTHREADS) {
-        const int r = c >> 4, kc = (c & 15) * 8;
-        const int n = n0 + r, co = co0 + kc;
-        frag_t v = zero8<TC>();
-        if (n < N && co < Cout) v = dx_load8<TA, TC>(dY + (size_t)n * p.lddy + co);
-        *reinterpret_cast<frag_t*>(&dYs[r * LDA + kc]) = v;
-      }
-      for (int c = tid; c < XROWS * (WG_CI / 8); c += NTHREADS) {
-        const int r = c >> 3, kc = (c & 7) * 8;
-        const int n = n0 + r - HALO, ci = ci0 + kc;
-        frag_t v = zero8<TC>();
-        if (n >= 0 && n < N && ci < Cin) v = dx_load8<TB, TC>(X + (size_t)n * p.ldx + ci);
-        *reinterpret_cast<frag_t*>(&Xs[r * LDB + kc]) = v;
-      }
-      __syncthreads();
+  // rows beyond len + halo carry exactly-zero gradients (masked upstream): skipped
+  auto nlim_of = [&](int b) { return p.lengths ? min(N, (int)p.lengths[b] + 2) : N; };
+  int b = (int)((long)p.B * split / p.nsplit), n0 = 0;
+  int nlim = b < b_end ? nlim_of(b) : 0;
+
+  rawa_t ra[A_PT];
+  rawb_t rb[B_PT];
+  auto fetch = [&](int fb, int fn0) {
+    const TA* dY = reinterpret_cast<const TA*>(p.dy) + (size_t)fb * N * p.lddy;
+    const TB* X = reinterpret_cast<const TB*>(p.x) + (size_t)fb * N * p.ldx;
+#pragma unroll
+    for (int t = 0; t < A_PT; ++t) {
+      const int c = tid + t * NTHREADS;
+      const int r = c >> 4, kc = (c & 15) * 8;
+      const int n = fn0 + r, co = co0 + kc;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ra[t][e] = (TA)0.f;
+      if (n < N && co < Cout) ra[t] = raw_load8<TA>(dY + (size_t)n * p.lddy + co);
+    }
+#pragma unroll
+    for (int t = 0; t < B_PT; ++t) {
+      const int c = tid + t * NTHREADS;
+      const int r = c >> 3, kc = (c & 7) * 8;
+      const int n = fn0 + r - HALO, ci = ci0 + kc;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rb[t][e] = (TB)0.f;
+      if (c < B_CH && n >= 0 && n < N && ci < Cin) rb[t] = raw_load8<TB>(X + (size_t)n * p.ldx + ci);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int t = 0; t < A_PT; ++t) {
+      const int c = tid + t * NTHREADS;
+      *reinterpret_cast<frag_t*>(&dYs[(c >> 4) * LDA + (c & 15) * 8]) = cvt8<TA, TC>(ra[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < B_PT; ++t) {
+      const int c = tid + t * NTHREADS;
+      if (c < B_CH) *reinterpret_cast<frag_t*>(&Xs[(c >> 3) * LDB + (c & 7) * 8]) = cvt8<TB, TC>(rb[t]);
+    }
+  };
+  auto advance = [&]() {   // next (b, n0) work item; b == b_end when exhausted
+    n0 += WG_P;
+    while (b < b_end && n0 >= nlim) {
+      ++b; n0 = 0;
+      nlim = b < b_end ? nlim_of(b) : 0;
+    }
+  };
+  while (b < b_end && n0 >= nlim) { ++b; nlim = b < b_end ? nlim_of(b) : 0; }   // skip empty leading utterances
+
+  if (b < b_end) {
+    fetch(b, n0);
+    commit();
+    __syncthreads();
+  }
+  while (b < b_end) {
+    advance();
+    const bool more = b < b_end;
+    if (more) fetch(b, n0);
+    if (!(p.debug & 2))
+#pragma unroll
+    for (int ks = 0; ks < WG_P / 16; ++ks) {
+      const int kA = ks * 16 + 8 * g, kB = kA + 4;
+      frag_t a[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = gather8<TC, 32>(dYs, LDA, kA, kB, wm * 64 + i * 32, lane);
       if (do_bias) {
-#pragma unroll 8
-        for (int r = 0; r < WG_P; ++r) bsum += (float)dYs[r * LDA + tid];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dx_mma(bacc[i], a[i], ones);
       }
 #pragma unroll
-      for (int ks = 0; ks < WG_P / 16; ++ks) {
-        const int kA = ks * 16 + 8 * g, kB = kA + 4;
-        frag_t a[2];
+      for (int t = 0; t < TAPS; ++t) {
+        frag_t bx = gather8<TC, 32>(Xs, LDB, kA + t, kB + t, wn * 32, lane);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = gather8<TC, 32>(dYs, LDA, kA, kB, wm * 64 + i * 32, lane);
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-          frag_t bx = gather8<TC, 32>(Xs, LDB, kA + t, kB + t, wn * 32, lane);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) dx_mma(acc[t][i], a[i], bx);
-        }
+        for (int i = 0; i < 2; ++i) dx_mma(acc[t][i], a[i], bx);
       }
+    }
+    __syncthreads();
+    if (more) {
+      commit();
       __syncthreads();
     }
   }
   const int ci = ci0 + wn * 32 + l31;
-  if (ci < Cin) {
+  if (ci < Cin && !(p.debug & 1)) {
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -229,12 +456,21 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradArgs p) {
           if (co < Cout) atomicAdd(p.dw + ((size_t)co * Cin + ci) * TAPS + t, acc[t][i][r]);
         }
   }
-  if (do_bias && co0 + tid < Cout) atomicAdd(p.db + co0 + tid, bsum);
+  if (do_bias && l31 == 0) {   // every column of bacc holds the same row sums; column 0 publishes them
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 64 + i * 32 + dx_acc_row(r, g);
+        if (co < Cout) atomicAdd(p.db + co, bacc[i][r]);
+      }
+  }
 }
 
 template <typename TA, typename TB, typename TC>
 int launch_wgrad(const WgradArgs& a, int taps, hipStream_t s) {
-  dim3 grid(dx_cdiv(a.Cout, WG_CO) * a.tiles_ci, a.nsplit), block(NTHREADS);
+  const int ntiles = dx_cdiv(a.Cout, WG_CO) * a.tiles_ci;
+  dim3 grid(ntiles * a.nsplit), block(NTHREADS);
   if (taps == 1)
     hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 1>), grid, block, 0, s, a);
   else
@@ -259,17 +495,53 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, TC* __restrict__
   }
 }
 
+
+// all GEMM weights of the model in ONE launch: descriptor table on the device, flat element index -> (descriptor, element)
+struct PackDesc { const float* w; void* out; int Cout, Cin, taps, tf; long begin; };   // begin = prefix sum of element counts
+template <typename TC>
+__global__ __launch_bounds__(256) void pack_batched_kernel(const PackDesc* __restrict__ descs, int n, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (descs[mid].begin <= i) lo = mid; else hi = mid - 1; }
+    const PackDesc d = descs[lo];
+    const long e = i - d.begin;
+    TC* out = reinterpret_cast<TC*>(d.out);
+    if (!d.tf) {
+      const int ci = e % d.Cin; const long t = e / d.Cin; const int co = t % d.Cout; const int tap = t / d.Cout;
+      out[e] = (TC)d.w[((long)co * d.Cin + ci) * d.taps + tap];
+    } else {
+      const int co = e % d.Cout; const long t = e / d.Cout; const int ci = t % d.Cin; const int tap = t / d.Cin;
+      out[e] = (TC)d.w[((long)co * d.Cin + ci) * d.taps + (d.taps - 1 - tap)];
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int dx_pack_desc_size(void) { return (int)sizeof(PackDesc); }
+
+extern "C" int dx_pack_conv_weights_batched(const void* descs_dev, int n, long total_elems, int out_dtype, void* stream) {
+  DX_REQUIRE(descs_dev && n > 0 && total_elems > 0, DX_ERR_ARG, "dx_pack_conv_weights_batched: bad arguments");
+  const long g = (total_elems + 255) / 256;
+  const int grid = (int)(g < 4096 ? g : 4096);
+  if (out_dtype == DX_BF16)
+    hipLaunchKernelGGL(pack_batched_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev, n, total_elems);
+  else if (out_dtype == DX_F32)
+    hipLaunchKernelGGL(pack_batched_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev, n, total_elems);
+  else { dx_set_error("dx_pack_conv_weights_batched: bad out_dtype %d", out_dtype); return DX_ERR_DTYPE; }
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
 
 extern "C" int dx_conv1d(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const float* bias,
                          void* y, int y_dtype, long ldy, const void* relu_gate, int gate_dtype,
-                         const int64_t* mask_lengths, int B, int N, int Cin, int Cout, int taps, int flags, void* stream) {
+                         const int64_t* mask_lengths, const int64_t* skip_lengths, int B, int N, int Cin, int Cout,
+                         int taps, int flags, void* stream) {
   DX_REQUIRE(x && w_packed && y, DX_ERR_ARG, "dx_conv1d: null pointer");
   DX_REQUIRE(B > 0 && N > 0 && Cin > 0 && Cout > 0, DX_ERR_SHAPE, "dx_conv1d: empty shape B=%d N=%d Cin=%d Cout=%d", B, N, Cin, Cout);
   DX_REQUIRE(Cin % 8 == 0 && ldx % 8 == 0, DX_ERR_SHAPE, "dx_conv1d: Cin (%d) and ldx (%ld) must be multiples of 8", Cin, ldx);
   DX_REQUIRE(taps == 1 || taps == 3, DX_ERR_UNSUPPORTED, "dx_conv1d: taps=%d (only 1 and 3)", taps);
-  DX_REQUIRE(B <= 65535 && dx_cdiv(Cout, BN) <= 65535, DX_ERR_SHAPE, "dx_conv1d: grid too large");
-  ConvArgs a{x, ldx, w_packed, bias, y, ldy, relu_gate, mask_lengths, N, Cin, Cout, flags};
+  ConvArgs a{x, ldx, w_packed, bias, y, ldy, relu_gate, mask_lengths, skip_lengths, N, Cin, Cout, flags, B};
   hipStream_t s = (hipStream_t)stream;
   const int gd = relu_gate ? gate_dtype : y_dtype;
   if (w_dtype == DX_BF16) {
@@ -312,9 +584,16 @@ extern "C" int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const vo
   DX_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0, DX_ERR_SHAPE,
              "dx_conv1d_wgrad: Cin, Cout and the row strides must be multiples of 8");
   DX_REQUIRE(taps == 1 || taps == 3, DX_ERR_UNSUPPORTED, "dx_conv1d_wgrad: taps=%d (only 1 and 3)", taps);
-  WgradArgs a{dy, lddy, x, ldx, dw, db, lengths, B, N, Cin, Cout, 1, dx_cdiv(Cin, WG_CI)};
+  static int dbg = getenv("DX_WGRAD_DEBUG") ? atoi(getenv("DX_WGRAD_DEBUG")) : 0;
+  static int wmap = getenv("DX_WGRAD_MAP") ? atoi(getenv("DX_WGRAD_MAP")) : 0;
+  WgradArgs a{dy, lddy, x, ldx, dw, db, lengths, B, N, Cin, Cout, 1, dx_cdiv(Cin, WG_CI), wmap, dbg};
   const int tiles = dx_cdiv(Cout, WG_CO) * a.tiles_ci;
-  int ns = 1024 / tiles;                 // enough workgroups for 256 CUs, as few atomic passes as possible
+  static int target = getenv("DX_WGRAD_BLOCKS") ? atoi(getenv("DX_WGRAD_BLOCKS")) : 256;
+  // split-K over the batch: enough workgroups to occupy the chip, but every extra split costs a full pass of fp32
+  // atomics over the weight tensor (~200 G atomics/s measured) -> keep >= ~12 stages of work per workgroup
+  int ns = target / tiles;
+  const int by_work = (int)((long)B * dx_cdiv(N, WG_P) / 12);
+  if (ns > by_work) ns = by_work;
   a.nsplit = ns < 1 ? 1 : (ns > B ? B : ns);
   hipStream_t s = (hipStream_t)stream;
   if (compute_dtype == DX_BF16) {

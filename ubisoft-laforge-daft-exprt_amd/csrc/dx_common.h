@@ -34,7 +34,7 @@ void dx_set_error(const char* fmt, ...);
     }                                                                       \
   } while (0)
 
-static inline int dx_cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int dx_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- device helpers -------------------------------------------------------------------
 template <typename T>
@@ -166,18 +166,19 @@ __device__ __forceinline__ typename Vec8<TC>::type pack8(const float* p) {
   return v;
 }
 
-// Counter-based dropout RNG: one 32-bit hash per element index.  keep iff hash >= p * 2^32.
-// (Bit-parity with torch's Philox stream is not a goal -- SURVEY section 7; the forward and
-// backward passes regenerate the same mask from (seed, element index).)
-__device__ __forceinline__ uint32_t dx_hash32(uint64_t seed, uint64_t idx) {
-  uint64_t x = idx * 0x9E3779B97F4A7C15ull + seed;
-  x ^= x >> 32;
-  x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  return (uint32_t)x;
+// Counter-based dropout RNG: one 32-bit hash (murmur3 finaliser) per element.  keep iff hash >= p * 2^32.
+// `key` is a 32-bit stream key folded on the fly from the 64-bit call seed (+ a per-(batch, head) salt in attention);
+// `idx` is the element index inside the tensor (fits 32 bits for every tensor of this model, B*N*C < 2^32).
+// Bit-parity with torch's Philox stream is not a goal; the forward and backward kernels
+// regenerate the same mask from (seed, element index).  64-bit multiplies are avoided on purpose: they cost 4
+// quarter-rate v_mul each and made the d_head = 16 attention kernels VALU-bound.
+__host__ __device__ __forceinline__ uint32_t dx_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+  return x;
 }
-__device__ __forceinline__ bool dx_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
-  return dx_hash32(seed, idx) >= thresh;
+__host__ __device__ __forceinline__ uint32_t dx_key32(uint64_t seed, uint32_t salt) {
+  return dx_mix32((uint32_t)seed ^ dx_mix32((uint32_t)(seed >> 32) + 0x9E3779B9u * (salt + 1u)));
+}
+__device__ __forceinline__ bool dx_keep(uint32_t key, uint32_t idx, uint32_t thresh) {
+  return dx_mix32(idx * 0x9E3779B1u + key) >= thresh;
 }

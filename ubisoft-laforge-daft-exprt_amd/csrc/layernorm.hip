@@ -18,8 +18,8 @@ namespace {
 struct LNArgs {
   const void* x; const float* res; const float* gamma; const float* beta;
   const float* film; long ldf;        // film row b: [gamma(C) | beta(C)], rows ldf apart
-  const int64_t* lengths;
-  void* y; float* s_out; float* mean; float* rstd;
+  const int64_t* lengths; const int64_t* skip;
+  void* y; void* y_lp; float* s_out; float* mean; float* rstd;   // y_lp: optional bf16 copy of y (MFMA operand of the next GEMM)
   int N; long rows;
   float p_pre, p_post; uint64_t seed_pre, seed_post;
 };
@@ -73,6 +73,21 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
   if (row >= a.rows) return;
   const int b = (int)(row / a.N), n = (int)(row - (long)b * a.N);
   const TI* x = reinterpret_cast<const TI*>(a.x) + row * C;
+  const uint32_t key_pre = dx_key32(a.seed_pre, 0), key_post = dx_key32(a.seed_post, 1);
+  if (a.skip && n >= (int)a.skip[b] + 2) {   // rows past length + conv halo never reach a valid output: zeros, no reads
+    TO* y0 = reinterpret_cast<TO*>(a.y) + row * C;
+    float z[L::V];
+#pragma unroll
+    for (int i = 0; i < L::V; ++i) z[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < L::NV; ++k) {
+      store_vec<TO, L::V>(y0 + L::col(lane, k), z);
+      if (a.y_lp) store_vec<bf16_t, L::V>(reinterpret_cast<bf16_t*>(a.y_lp) + row * C + L::col(lane, k), z);
+      if (a.s_out) store_vec<float, L::V>(a.s_out + row * C + L::col(lane, k), z);
+    }
+    if (a.mean && lane == 0) { a.mean[row] = 0.f; a.rstd[row] = 0.f; }
+    return;
+  }
   float v[L::EPL];
   const uint32_t th_pre = drop_thresh(a.p_pre);
   const float sc_pre = a.p_pre > 0.f ? 1.f / (1.f - a.p_pre) : 1.f;
@@ -83,7 +98,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
     if (th_pre) {
 #pragma unroll
       for (int i = 0; i < L::V; ++i)
-        v[k * L::V + i] = dx_keep(a.seed_pre, (uint64_t)row * C + c0 + i, th_pre) ? v[k * L::V + i] * sc_pre : 0.f;
+        v[k * L::V + i] = dx_keep(key_pre, (uint32_t)row * C + c0 + i, th_pre) ? v[k * L::V + i] * sc_pre : 0.f;
     }
     if (a.res) {
       float r[L::V];
@@ -115,7 +130,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
 #pragma unroll
     for (int i = 0; i < L::V; ++i) {
       float t = (v[k * L::V + i] - mean) * rstd * g[i] + bt[i];
-      if (th_post) t = dx_keep(a.seed_post, (uint64_t)row * C + c0 + i, th_post) ? t * sc_post : 0.f;
+      if (th_post) t = dx_keep(key_post, (uint32_t)row * C + c0 + i, th_post) ? t * sc_post : 0.f;
       o[i] = t;
     }
     if (a.film) {
@@ -130,6 +145,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
       for (int i = 0; i < L::V; ++i) o[i] = 0.f;
     }
     store_vec<TO, L::V>(y + c0, o);
+    if (a.y_lp) store_vec<bf16_t, L::V>(reinterpret_cast<bf16_t*>(a.y_lp) + row * C + c0, o);
   }
 }
 
@@ -137,9 +153,10 @@ struct LNBwdArgs {
   const void* dy;            // grad wrt the kernel's output y, dtype TG, (rows, C)
   const void* s;             // the normalised tensor's input: s_out of the forward (fp32) or the raw x (TI)
   const float* mean; const float* rstd; const float* gamma; const float* beta;
-  const float* film; long ldf; const int64_t* lengths;
+  const float* film; long ldf; const int64_t* lengths; const int64_t* skip;
   void* ds;                  // out: grad wrt s (dtype TD) -- also the residual gradient
   void* dx_pre;              // out (nullable): grad wrt x before dropout_pre (dtype TD); only when p_pre > 0
+  void* dx_pre_lp;           // out (nullable): the same gradient as bf16 (MFMA operand of the following dgrad / wgrad)
   float* dgamma; float* dbeta;          // (C) accumulated with atomics
   float* dfilm; long lddf;              // (B, 2C) accumulated with atomics (nullable)
   int N; int B; int rows_per_block;
@@ -158,8 +175,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
   const int n_end = min(a.N, n_begin + a.rows_per_block);
   const int len = a.lengths ? (int)a.lengths[b] : a.N;
   const uint32_t th_pre = drop_thresh(a.p_pre), th_post = drop_thresh(a.p_post);
+  const uint32_t key_pre = dx_key32(a.seed_pre, 0), key_post = dx_key32(a.seed_post, 1);
   const float sc_pre = a.p_pre > 0.f ? 1.f / (1.f - a.p_pre) : 1.f;
   const float sc_post = a.p_post > 0.f ? 1.f / (1.f - a.p_post) : 1.f;
+  const int nskip = a.skip ? (int)a.skip[b] + 2 : a.N;
 
   float gam[L::EPL], bet[L::EPL], fg[L::EPL];
   float acc_g[L::EPL], acc_b[L::EPL], acc_fg[L::EPL], acc_fb[L::EPL];
@@ -175,6 +194,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
 
   for (int n = n_begin + wave; n < n_end; n += 4) {
     const long row = (long)b * a.N + n;
+    if (n >= nskip) {   // gradient rows past length + halo are exactly zero
+      TD* ds0 = reinterpret_cast<TD*>(a.ds) + row * C;
+      TD* dxp0 = a.dx_pre ? reinterpret_cast<TD*>(a.dx_pre) + row * C : nullptr;
+      float z[L::V];
+#pragma unroll
+      for (int i = 0; i < L::V; ++i) z[i] = 0.f;
+#pragma unroll
+      for (int k = 0; k < L::NV; ++k) {
+        store_vec<TD, L::V>(ds0 + L::col(lane, k), z);
+        if (dxp0) store_vec<TD, L::V>(dxp0 + L::col(lane, k), z);
+        if (a.dx_pre_lp) store_vec<bf16_t, L::V>(reinterpret_cast<bf16_t*>(a.dx_pre_lp) + row * C + L::col(lane, k), z);
+      }
+      continue;
+    }
     const TG* dy = reinterpret_cast<const TG*>(a.dy) + row * C;
     const TI* s = reinterpret_cast<const TI*>(a.s) + row * C;
     const float mean = a.mean[row], rstd = a.rstd[row];
@@ -199,7 +232,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
         xh[j] = (xh[j] - mean) * rstd;
         float ln = xh[j] * gam[j] + bet[j];                 // LayerNorm output before dropout_post / FiLM
         float keep_post = 1.f;
-        if (th_post) keep_post = dx_keep(a.seed_post, (uint64_t)row * C + c, th_post) ? sc_post : 0.f;
+        if (th_post) keep_post = dx_keep(key_post, (uint32_t)row * C + c, th_post) ? sc_post : 0.f;
         if (a.film) {                                       // y = fg * (ln * keep) + fb
           acc_fg[j] += gy * ln * keep_post;
           acc_fb[j] += gy;
@@ -227,10 +260,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
         o[i] = rstd * (g[j] - m1 - xh[j] * m2);
         if (a.relu_input && !pos[j]) o[i] = 0.f;
         o2[i] = o[i];
-        if (th_pre) o2[i] = dx_keep(a.seed_pre, (uint64_t)row * C + c0 + i, th_pre) ? o[i] * sc_pre : 0.f;
+        if (th_pre) o2[i] = dx_keep(key_pre, (uint32_t)row * C + c0 + i, th_pre) ? o[i] * sc_pre : 0.f;
       }
       store_vec<TD, L::V>(ds + c0, o);
       if (dxp) store_vec<TD, L::V>(dxp + c0, o2);
+      if (a.dx_pre_lp) store_vec<bf16_t, L::V>(reinterpret_cast<bf16_t*>(a.dx_pre_lp) + row * C + c0, o2);
     }
   }
   // ---- reduce the per-channel partials over the 4 waves, one atomic per channel per block
@@ -280,14 +314,14 @@ int launch_bwd(const LNBwdArgs& a, int C, hipStream_t s) {
 }  // namespace
 
 extern "C" int dx_layernorm_fwd(const void* x, int x_dtype, const float* residual, const float* gamma, const float* beta,
-                                const float* film, long ldf, const int64_t* lengths, void* y, int y_dtype, float* s_out,
-                                float* mean, float* rstd, int B, int N, int C, float p_pre, uint64_t seed_pre,
+                                const float* film, long ldf, const int64_t* lengths, const int64_t* skip_lengths, void* y,
+                                int y_dtype, void* y_lp, float* s_out, float* mean, float* rstd, int B, int N, int C, float p_pre, uint64_t seed_pre,
                                 float p_post, uint64_t seed_post, void* stream) {
   DX_REQUIRE(x && gamma && beta && y, DX_ERR_ARG, "dx_layernorm_fwd: null pointer");
   DX_REQUIRE(B > 0 && N > 0, DX_ERR_SHAPE, "dx_layernorm_fwd: empty shape");
   DX_REQUIRE((mean == nullptr) == (rstd == nullptr), DX_ERR_ARG, "dx_layernorm_fwd: mean and rstd come together");
   DX_REQUIRE(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, DX_ERR_ARG, "dx_layernorm_fwd: dropout p out of [0,1)");
-  LNArgs a{x, residual, gamma, beta, film, ldf, lengths, y, s_out, mean, rstd, N, (long)B * N, p_pre, p_post, seed_pre, seed_post};
+  LNArgs a{x, residual, gamma, beta, film, ldf, lengths, skip_lengths, y, y_lp, s_out, mean, rstd, N, (long)B * N, p_pre, p_post, seed_pre, seed_post};
   hipStream_t s = (hipStream_t)stream;
   if (x_dtype == DX_F32 && y_dtype == DX_F32) return launch_fwd<float, float>(a, C, s);
   if (x_dtype == DX_BF16 && y_dtype == DX_BF16) return launch_fwd<bf16_t, bf16_t>(a, C, s);
@@ -299,8 +333,8 @@ extern "C" int dx_layernorm_fwd(const void* x, int x_dtype, const float* residua
 
 extern "C" int dx_layernorm_bwd(const void* dy, int dy_dtype, const void* s_in, int s_dtype, const float* mean,
                                 const float* rstd, const float* gamma, const float* beta, const float* film, long ldf,
-                                const int64_t* lengths, void* ds, void* dx_pre, int d_dtype, float* dgamma, float* dbeta,
-                                float* dfilm, long lddf, int B, int N, int C, float p_pre, uint64_t seed_pre,
+                                const int64_t* lengths, const int64_t* skip_lengths, void* ds, void* dx_pre, void* dx_pre_lp,
+                                int d_dtype, float* dgamma, float* dbeta, float* dfilm, long lddf, int B, int N, int C, float p_pre, uint64_t seed_pre,
                                 float p_post, uint64_t seed_post, int relu_input, void* stream) {
   DX_REQUIRE(dy && s_in && mean && rstd && gamma && beta && ds && dgamma && dbeta, DX_ERR_ARG, "dx_layernorm_bwd: null pointer");
   DX_REQUIRE(B > 0 && N > 0, DX_ERR_SHAPE, "dx_layernorm_bwd: empty shape");
@@ -308,7 +342,7 @@ extern "C" int dx_layernorm_bwd(const void* dy, int dy_dtype, const void* s_in, 
   // enough workgroups to fill 256 CUs, few enough that the per-channel atomics stay cheap
   int rpb = 32;
   while (rpb < 512 && (long)dx_cdiv(N, rpb) * B > 2048) rpb *= 2;
-  LNBwdArgs a{dy, s_in, mean, rstd, gamma, beta, film, ldf, lengths, ds, dx_pre, dgamma, dbeta, dfilm, lddf, N, B, rpb,
+  LNBwdArgs a{dy, s_in, mean, rstd, gamma, beta, film, ldf, lengths, skip_lengths, ds, dx_pre, dx_pre_lp, dgamma, dbeta, dfilm, lddf, N, B, rpb,
               p_pre, p_post, seed_pre, seed_post, relu_input};
   hipStream_t s = (hipStream_t)stream;
   if (s_dtype == DX_F32 && dy_dtype == DX_F32 && d_dtype == DX_F32) return launch_bwd<float, float, float>(a, C, s);

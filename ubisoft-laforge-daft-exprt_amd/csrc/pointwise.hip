@@ -125,15 +125,16 @@ __global__ void gather_add_bwd_kernel(const float* __restrict__ dz, const int64_
 }
 
 // ------------------------------------------------------------------ masked mean over time
-// grid (B); 128 threads = channels
+// grid (B, chunks); 128 threads = channels; partial sums combined with atomics into a zeroed output
 __global__ __launch_bounds__(128) void masked_mean_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ lengths,
-                                                              float* __restrict__ out, int N) {
+                                                              float* __restrict__ out, int N, int rows_per_chunk) {
   const int c = threadIdx.x, b = blockIdx.x;
   const int len = (int)lengths[b];
+  const int n0 = blockIdx.y * rows_per_chunk, n1 = min(min(N, len), n0 + rows_per_chunk);  // pads are zeros (masked upstream)
   const float* p = x + (long)b * N * C128 + c;
   float acc = 0.f;
-  for (int n = 0; n < N; ++n) acc += p[(long)n * C128];  // pads are zeros (masked upstream), summed like the reference
-  out[b * C128 + c] = acc / (float)len;
+  for (int n = n0; n < n1; ++n) acc += p[(long)n * C128];
+  if (n1 > n0) atomicAdd(out + b * C128 + c, acc / (float)len);
 }
 __global__ __launch_bounds__(256) void masked_mean_bwd_kernel(const float* __restrict__ dy, const int64_t* __restrict__ lengths,
                                                               float* __restrict__ dx, int N, long rows) {
@@ -184,12 +185,27 @@ __global__ void film_assemble_bwd_kernel(FilmBwdArgs a) {
     const float pg = a.post ? a.post[blk0 + blk] : 1.f, pb = a.post ? a.post[a.nblk + blk0 + blk] : 1.f;
     a.dg_raw[i] = dg * pg;
     a.db_raw[i] = db * pb;
-    if (a.dpost) {
-      // wave-level pre-reduction would be nicer; the tensor is tiny (B x 2560) so plain atomics are fine
-      atomicAdd(a.dpost + blk0 + blk, dg * a.g_raw[i]);
-      atomicAdd(a.dpost + a.nblk + blk0 + blk, db * a.b_raw[i]);
-    }
   }
+}
+// dpost[0][blk] += sum_{b,c} dfilm_gamma * g_raw, dpost[1][blk] += sum_{b,c} dfilm_beta * b_raw: one workgroup per
+// (gamma|beta, block) -- a block-level tree reduction instead of 2 * B * W contended atomics
+__global__ __launch_bounds__(256) void film_dpost_kernel(FilmBwdArgs a) {
+  __shared__ float red[4];
+  const int which = blockIdx.x / a.nblk, gblk = blockIdx.x % a.nblk;
+  int m = 0, blk0 = 0, col0 = 0;
+  while (gblk >= blk0 + a.nb[m]) { blk0 += a.nb[m]; col0 += a.nb[m] * a.ch[m]; ++m; }
+  const int blk = gblk - blk0, ch = a.ch[m];
+  const float* raw = which ? a.b_raw : a.g_raw;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < a.B * ch; i += 256) {
+    const int b = i / ch, c = i - b * ch;
+    const float d = a.dfilm[m][((long)b * a.nb[m] + blk) * 2 * ch + (which ? ch : 0) + c];
+    acc += d * raw[(long)b * a.W + col0 + blk * ch + c];
+  }
+  acc = dx_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) a.dpost[which * a.nblk + gblk] += red[0] + red[1] + red[2] + red[3];
 }
 
 // ------------------------------------------------------------------ exact-fp32 small linear
@@ -219,19 +235,22 @@ __global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float* __re
 __global__ __launch_bounds__(256) void linear_small_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                   const float* __restrict__ w, float* __restrict__ dx,
                                                                   const int64_t* __restrict__ mask_len, int N, long M, int K,
-                                                                  int O, int relu, float scale) {
+                                                                  int O, int relu, float scale, int o_chunk) {
+  // gridDim.y splits the output-feature loop (FiLM projections: O = 1280 for only M*K = 6144 threads); partial
+  // sums are combined with atomics into a zeroed dx when there is more than one chunk
   const long total = M * K;
+  const int o0 = blockIdx.y * o_chunk, o1 = min(O, o0 + o_chunk);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long m = i / K; const int k = (int)(i - m * K);
     float acc = 0.f;
     if (!mask_len || (int)(m % N) < (int)mask_len[m / N]) {
-      for (int o = 0; o < O; ++o) {
+      for (int o = o0; o < o1; ++o) {
         float g = dy[m * O + o];
         if (relu && !(y[m * O + o] > 0.f)) g = 0.f;
         acc = fmaf(g, w[(long)o * K + k], acc);
       }
     }
-    dx[i] = acc * scale;
+    if (gridDim.y == 1) dx[i] = acc * scale; else atomicAdd(dx + i, acc * scale);
   }
 }
 // dW[o][k] += sum_m dyg[m][o] x[m][k]; db[o] += sum_m dyg[m][o].  grid (ceil(O*K/256), mchunks)
@@ -331,7 +350,9 @@ extern "C" int dx_embed_pos_bwd(const int64_t* ids, const float* dout, const int
 extern "C" int dx_masked_mean_fwd(const float* x, const int64_t* lengths, float* out, int B, int N, int C, void* stream) {
   DX_REQUIRE(x && lengths && out, DX_ERR_ARG, "dx_masked_mean_fwd: null pointer");
   DX_REQUIRE(C == C128, DX_ERR_UNSUPPORTED, "dx_masked_mean_fwd: C=%d (only 128)", C);
-  hipLaunchKernelGGL(masked_mean_fwd_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, x, lengths, out, N);
+  hipMemsetAsync(out, 0, (size_t)B * C128 * sizeof(float), (hipStream_t)stream);
+  const int rpc = 64;
+  hipLaunchKernelGGL(masked_mean_fwd_kernel, dim3(B, dx_cdiv(N, rpc)), dim3(128), 0, (hipStream_t)stream, x, lengths, out, N, rpc);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
@@ -364,6 +385,7 @@ extern "C" int dx_film_assemble_bwd(const float* g_raw, const float* b_raw, cons
   a.dg_raw = dg_raw; a.db_raw = db_raw; a.dpost = post ? dpost : nullptr; a.B = B;
   for (int m = 0; m < 3; ++m) { a.nb[m] = nb[m]; a.ch[m] = ch[m]; a.W += nb[m] * ch[m]; a.nblk += nb[m]; }
   hipLaunchKernelGGL(film_assemble_bwd_kernel, dim3(grid_for((long)B * a.W)), dim3(256), 0, (hipStream_t)stream, a);
+  if (a.dpost) hipLaunchKernelGGL(film_dpost_kernel, dim3(2 * a.nblk), dim3(256), 0, (hipStream_t)stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
@@ -383,7 +405,12 @@ extern "C" int dx_linear_small_bwd(const float* dy, const float* y, const float*
   DX_REQUIRE(dy && x && w && dw, DX_ERR_ARG, "dx_linear_small_bwd: null pointer");
   DX_REQUIRE(!relu || y, DX_ERR_ARG, "dx_linear_small_bwd: relu needs the forward output y");
   hipStream_t s = (hipStream_t)stream;
-  if (dx) hipLaunchKernelGGL(linear_small_bwd_dx_kernel, dim3(grid_for(M * K)), dim3(256), 0, s, dy, y, w, dx, mask_lengths, N, M, K, O, relu, dx_scale);
+  if (dx) {
+    const int chunks = (O > 64 && M * K < (1L << 18)) ? dx_cdiv(O, 64) : 1;
+    if (chunks > 1) hipMemsetAsync(dx, 0, (size_t)M * K * sizeof(float), s);
+    hipLaunchKernelGGL(linear_small_bwd_dx_kernel, dim3(grid_for(M * K), chunks), dim3(256), 0, s, dy, y, w, dx, mask_lengths, N, M, K, O,
+                       relu, dx_scale, dx_cdiv(O, chunks));
+  }
   int rpc = 64;
   while (rpc < 4096 && (M + rpc - 1) / rpc > 256) rpc *= 2;
   dim3 grid(dx_cdiv(O * K, 256), (unsigned)((M + rpc - 1) / rpc));

@@ -201,6 +201,7 @@ class DaftExprt(nn.Module):
             off += n
         self._flat, self._gflat = flat, gflat
         self._pos = None
+        self._packed = {}
         self.mark_updated()
 
     def flat_parameters(self):
@@ -241,20 +242,26 @@ class DaftExprt(nn.Module):
         return self._pos
 
     def _weights(self, need_dgrad):
-        ''' MFMA-operand copies of the GEMM weights (compute dtype; forward and data-gradient packings) '''
-        stale = self._packed_version != self._param_version or self.always_repack
-        if stale:
+        ''' MFMA-operand copies of the GEMM weights (compute dtype): forward packing [tap][Cout][Cin] and
+            data-gradient packing [tap][Cin][Cout] with flipped taps, refreshed by ONE batched kernel launch each '''
+        if not self._packed:
+            dev, fwd, bwd = self._flat.device, [], []
             for name in self._gemm_weights:
                 w = self._P[name]
-                self._packed[name] = ops.pack_conv_weight(w, self.cd, out=self._packed.get(name))
+                taps = w.shape[2] if w.dim() == 3 else 1
+                self._packed[name] = torch.empty((taps, w.shape[0], w.shape[1]), dtype=self.cd, device=dev)
+                fwd.append((w, self._packed[name], False))
+                if name != 'prosody_encoder.convs.0.conv.weight':   # the mel input needs no gradient
+                    self._packed['T:' + name] = torch.empty((taps, w.shape[1], w.shape[0]), dtype=self.cd, device=dev)
+                    bwd.append((w, self._packed['T:' + name], True))
+            self._pack_fwd, self._pack_bwd = ops.pack_table(fwd, dev), ops.pack_table(bwd, dev)
+            self._packed_version = self._dgrad_version = -1
+        if self._packed_version != self._param_version or self.always_repack:
+            ops.pack_weights_batched(*self._pack_fwd, self.cd)
             self._packed_version = self._param_version
             self._dgrad_version = -1
-        if need_dgrad and getattr(self, '_dgrad_version', -1) != self._packed_version:
-            for name in self._gemm_weights:
-                if name == 'prosody_encoder.convs.0.conv.weight':
-                    continue   # the mel input needs no gradient
-                self._packed['T:' + name] = ops.pack_conv_weight(self._P[name], self.cd, transpose_flip=True,
-                                                                 out=self._packed.get('T:' + name))
+        if need_dgrad and self._dgrad_version != self._packed_version:
+            ops.pack_weights_batched(*self._pack_bwd, self.cd)
             self._dgrad_version = self._packed_version
         return self._packed
 
@@ -295,44 +302,55 @@ class DaftExprt(nn.Module):
             [mel, output_lengths], weights
 
     # ------------------------------------------------------------------ forward building blocks
-    def _fft_block_fwd(self, W, pre, x, film, lengths, cfg, train, save):
+    def _fft_block_fwd(self, W, pre, x, film, lengths, cfg, train, save, x_lp=None):
+        ''' one FFT block (`model.py:251-264`).  In bf16 mode the LayerNorm kernels also emit bf16 copies of their
+            outputs (`*_lp`): they are what the following GEMMs read (half the bytes, no in-kernel conversion) --
+            numerically identical to casting at operand-load time.  Returns (u, u_lp, saved). '''
         P, cd = self._P, self.cd
+        lp = cd == torch.bfloat16
         a_pre, f_pre = f'{pre}.attention', f'{pre}.feed_forward'
         p_attn = cfg['attn_dropout'] if train else 0.
         p_conv = cfg['conv_dropout'] if train else 0.
         s = _Saved() if save else None
         seeds = [self._seed() for _ in range(3)]
-        qkv = ops.conv1d(x, W[f'{a_pre}.multi_head_attention.in_proj_weight'], P[f'{a_pre}.multi_head_attention.in_proj_bias'],
-                         out_dtype=cd)
+        xin = x_lp if x_lp is not None else x
+        qkv = ops.conv1d(xin, W[f'{a_pre}.multi_head_attention.in_proj_weight'], P[f'{a_pre}.multi_head_attention.in_proj_bias'],
+                         out_dtype=cd, skip_lengths=lengths)
         o, lse = ops.attention_fwd(qkv, lengths, cfg['attn_nb_heads'], p_attn, seeds[0], need_lse=save)
         proj = ops.conv1d(o, W[f'{a_pre}.multi_head_attention.out_proj.weight'], P[f'{a_pre}.multi_head_attention.out_proj.bias'],
-                          out_dtype=torch.float32)
-        a, s1, mean1, rstd1 = ops.layernorm_fwd(proj, P[f'{a_pre}.layer_norm.weight'], P[f'{a_pre}.layer_norm.bias'], residual=x,
-                                                lengths=lengths, save=save, save_s=save, p_pre=p_attn, seed_pre=seeds[1])
-        h = ops.conv1d(a, W[f'{f_pre}.convs.0.conv.weight'], P[f'{f_pre}.convs.0.conv.bias'], out_dtype=cd, relu=True)
-        z = ops.conv1d(h, W[f'{f_pre}.convs.2.conv.weight'], P[f'{f_pre}.convs.2.conv.bias'], out_dtype=torch.float32)
-        u, s2, mean2, rstd2 = ops.layernorm_fwd(z, P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'], residual=a,
-                                                film=film, lengths=lengths, save=save, save_s=save, p_pre=p_conv, seed_pre=seeds[2])
+                          out_dtype=torch.float32, skip_lengths=lengths)
+        r = ops.layernorm_fwd(proj, P[f'{a_pre}.layer_norm.weight'], P[f'{a_pre}.layer_norm.bias'], residual=x, lengths=lengths,
+                              save=save, save_s=save, p_pre=p_attn, seed_pre=seeds[1], skip_lengths=lengths, lp_copy=lp)
+        (a, a_lp, s1, mean1, rstd1) = r if lp else (r[0], None) + tuple(r[1:])
+        ain = a_lp if lp else a
+        h = ops.conv1d(ain, W[f'{f_pre}.convs.0.conv.weight'], P[f'{f_pre}.convs.0.conv.bias'], out_dtype=cd, relu=True,
+                       skip_lengths=lengths)
+        z = ops.conv1d(h, W[f'{f_pre}.convs.2.conv.weight'], P[f'{f_pre}.convs.2.conv.bias'], out_dtype=torch.float32,
+                       skip_lengths=lengths)
+        r = ops.layernorm_fwd(z, P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'], residual=a, film=film,
+                              lengths=lengths, save=save, save_s=save, p_pre=p_conv, seed_pre=seeds[2], skip_lengths=lengths,
+                              lp_copy=lp)
+        (u, u_lp, s2, mean2, rstd2) = r if lp else (r[0], None) + tuple(r[1:])
         if save:
-            s.pre, s.cfg, s.x, s.film, s.lengths = pre, cfg, x, film, lengths
-            s.qkv, s.o, s.lse, s.s1, s.mean1, s.rstd1, s.a, s.h, s.s2, s.mean2, s.rstd2 = qkv, o, lse, s1, mean1, rstd1, a, h, s2, mean2, rstd2
+            s.pre, s.cfg, s.x, s.film, s.lengths = pre, cfg, xin, film, lengths
+            s.qkv, s.o, s.lse, s.s1, s.mean1, s.rstd1, s.a, s.h, s.s2, s.mean2, s.rstd2 = qkv, o, lse, s1, mean1, rstd1, ain, h, s2, mean2, rstd2
             s.seeds, s.p_attn, s.p_conv = seeds, p_attn, p_conv
-        return u, s
+        return u, u_lp, s
 
-    def _conv_ln_fwd(self, W, conv_name, ln_name, x, p_drop, out_dtype, save, film=None, lengths=None):
+    def _conv_ln_fwd(self, W, conv_name, ln_name, x, p_drop, out_dtype, save, film=None, lengths=None, skip=None):
         ''' conv k3 -> ReLU -> LayerNorm -> Dropout [-> FiLM -> mask]  (prenet `model.py:341-363`, predictor 528-566) '''
         P = self._P
         cout = P[f'{conv_name}.conv.weight'].shape[0]
         c_dtype = torch.float32 if (self.cd == torch.float32 or cout == 128) else self.cd   # wide tensors in the MFMA operand type
-        c = ops.conv1d(x, W[f'{conv_name}.conv.weight'], P[f'{conv_name}.conv.bias'], relu=True, out_dtype=c_dtype)
+        c = ops.conv1d(x, W[f'{conv_name}.conv.weight'], P[f'{conv_name}.conv.bias'], relu=True, out_dtype=c_dtype, skip_lengths=skip)
         seed = self._seed()
         y, _, mean, rstd = ops.layernorm_fwd(c, P[f'{ln_name}.weight'], P[f'{ln_name}.bias'], film=film, lengths=lengths,
-                                             out_dtype=out_dtype, save=save, p_post=p_drop, seed_post=seed)
+                                             out_dtype=out_dtype, save=save, p_post=p_drop, seed_post=seed, skip_lengths=skip)
         s = None
         if save:
             s = _Saved()
-            s.conv_name, s.ln_name, s.x, s.c, s.mean, s.rstd, s.p, s.seed, s.film, s.lengths = \
-                conv_name, ln_name, x, c, mean, rstd, p_drop, seed, film, lengths
+            s.conv_name, s.ln_name, s.x, s.c, s.mean, s.rstd, s.p, s.seed, s.film, s.lengths, s.skip = \
+                conv_name, ln_name, x, c, mean, rstd, p_drop, seed, film, lengths, skip
         return y, s
 
     def _prosody_encoder_fwd(self, W, frames_energy, frames_pitch, mel_specs, speaker_ids, output_lengths, train, save):
@@ -342,16 +360,17 @@ class DaftExprt(nn.Module):
         s = _Saved()
         x = mel_specs.transpose(1, 2).contiguous()   # (B, T, n_mel) channel-last view of the input batch
         wide = self.cd
-        l1, s.c1 = self._conv_ln_fwd(W, f'{pre}.convs.0', f'{pre}.convs.2', x, p_conv, wide, save)
-        l2, s.c2 = self._conv_ln_fwd(W, f'{pre}.convs.4', f'{pre}.convs.6', l1, p_conv, wide, save)
-        l3, s.c3 = self._conv_ln_fwd(W, f'{pre}.convs.8', f'{pre}.convs.10', l2, p_conv, torch.float32, save)
+        l1, s.c1 = self._conv_ln_fwd(W, f'{pre}.convs.0', f'{pre}.convs.2', x, p_conv, wide, save, skip=output_lengths)
+        l2, s.c2 = self._conv_ln_fwd(W, f'{pre}.convs.4', f'{pre}.convs.6', l1, p_conv, wide, save, skip=output_lengths)
+        l3, s.c3 = self._conv_ln_fwd(W, f'{pre}.convs.8', f'{pre}.convs.10', l2, p_conv, torch.float32, save, skip=output_lengths)
         x0 = ops.scalar_embed_fwd([frames_energy, frames_pitch],
                                   [P[f'{pre}.energy_embedding.conv.weight'], P[f'{pre}.pitch_embedding.conv.weight']],
                                   [P[f'{pre}.energy_embedding.conv.bias'], P[f'{pre}.pitch_embedding.conv.bias']],
                                   base=l3, pos_table=self._pos_table(), lengths=output_lengths)
         s.blocks = []
+        x_lp = None
         for blk in range(cfg['nb_blocks']):
-            x0, sb = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x0, None, output_lengths, cfg, train, save)
+            x0, x_lp, sb = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x0, None, output_lengths, cfg, train, save, x_lp)
             s.blocks.append(sb)
         emb = ops.masked_mean_fwd(x0, output_lengths)
         z = ops.gather_add_fwd(emb, P[f'{pre}.spk_embedding.weight'], speaker_ids)
@@ -377,9 +396,9 @@ class DaftExprt(nn.Module):
         ''' `model.py:490-509` '''
         cfg, pre = self.hp.phoneme_encoder, 'phoneme_encoder'
         x = ops.embed_pos_fwd(symbols, self._P[f'{pre}.symbols_embedding.weight'], self._pos_table(), input_lengths)
-        blocks = []
+        blocks, x_lp = [], None
         for blk in range(cfg['nb_blocks']):
-            x, sb = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x, film[:, blk, :], input_lengths, cfg, train, save)
+            x, x_lp, sb = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x, film[:, blk, :], input_lengths, cfg, train, save, x_lp)
             blocks.append(sb)
         return x, blocks
 
@@ -389,10 +408,10 @@ class DaftExprt(nn.Module):
         p = cfg['conv_dropout'] if train else 0.
         x, saved = enc, []
         for blk in range(cfg['nb_blocks']):
-            x, s1 = self._conv_ln_fwd(W, f'{pre}.blocks.{blk}.0', f'{pre}.blocks.{blk}.2', x, p, self.cd, save)
+            x, s1 = self._conv_ln_fwd(W, f'{pre}.blocks.{blk}.0', f'{pre}.blocks.{blk}.2', x, p, self.cd, save, skip=input_lengths)
             last = blk == cfg['nb_blocks'] - 1
             x, s2 = self._conv_ln_fwd(W, f'{pre}.blocks.{blk}.4', f'{pre}.blocks.{blk}.6', x, p, torch.float32 if last else self.cd,
-                                      save, film=film[:, blk, :], lengths=input_lengths if last else None)
+                                      save, film=film[:, blk, :], lengths=input_lengths if last else None, skip=input_lengths)
             saved.append((s1, s2))
         L = x.shape[1]
         y = ops.linear_small_fwd(x, P[f'{pre}.projection.linear_layer.weight'], P[f'{pre}.projection.linear_layer.bias'],
@@ -422,12 +441,12 @@ class DaftExprt(nn.Module):
     def _decoder_fwd(self, W, x, film, output_lengths, train, save):
         ''' `model.py:689-710` (positional add + mask already applied by the upsampling kernel) '''
         cfg, pre, P = self.hp.frame_decoder, 'frame_decoder', self._P
-        blocks = []
+        blocks, x_lp = [], None
         for blk in range(cfg['nb_blocks']):
-            x, sb = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x, film[:, blk, :], output_lengths, cfg, train, save)
+            x, x_lp, sb = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x, film[:, blk, :], output_lengths, cfg, train, save, x_lp)
             blocks.append(sb)
         mel = ops.conv1d(x, W[f'{pre}.projection.linear_layer.weight'], P[f'{pre}.projection.linear_layer.bias'],
-                         out_dtype=torch.float32, mask_lengths=output_lengths, transposed_out=True)
+                         out_dtype=torch.float32, mask_lengths=output_lengths, transposed_out=True, skip_lengths=output_lengths)
         return mel, (blocks, x)
 
     def _forward(self, inputs, train, save):
@@ -457,24 +476,25 @@ class DaftExprt(nn.Module):
         ''' du: grad wrt the block output (fp32).  Returns grad wrt the block input. dfilm: (B, 2C) view or None '''
         P, G, cd = self._P, self._G, self.cd
         a_pre, f_pre = f'{s.pre}.attention', f'{s.pre}.feed_forward'
+        lp = cd == torch.bfloat16
         ds2, dz = ops.layernorm_bwd(du, s.s2, s.mean2, s.rstd2, P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'],
                                     G[f'{f_pre}.layer_norm.weight'], G[f'{f_pre}.layer_norm.bias'], film=s.film, dfilm=dfilm,
-                                    lengths=s.lengths, p_pre=s.p_conv, seed_pre=s.seeds[2])
+                                    lengths=s.lengths, p_pre=s.p_conv, seed_pre=s.seeds[2], skip_lengths=s.lengths, lp_only=lp)
         da = ds2
         ops.conv1d_wgrad(dz, s.h, G[f'{f_pre}.convs.2.conv.weight'], G[f'{f_pre}.convs.2.conv.bias'], cd, s.lengths)
-        dh = ops.conv1d(dz, W[f'T:{f_pre}.convs.2.conv.weight'], None, out_dtype=cd, relu_gate=s.h)
+        dh = ops.conv1d(dz, W[f'T:{f_pre}.convs.2.conv.weight'], None, out_dtype=cd, relu_gate=s.h, skip_lengths=s.lengths)
         ops.conv1d_wgrad(dh, s.a, G[f'{f_pre}.convs.0.conv.weight'], G[f'{f_pre}.convs.0.conv.bias'], cd, s.lengths)
-        ops.conv1d(dh, W[f'T:{f_pre}.convs.0.conv.weight'], None, out=da, accumulate=True)
+        ops.conv1d(dh, W[f'T:{f_pre}.convs.0.conv.weight'], None, out=da, accumulate=True, skip_lengths=s.lengths)
         ds1, dproj = ops.layernorm_bwd(da, s.s1, s.mean1, s.rstd1, P[f'{a_pre}.layer_norm.weight'], P[f'{a_pre}.layer_norm.bias'],
                                        G[f'{a_pre}.layer_norm.weight'], G[f'{a_pre}.layer_norm.bias'], lengths=s.lengths,
-                                       p_pre=s.p_attn, seed_pre=s.seeds[1])
+                                       p_pre=s.p_attn, seed_pre=s.seeds[1], skip_lengths=s.lengths, lp_only=lp)
         dx = ds1
         mha = f'{a_pre}.multi_head_attention'
         ops.conv1d_wgrad(dproj, s.o, G[f'{mha}.out_proj.weight'], G[f'{mha}.out_proj.bias'], cd, s.lengths)
-        d_o = ops.conv1d(dproj, W[f'T:{mha}.out_proj.weight'], None, out_dtype=cd)
+        d_o = ops.conv1d(dproj, W[f'T:{mha}.out_proj.weight'], None, out_dtype=cd, skip_lengths=s.lengths)
         dqkv = ops.attention_bwd(s.qkv, s.o, d_o, s.lse, s.lengths, s.cfg['attn_nb_heads'], s.p_attn, s.seeds[0])
         ops.conv1d_wgrad(dqkv, s.x, G[f'{mha}.in_proj_weight'], G[f'{mha}.in_proj_bias'], cd, s.lengths)
-        ops.conv1d(dqkv, W[f'T:{mha}.in_proj_weight'], None, out=dx, accumulate=True)
+        ops.conv1d(dqkv, W[f'T:{mha}.in_proj_weight'], None, out=dx, accumulate=True, skip_lengths=s.lengths)
         return dx
 
     def _conv_ln_bwd(self, W, s, dy, dfilm=None, need_dx=True, dx_out=None, lengths_hint=None):
@@ -482,13 +502,13 @@ class DaftExprt(nn.Module):
         P, G = self._P, self._G
         dc, _ = ops.layernorm_bwd(dy, s.c, s.mean, s.rstd, P[f'{s.ln_name}.weight'], P[f'{s.ln_name}.bias'],
                                   G[f'{s.ln_name}.weight'], G[f'{s.ln_name}.bias'], film=s.film, dfilm=dfilm, lengths=s.lengths,
-                                  d_dtype=s.c.dtype, p_post=s.p, seed_post=s.seed, relu_input=True)
+                                  d_dtype=s.c.dtype, p_post=s.p, seed_post=s.seed, relu_input=True, skip_lengths=s.skip)
         ops.conv1d_wgrad(dc, s.x, G[f'{s.conv_name}.conv.weight'], G[f'{s.conv_name}.conv.bias'], self.cd, lengths_hint)
         if not need_dx:
             return None
         if dx_out is not None:
-            return ops.conv1d(dc, W[f'T:{s.conv_name}.conv.weight'], None, out=dx_out, accumulate=True)
-        return ops.conv1d(dc, W[f'T:{s.conv_name}.conv.weight'], None, out_dtype=s.x.dtype)
+            return ops.conv1d(dc, W[f'T:{s.conv_name}.conv.weight'], None, out=dx_out, accumulate=True, skip_lengths=s.skip)
+        return ops.conv1d(dc, W[f'T:{s.conv_name}.conv.weight'], None, out_dtype=s.x.dtype, skip_lengths=s.skip)
 
     def _backward(self, S, d_spk, d_dur, d_energy, d_pitch, d_mel, d_mel_is_bt=False, section_done=None):
         ''' hand-written backward pass: accumulates every parameter gradient into the flat gradient buffer.
@@ -512,7 +532,7 @@ class DaftExprt(nn.Module):
             d_mel_bt = d_mel if d_mel_is_bt else d_mel.transpose(1, 2).contiguous()
             wname = f'{pre}.projection.linear_layer'
             ops.conv1d_wgrad(d_mel_bt, dec_x, G[f'{wname}.weight'], G[f'{wname}.bias'], self.cd, S.gu.output_lengths)
-            d_dec = ops.conv1d(d_mel_bt, W[f'T:{wname}.weight'], None, out_dtype=torch.float32)
+            d_dec = ops.conv1d(d_mel_bt, W[f'T:{wname}.weight'], None, out_dtype=torch.float32, skip_lengths=S.gu.output_lengths)
         for blk in reversed(range(len(blocks))):
             d_dec = self._fft_block_bwd(W, blocks[blk], d_dec, dfilms[2][:, blk, :])
         done('frame_decoder')

@@ -55,7 +55,7 @@ def pack_conv_weight(w, dtype, transpose_flip=False, out=None):
 
 
 def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, mask_lengths=None,
-           transposed_out=False, out=None, accumulate=False):
+           transposed_out=False, out=None, accumulate=False, skip_lengths=None):
     ''' x (B, N, Cin) [last dim contiguous]; w_packed (taps, Cout, Cin) -> (B, N, Cout) or (B, Cout, N) '''
     H.require_gpu(x, w_packed)
     B, N, Cin = x.shape
@@ -71,8 +71,27 @@ def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, m
       H.check(H.lib().dx_conv1d(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(bias),
                               H.ptr(out), H.dt(out), out.stride(1), H.ptr(relu_gate),
                               H.dt(relu_gate) if relu_gate is not None else 0,
-                              H.ptr(mask_lengths), B, N, Cin, Cout, taps, flags, H.stream()))
+                              H.ptr(mask_lengths), H.ptr(skip_lengths), B, N, Cin, Cout, taps, flags, H.stream()))
     return out
+
+
+def pack_table(entries, device):
+    ''' entries: [(w fp32 tensor, out tensor, transpose_flip)] -> (device descriptor table, n, total_elems) for
+        pack_weights_batched (one launch for every GEMM weight of the model) '''
+    import numpy as np
+    dt = np.dtype([('w', '<u8'), ('out', '<u8'), ('Cout', '<i4'), ('Cin', '<i4'), ('taps', '<i4'), ('tf', '<i4'), ('begin', '<i8')])
+    assert dt.itemsize == H.lib().dx_pack_desc_size()
+    arr, begin = np.zeros(len(entries), dtype=dt), 0
+    for i, (w, out, tf) in enumerate(entries):
+        taps = w.shape[2] if w.dim() == 3 else 1
+        arr[i] = (w.data_ptr(), out.data_ptr(), w.shape[0], w.shape[1], taps, int(tf), begin)
+        begin += w.numel()
+    table = torch.from_numpy(arr.view(np.uint8).copy()).to(device)
+    return table, len(entries), begin
+
+
+def pack_weights_batched(table, n, total, dtype):
+    H.check(H.lib().dx_pack_conv_weights_batched(H.ptr(table), n, total, H._DT[dtype], H.stream()))
 
 
 def conv1d_wgrad(dy, x, dw, db, compute_dtype, lengths=None):
@@ -89,10 +108,12 @@ def conv1d_wgrad(dy, x, dw, db, compute_dtype, lengths=None):
 
 # ----------------------------------------------------------------------------- LayerNorm (+ residual, dropout, FiLM, mask)
 def layernorm_fwd(x, gamma, beta, residual=None, film=None, lengths=None, out_dtype=torch.float32, save=False,
-                  save_s=False, p_pre=0., seed_pre=0, p_post=0., seed_post=0):
+                  save_s=False, p_pre=0., seed_pre=0, p_post=0., seed_post=0, skip_lengths=None, lp_copy=False):
+    ''' returns (y, s_out, mean, rstd) -- or (y, y_bf16, s_out, mean, rstd) with lp_copy '''
     B, N, C = x.shape
     assert x.is_contiguous()
     y = torch.empty((B, N, C), dtype=out_dtype, device=x.device)
+    y_lp = torch.empty((B, N, C), dtype=torch.bfloat16, device=x.device) if lp_copy else None
     mean = rstd = s_out = None
     if save:
         mean = torch.empty(B * N, dtype=torch.float32, device=x.device)
@@ -101,23 +122,29 @@ def layernorm_fwd(x, gamma, beta, residual=None, film=None, lengths=None, out_dt
         s_out = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
     ldf = film.stride(0) if film is not None else 0
     H.check(H.lib().dx_layernorm_fwd(H.ptr(x), H.dt(x), H.ptr(residual), H.ptr(gamma), H.ptr(beta), H.ptr(film), ldf,
-                                     H.ptr(lengths), H.ptr(y), H.dt(y), H.ptr(s_out), H.ptr(mean), H.ptr(rstd), B, N, C,
+                                     H.ptr(lengths), H.ptr(skip_lengths), H.ptr(y), H.dt(y), H.ptr(y_lp), H.ptr(s_out), H.ptr(mean), H.ptr(rstd), B, N, C,
                                      float(p_pre), int(seed_pre), float(p_post), int(seed_post), H.stream()))
+    if lp_copy:
+        return y, y_lp, s_out, mean, rstd
     return y, s_out, mean, rstd
 
 
 def layernorm_bwd(dy, s_in, mean, rstd, gamma, beta, dgamma, dbeta, film=None, dfilm=None, lengths=None,
-                  d_dtype=torch.float32, p_pre=0., seed_pre=0, p_post=0., seed_post=0, relu_input=False):
-    ''' returns (ds, dx_pre); dx_pre is ds itself when there is no pre-dropout. dgamma/dbeta/dfilm accumulate. '''
+                  d_dtype=torch.float32, p_pre=0., seed_pre=0, p_post=0., seed_post=0, relu_input=False, skip_lengths=None, lp_only=False):
+    ''' returns (ds, dx_pre); dx_pre is ds itself when there is no pre-dropout. dgamma/dbeta/dfilm accumulate.
+        lp_only: dx_pre is returned as a bf16 tensor only (it feeds MFMA operands exclusively). '''
     B, N, C = dy.shape
     ds = torch.empty((B, N, C), dtype=d_dtype, device=dy.device)
-    dx_pre = torch.empty_like(ds) if p_pre > 0. else None
+    dx_pre = torch.empty_like(ds) if (p_pre > 0. and not lp_only) else None
+    dx_lp = torch.empty((B, N, C), dtype=torch.bfloat16, device=dy.device) if lp_only else None
     ldf = film.stride(0) if film is not None else 0
     lddf = dfilm.stride(0) if dfilm is not None else 0
     H.check(H.lib().dx_layernorm_bwd(H.ptr(dy), H.dt(dy), H.ptr(s_in), H.dt(s_in), H.ptr(mean), H.ptr(rstd), H.ptr(gamma),
-                                     H.ptr(beta), H.ptr(film), ldf, H.ptr(lengths), H.ptr(ds), H.ptr(dx_pre), H.dt(ds),
+                                     H.ptr(beta), H.ptr(film), ldf, H.ptr(lengths), H.ptr(skip_lengths), H.ptr(ds), H.ptr(dx_pre), H.ptr(dx_lp), H.dt(ds),
                                      H.ptr(dgamma), H.ptr(dbeta), H.ptr(dfilm), lddf, B, N, C, float(p_pre), int(seed_pre),
                                      float(p_post), int(seed_post), int(relu_input), H.stream()))
+    if lp_only:
+        return ds, dx_lp
     return ds, (dx_pre if dx_pre is not None else ds)
 
 
