@@ -56,11 +56,13 @@ __device__ __forceinline__ void stage_tile(TC* dst, const TC* src, long ld_g, in
 
 __device__ __forceinline__ uint32_t athresh(float p) { return p <= 0.f ? 0u : (uint32_t)(p * 4294967296.0); }
 
-constexpr int KT = 64;  // rows of the streamed axis per LDS stage
+// rows of the streamed axis per LDS stage: every stage exposes one global-load latency, so small heads take big stages
+template <int DH> struct Stage { static constexpr int KT = DH <= 16 ? 256 : 128; };
 
 // =============================================================================== forward
 template <typename TC, int DH>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  constexpr int KT = Stage<DH>::KT;
   constexpr int LD = DH + APad<TC>::value, KS = DH / 16, MT = (DH + 31) / 32, WRAP = DH >= 32 ? 32 : 16;
   typedef typename Vec8<TC>::type frag_t;
   __shared__ __attribute__((aligned(16))) TC Ks[KT * LD];
@@ -191,6 +193,7 @@ __global__ void attn_delta_kernel(const TC* __restrict__ o, const TC* __restrict
 // =============================================================================== backward: dQ
 template <typename TC, int DH>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+  constexpr int KT = Stage<DH>::KT;
   constexpr int LD = DH + APad<TC>::value, KS = DH / 16, MT = (DH + 31) / 32, WRAP = DH >= 32 ? 32 : 16;
   typedef typename Vec8<TC>::type frag_t;
   __shared__ __attribute__((aligned(16))) TC Ks[KT * LD];
@@ -284,6 +287,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 // =============================================================================== backward: dK, dV
 template <typename TC, int DH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+  constexpr int KT = Stage<DH>::KT;
   constexpr int LD = DH + APad<TC>::value, KS = DH / 16, MT = (DH + 31) / 32, WRAP = DH >= 32 ? 32 : 16;
   typedef typename Vec8<TC>::type frag_t;
   __shared__ __attribute__((aligned(16))) TC Qs[KT * LD];

@@ -298,7 +298,7 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
 // offset.  Wave (wm, wn) accumulates 64 co x 32 ci x taps = 2*taps MFMA 32x32 tiles.
 constexpr int WG_CO = 128, WG_CI = 64;
 #ifndef DX_WG_P
-#define DX_WG_P 128
+#define DX_WG_P 64
 #endif
 constexpr int WG_P = DX_WG_P;
 
@@ -427,10 +427,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradArgs p) {
       frag_t a[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) a[i] = gather8<TC, 32>(dYs, LDA, kA, kB, wm * 64 + i * 32, lane);
-      if (do_bias) {
+      // unconditional (branch-free): the matrix pipe has slack, a branch here makes the compiler bounce accumulators
 #pragma unroll
-        for (int i = 0; i < 2; ++i) dx_mma(bacc[i], a[i], ones);
-      }
+      for (int i = 0; i < 2; ++i) dx_mma(bacc[i], a[i], ones);
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         frag_t bx = gather8<TC, 32>(Xs, LDB, kA + t, kB + t, wn * 32, lane);
