@@ -1,0 +1,124 @@
+"""CPU tests of the host-side logic of the product package (no GPU, no oracle in the product path):
+hyper-parameters, schedules, collate contracts vs the golden fixtures, state_dict ABI, checkpoint round trip."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from daft_exprt.data_loader import DaftExprtDataCollate, SyntheticUtterances, synthetic_batch
+from daft_exprt.hparams import HyperParams
+from daft_exprt.loss import DaftExprtLoss
+from daft_exprt.model import DaftExprt, param_table
+from daft_exprt.train import update_learning_rate
+from tests.util import make_hparams, INPUT_NAMES
+
+
+def test_hparams_defaults_and_derived_fields(tmp_path):
+    hp = make_hparams()
+    assert hp.n_symbols == 76 and hp.symbols[0] == '_'
+    assert hp.n_speakers == 12 and hp.speakers_id == list(range(11))          # hparams.py:195-203 of the reference
+    assert hp.batch_size == 16 and hp.accumulation_steps == 3 and hp.betas == (0.9, 0.98) and hp.epsilon == 1e-9
+    assert hp.prosody_encoder['attn_nb_heads'] == 8 and hp.frame_decoder['conv_channels'] == 1024
+    assert hp.compute_dtype == 'bf16'
+    with pytest.raises(AssertionError):
+        HyperParams(verbose=False, training_files='a', validation_files='b', output_directory='c', language='english')  # speakers missing
+    with pytest.raises(AssertionError):
+        make_hparams(filter_length=1000)          # not a multiple of hop_length
+    path = os.path.join(tmp_path, 'cfg', 'config.json')
+    hp.save_hyper_params(path)
+    cfg = json.load(open(path))
+    hp2 = HyperParams(verbose=False, **cfg)       # JSON round trip, as launch_training does
+    assert hp2.n_speakers == hp.n_speakers and hp2.prosody_encoder == hp.prosody_encoder and list(hp2.betas) == [0.9, 0.98]
+
+
+def test_schedules_match_reference_kats(golden_dir):
+    fx = np.load(os.path.join(golden_dir, 'schedules.npz'))
+    hp = make_hparams()
+    crit = DaftExprtLoss(0, hp)
+    for it, lr, adv in zip(fx['iterations'], fx['lr'], fx['adv']):
+        assert update_learning_rate(hp, int(it)) == pytest.approx(float(lr), rel=1e-12)
+        assert crit.update_adversarial_weight(int(it)) == pytest.approx(float(adv), rel=1e-12)
+
+
+def test_collate_contract_matches_reference(golden_dir):
+    fx = np.load(os.path.join(golden_dir, 'forward_eval.npz'))
+    items = []
+    for i in range(4):
+        g = lambda nm: torch.from_numpy(fx[f'item{i}_{nm}'])
+        items.append([g('symbols'), g('dur_float'), g('dur_int'), g('sym_energy'), g('sym_pitch'), g('frames_energy'),
+                      g('frames_pitch'), g('mel'), int(fx[f'item{i}_speaker']), f'dir{i}', f'file{i}'])
+    batch = DaftExprtDataCollate(make_hparams())(items)
+    for name, got in zip(INPUT_NAMES, batch[:11]):
+        want = fx[f'in_{name}']
+        assert got.numpy().dtype == want.dtype and np.array_equal(got.numpy(), want), name
+    assert list(batch[11]) == list(fx['collate_dirs']) and list(batch[12]) == list(fx['collate_files'])
+
+
+def test_synthetic_batches_follow_the_collate_invariants():
+    hp = make_hparams()
+    b = synthetic_batch(hp, 6, seed=3, t_max=300)
+    symbols, dur_f, dur_i, s_en, s_pi, in_len, f_en, f_pi, mel, out_len, spk = b[:11]
+    assert torch.all(in_len[:-1] >= in_len[1:])                                  # sorted by phoneme count
+    assert torch.equal(dur_i.sum(1), out_len) and int(out_len.max()) == mel.shape[2] == 300
+    assert int(symbols.max()) < hp.n_symbols and int(spk.max()) < hp.n_speakers - 1
+    for r in range(6):
+        assert not symbols[r, in_len[r]:].any() and not mel[r, :, out_len[r]:].any()   # zero padding
+    ds = SyntheticUtterances(hp, 4, seed=3)
+    assert torch.equal(ds[2][0], ds[2][0])                                       # deterministic per index
+
+
+def test_state_dict_abi_and_module_prefix():
+    hp = make_hparams()
+    m = DaftExprt(hp)
+    sd = m.state_dict()
+    assert len(sd) == 193 and sum(v.numel() for v in sd.values()) == 14727153
+    assert sd['prosody_encoder.post_multipliers'].shape == (2, 9)
+    assert sd['frame_decoder.blocks.3.attention.multi_head_attention.in_proj_weight'].shape == (384, 128)
+    assert sd['prosody_predictor.projection.linear_layer.weight'].shape == (3, 256)
+    assert sd['gaussian_upsampling.projection.0.linear_layer.weight'].shape == (1, 128)
+    assert sd['prosody_encoder.gammas_predictor.linear_layer.weight'].shape == (1280, 128)
+    # parameters are views of one flat buffer, in registration order
+    flat = m.flat_parameters()
+    off = 0
+    for (name, shape, _), (n2, p) in zip(param_table(hp), m.named_parameters()):
+        assert name == n2 and p.data_ptr() == flat.data_ptr() + 4 * off
+        off += p.numel()
+    # load_state_dict keeps the views
+    m2 = DaftExprt(hp)
+    m2.load_state_dict({k: v.clone() for k, v in sd.items()})
+    assert torch.equal(m2.flat_parameters(), flat) and m2.prosody_encoder.post_multipliers.data_ptr() == m2.flat_parameters().data_ptr()
+
+
+def test_checkpoint_round_trip(tmp_path):
+    from daft_exprt.optim import FusedAdam
+    from daft_exprt.train import save_checkpoint, load_checkpoint
+    hp = make_hparams()
+    hp.multiprocessing_distributed = True          # -> 'module.' prefixed keys, like a DDP-trained reference checkpoint
+    m = DaftExprt(hp)
+    opt = FusedAdam(m, lr=3e-4)
+    opt.step_count = 7
+    opt.exp_avg.uniform_(-1, 1)
+    opt.exp_avg_sq.uniform_(0, 1)
+    path = os.path.join(tmp_path, 'checkpoints', 'DaftExprt_7')
+    save_checkpoint(m, opt, hp, 3e-4, 7, best_val_loss=1.5, filepath=path)
+    ckpt = torch.load(path, weights_only=False)
+    assert set(ckpt) == {'iteration', 'learning_rate', 'best_val_loss', 'state_dict', 'optimizer', 'config_params'}   # train.py:73-78
+    assert all(k.startswith('module.') for k in ckpt['state_dict'])
+    assert set(ckpt['optimizer']['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}                                     # torch Adam layout
+    m2 = DaftExprt(hp)
+    opt2 = FusedAdam(m2)
+    _, _, it, lr, best = load_checkpoint(path, 0, m2, opt2, hp)
+    assert (it, lr, best) == (7, 3e-4, 1.5) and opt2.step_count == 7
+    assert torch.equal(m2.flat_parameters(), m.flat_parameters()) and torch.equal(opt2.exp_avg, opt.exp_avg)
+
+
+def test_product_fails_loudly_without_gpu():
+    ''' no CPU fallback: CPU tensors must raise, never silently run elsewhere '''
+    hp = make_hparams()
+    m = DaftExprt(hp)
+    batch = synthetic_batch(hp, 2, seed=1, t_max=40, l_range=(5, 9))
+    inputs = tuple(t for t in batch[:11])
+    with pytest.raises(RuntimeError):
+        m(inputs)

@@ -1,0 +1,76 @@
+"""Data-parallel path on CPU: world_size 2 over gloo.  The gradient reducer only needs the model's flat buffers and
+section table, so a stand-in with the real section layout exercises the bucket construction, the asynchronous
+all-reduce launched from the backward hooks, the parameter broadcast and the rank-consistent result."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class _FlatModel(object):
+    ''' the parts of DaftExprt that parallel.GradReducer touches '''
+    def __init__(self, real):
+        self.SECTIONS = real.SECTIONS
+        self._slices = real.section_slices()
+        n = real.n_params
+        self.flat = torch.zeros(n)
+        self.gflat = torch.zeros(n)
+        self.updated = 0
+
+    def section_slices(self):
+        return self._slices
+
+    def flat_parameters(self):
+        return self.flat
+
+    def flat_gradients(self):
+        return self.gflat
+
+    def mark_updated(self):
+        self.updated += 1
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'ubisoft-laforge-daft-exprt_amd'))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from daft_exprt.model import DaftExprt
+    from daft_exprt.parallel import GradReducer
+    from tests.util import make_hparams
+    torch.manual_seed(100 + rank)
+    real = DaftExprt(make_hparams())
+    model = _FlatModel(real)
+    model.flat.copy_(torch.randn(real.n_params))          # different on every rank
+    red = GradReducer(model)
+    # buckets: contiguous, in backward order, cover every parameter exactly once
+    covered = sorted((off, n) for _, off, n in red.buckets)
+    assert covered[0][0] == 0 and sum(n for _, n in covered) == real.n_params
+    assert all(covered[i][0] + covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+    assert [s for s, _, _ in red.buckets][0] == 'frame_decoder' and [s for s, _, _ in red.buckets][-1] == 'prosody_encoder'
+    red.broadcast_parameters()
+    ref = [torch.zeros_like(model.flat) for _ in range(world)]
+    dist.all_gather(ref, model.flat)
+    assert torch.equal(ref[0], ref[1]) and model.updated == 1
+    # gradients: rank r holds (r + 1) * g ; hooks fire in backward order; result must be the SUM on every rank
+    g = torch.arange(real.n_params, dtype=torch.float32) % 97
+    model.gflat.copy_(g * (rank + 1))
+    for sec in reversed(model.SECTIONS):
+        red.section_done(sec)
+    red.wait()
+    assert torch.equal(model.gflat, g * 3), 'all-reduce over the section buckets is not the rank sum'
+    # non-overlapped variant
+    model.gflat.copy_(g * (rank + 1))
+    red.all_reduce_now()
+    assert torch.equal(model.gflat, g * 3)
+    dist.destroy_process_group()
+    open(os.path.join(tmp, f'ok{rank}'), 'w').write('ok')
+
+
+def test_grad_reducer_world2_gloo(tmp_path):
+    port = 29500 + (os.getpid() % 500)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(tmp_path, 'ok0')) and os.path.exists(os.path.join(tmp_path, 'ok1'))
