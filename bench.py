@@ -70,6 +70,55 @@ def cpu_baseline(hp, batch, n_utt=8, steps=1):
             's_per_step': best}
 
 
+def synth_bench(args, hp, dev, rank, world):
+    ''' BASELINE configs[3]: batched prosody-transfer synthesis, forward only (prosody encoder on the reference mels ->
+        phoneme encoder -> predictor -> integer durations -> Gaussian upsampling -> mel decoder), B sentences per call '''
+    import numpy as np
+    from daft_exprt.model import DaftExprt
+    model = DaftExprt(hp).to(dev).eval()
+    with torch.no_grad():   # duration head centred on ~80 ms so that random-init weights give utterances of realistic length
+        model._P['prosody_predictor.projection.linear_layer.weight'][0].mul_(0.05)
+        model._P['prosody_predictor.projection.linear_layer.bias'].copy_(torch.tensor([0.08, 0., 0.]))
+        model.mark_updated()
+    hp.stats = {f'spk {i}': {'pitch': {'mean': 5.0, 'std': 0.3}} for i in range(hp.n_speakers)}
+    rng = np.random.RandomState(1234 + rank)
+    B = args.batch
+    L = np.sort(rng.randint(40, 161, size=B))[::-1].copy()
+    Tr = rng.randint(250, 1001, size=B)
+    Lm, Tm = int(L.max()), int(Tr.max())
+    symbols = torch.zeros(B, Lm, dtype=torch.long)
+    dur_f = torch.ones(B, Lm)
+    e_ref, p_ref, m_ref = torch.zeros(B, Tm), torch.zeros(B, Tm), torch.zeros(B, hp.n_mel_channels, Tm)
+    for b in range(B):
+        symbols[b, :L[b]] = torch.from_numpy(rng.randint(1, hp.n_symbols, size=L[b]))
+        dur_f[b, :L[b]] = min(1., 1000. / (L[b] * 0.08 * 86.13 * 1.15))     # keep every utterance <= ~1000 frames
+        e_ref[b, :Tr[b]] = torch.from_numpy(rng.uniform(0, 60, size=Tr[b]).astype(np.float32))
+        p_ref[b, :Tr[b]] = torch.from_numpy(np.where(rng.rand(Tr[b]) < 0.3, 0., rng.randn(Tr[b]) * 0.3 + 5.).astype(np.float32))
+        m_ref[b, :, :Tr[b]] = torch.from_numpy(np.clip(rng.randn(hp.n_mel_channels, Tr[b]) * 2 - 5, np.log(1e-5), 2.).astype(np.float32))
+    inputs = (symbols, dur_f, torch.ones(B, Lm), torch.zeros(B, Lm), torch.from_numpy(L), e_ref, p_ref, m_ref,
+              torch.from_numpy(Tr), torch.from_numpy(rng.randint(0, 11, size=B)))
+    inputs = tuple(t.to(dev) for t in inputs)
+    frames = 0
+    for w in range(args.warmup):
+        out = model.inference(tuple(t.clone() for t in inputs), 'add', hp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        enc, dec, _ = model.inference(tuple(t.clone() for t in inputs), 'add', hp)
+        frames += int(dec[1].sum())
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({'metric': 'synth-path mels/sec', 'value': B * args.steps / elapsed, 'unit': 'utterances/s', 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+                          'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+                          'config': {'workload': f'BASELINE configs[3]: batched prosody-transfer synthesis, {B} sentences per call, '
+                                                 'L~U{40..160}, reference mels T~U{250..1000}, forward only', 'global_batch': B * world,
+                                     'generated_frames_per_s': frames / elapsed, 'mean_generated_frames': frames / args.steps / B,
+                                     'audio_seconds_per_s (RTF)': frames / elapsed * hp.hop_length / hp.sampling_rate},
+                          'roofline': None, 'cpu_baseline': None}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -80,6 +129,9 @@ def main():
     ap.add_argument('--pool', type=int, default=4, help='distinct synthetic batches cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-probe', action='store_true')
+    ap.add_argument('--workload', default='train', choices=['train', 'synth'],
+                    help='train = BASELINE configs[1] (default; configs[4] with --batch 256 --tmin 500); synth = configs[3]')
+    ap.add_argument('--tmin', type=int, default=1, help='minimum frames per synthetic utterance (configs[4]: 500)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -98,11 +150,13 @@ def main():
 
     hp = make_hparams(args.batch, args.dtype)
     torch.manual_seed(hp.seed)
+    if args.workload == 'synth':
+        return synth_bench(args, hp, dev, rank, world)
     model = DaftExprt(hp).to(dev).train()
     trainer = Trainer(model, hp, world)
     batches, cpu_batches = [], []
     for i in range(args.pool):
-        cb = synthetic_batch(hp, args.batch, seed=1234 + rank + 1000 * i, t_max=1000, force_first_full=True)
+        cb = synthetic_batch(hp, args.batch, seed=1234 + rank + 1000 * i, t_min=args.tmin, t_max=1000, force_first_full=True)
         cpu_batches.append(cb)
         inputs, targets, _ = model.parse_batch(dev, cb)
         batches.append((inputs, targets))
@@ -178,9 +232,9 @@ def main():
         out = {'metric': 'training mel-frames/sec', 'value': done_frames / elapsed, 'unit': 'mel-frames/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-               'config': {'workload': 'BASELINE configs[1]: full Daft-Exprt train step (fwd + 7-term loss + bwd + Adam, dropout on), '
-                                      '11 speakers, batch 48 per GPU, 80-bin mel, T<=1000 (utterance 0 = 1000 frames), '
-                                      'bf16 MFMA operands, fp32 accumulate/master',
+               'config': {'workload': f'BASELINE configs[{1 if (args.batch == 48 and args.tmin == 1) else 4}]: full Daft-Exprt train step (fwd + 7-term loss + bwd + '
+                                      f'Adam, dropout on, adversarial weight at max), 11 speakers, batch {args.batch} per GPU, 80-bin mel, '
+                                      f'{args.tmin}<=T<=1000 (utterance 0 = 1000 frames), {args.dtype} MFMA operands, fp32 accumulate/master',
                           'global_batch': args.batch * world, 'batch_per_gpu': args.batch, 'accumulation_steps': 1,
                           'parallelism': f'dp{world}', 'valid_frames_per_step': done_frames / args.steps,
                           'params': model.n_params},
