@@ -38,9 +38,12 @@ template <typename TC> struct APad;
 template <> struct APad<bf16_t> { static constexpr int value = 8; };
 template <> struct APad<float> { static constexpr int value = 4; };
 
-template <typename TC> __device__ __forceinline__ float fast_exp(float x);
-template <> __device__ __forceinline__ float fast_exp<bf16_t>(float x) { return __expf(x); }
-template <> __device__ __forceinline__ float fast_exp<float>(float x) { return expf(x); }
+// 2^x: the softmax scale and log2(e) are folded into one FMA in front of it (p = 2^(s*c - m), c = scale*log2 e), so a
+// score costs FMA + v_exp_f32 instead of mul, sub, mul, v_exp.  The exact-fp32 mode uses the accurate exp2f.
+template <typename TC> __device__ __forceinline__ float fast_exp2(float x);
+template <> __device__ __forceinline__ float fast_exp2<bf16_t>(float x) { return __builtin_amdgcn_exp2f(x); }
+template <> __device__ __forceinline__ float fast_exp2<float>(float x) { return exp2f(x); }
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
 // stage `rows` rows x DH columns of a (.., ld_g)-strided global matrix into an LDS tile (zero beyond n_lim)
 template <typename TC, int DH, int LD>
@@ -99,6 +102,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) oT[mt][r] = 0.f;
   float m = -INFINITY, l = 0.f;
+  const float c2 = a.scale * LOG2E;
   const uint32_t th = athresh(a.p_drop), th16 = th >> 16;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const uint32_t drop_key = dx_key32(a.seed, (uint32_t)(b * a.H + h)), drop_row = (uint32_t)q * (uint32_t)N;
@@ -120,21 +124,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
           dx_mma(s, kf, qf[ks]);
         }
         float p[16], mx = -INFINITY;
+        if (k0 + 32 > len) {   // boundary tile only: pad keys -> -inf
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = k0 + dx_acc_row(r, g);
-          p[r] = key < len ? s[r] * a.scale : -INFINITY;
-          mx = fmaxf(mx, p[r]);
+          for (int r = 0; r < 16; ++r) s[r] = (k0 + dx_acc_row(r, g) < len) ? s[r] : -INFINITY;
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m, mx);
-        const float alpha = fast_exp<TC>(m - m_new);
+        const float m_new = fmaxf(m, mx * c2);           // running max in the scaled log2 domain
+        float alpha = 1.f;
+        const bool moved = !__all(m_new == m);           // wave-uniform: most tiles after the first few skip the rescale
+        if (moved) { alpha = fast_exp2<TC>(m - m_new); m = m_new; }
         float rs = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { p[r] = fast_exp<TC>(p[r] - m_new); rs += p[r]; }
+        for (int r = 0; r < 16; ++r) { p[r] = fast_exp2<TC>(fmaf(s[r], c2, -m)); rs += p[r]; }
         rs += __shfl_xor(rs, 32, 64);
         l = l * alpha + rs;
-        m = m_new;
         if (th) {   // one hash decides two keys (16 bits each): key pair (2e, 2e+1) -> hash of the even key
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
@@ -146,8 +151,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         frag_t pf[2] = {pack8<TC>(p), pack8<TC>(p + 8)};
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+          if (moved) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) oT[mt][r] *= alpha;
+            for (int r = 0; r < 16; ++r) oT[mt][r] *= alpha;
+          }
 #pragma unroll
           for (int kstep = 0; kstep < 2; ++kstep) {
             frag_t vf = gather8<TC, WRAP>(Vs + sub * 32 * LD, LD, kstep * 16 + 4 * g, kstep * 16 + 4 * g + 8, mt * 32, lane);
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         }
       }
     }
-    if (lse && g == 0) lse[q] = m + logf(l);
+    if (lse && g == 0) lse[q] = m * LN2 + logf(l);
   }
 }
 
@@ -214,6 +221,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqT[mt][r] = 0.f;
 
+  if (blockIdx.x * 128 >= len && q < N && g == 0)   // pad-query tiles: delta is never used, keep it finite
+    const_cast<float*>(a.delta)[((long)b * a.H + h) * N + q] = 0.f;
   if (blockIdx.x * 128 < len) {
     frag_t qf[KS], dof[KS];
 #pragma unroll
@@ -222,7 +231,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
       dof[ks] = q < N ? *reinterpret_cast<const frag_t*>(dO + (long)q * E + ks * 16 + g * 8) : zero8<TC>();
     }
     const long stat = ((long)b * a.H + h) * N + q;
-    const float lse_q = q < N ? a.lse[stat] : 0.f, delta_q = q < N ? a.delta[stat] : 0.f;
+    const float lse_q = q < N ? a.lse[stat] : 0.f;
+    // delta_q = sum_d dO[q][d] * O[q][d]: the lane pair (g = 0, 1) holds the whole row between them; published for
+    // the dK/dV kernel (launched after this one) so that no separate pass over O / dO is needed
+    float delta_q = 0.f;
+    if (q < N) {
+      const TC* Orow = reinterpret_cast<const TC*>(a.o) + ((long)b * N + q) * E + h * DH;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const frag_t of = *reinterpret_cast<const frag_t*>(Orow + ks * 16 + g * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) delta_q += (float)of[e] * (float)dof[ks][e];
+      }
+    }
+    delta_q += __shfl_xor(delta_q, 32, 64);
+    if (q < N && g == 0) const_cast<float*>(a.delta)[stat] = delta_q;
+    const float c2 = a.scale * LOG2E, lse2 = lse_q * LOG2E;
+    const bool tile_q_valid = blockIdx.x * 128 + wave * 32 + 32 <= len;
     const uint32_t th = athresh(a.p_drop), th16 = th >> 16;
     const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
     const uint32_t drop_key = dx_key32(a.seed, (uint32_t)(b * a.H + h)), drop_row = (uint32_t)q * (uint32_t)N;
@@ -246,6 +271,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
             dx_mma(dp, vf, dof[ks]);
           }
           float ds[16];
+          const bool interior = tile_q_valid && k0 + 32 <= len;   // wave-uniform: no masking needed
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
             const int key = k0 + dx_acc_row(r, g);   // registers r, r+1 hold keys key, key+1 (same hash, see forward)
@@ -255,8 +281,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
               ks0 = (hsh & 0xffffu) >= th16 ? inv_keep : 0.f;
               ks1 = (hsh >> 16) >= th16 ? inv_keep : 0.f;
             }
-            const float p0 = (q_valid && key < len) ? fast_exp<TC>(s[r] * a.scale - lse_q) : 0.f;
-            const float p1 = (q_valid && key + 1 < len) ? fast_exp<TC>(s[r + 1] * a.scale - lse_q) : 0.f;
+            float p0 = fast_exp2<TC>(fmaf(s[r], c2, -lse2)), p1 = fast_exp2<TC>(fmaf(s[r + 1], c2, -lse2));
+            if (!interior) { p0 = (q_valid && key < len) ? p0 : 0.f; p1 = (q_valid && key + 1 < len) ? p1 : 0.f; }
             ds[r] = p0 * (dp[r] * ks0 - delta_q);
             ds[r + 1] = p1 * (dp[r + 1] * ks1 - delta_q);
           }
@@ -322,13 +348,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     const uint32_t th = athresh(a.p_drop), th16 = th >> 16;
     const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
     const uint32_t drop_key = dx_key32(a.seed, (uint32_t)(b * a.H + h));
+    const float c2 = a.scale * LOG2E;
+    const bool tile_k_valid = blockIdx.x * 128 + wave * 32 + 32 <= len;
 
     for (int qt0 = 0; qt0 < len; qt0 += KT) {
       stage_tile<TC, DH, LD>(Qs, base, ld_g, qt0, KT, N, tid);
       stage_tile<TC, DH, LD>(dOs, dO, E, qt0, KT, N, tid);
       if (tid < KT) {
         const int qq = qt0 + tid;
-        lse_s[tid] = qq < N ? lse[qq] : 0.f;
+        lse_s[tid] = qq < N ? lse[qq] * LOG2E : 0.f;   // log2 domain, see fast_exp2
         delta_s[tid] = qq < N ? delta[qq] : 0.f;
       }
       __syncthreads();
@@ -347,11 +375,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
             dx_mma(dp, dof, vf[ks]);  // dP[q][key]
           }
           float pd[16], ds[16];
+          const bool interior = tile_k_valid && qb + 32 <= len;   // wave-uniform
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = sub * 32 + dx_acc_row(r, g);
             const int qq = qt0 + row;
-            const float p = (key_valid && qq < len) ? fast_exp<TC>(s[r] * a.scale - lse_s[row]) : 0.f;
+            float p = fast_exp2<TC>(fmaf(s[r], c2, -lse_s[row]));
+            if (!interior) p = (key_valid && qq < len) ? p : 0.f;
             float kscale = 1.f;
             if (th) {   // same decision as the forward: the hash of the even key of the pair, low / high 16 bits
               const uint32_t hsh = dx_mix32(((uint32_t)qq * (uint32_t)N + (uint32_t)(key & ~1)) * 0x9E3779B1u + drop_key);
@@ -403,9 +433,6 @@ int launch_fwd(const AttnArgs& a, int B, int dh, hipStream_t s) {
 template <typename TC>
 int launch_bwd(const AttnArgs& a, int B, int dh, float* delta, hipStream_t s) {
   dim3 grid(dx_cdiv(a.N, 128), a.H, B), block(256);
-  const long total = (long)B * a.N * a.H;
-  const int dgrid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL((attn_delta_kernel<TC>), dim3(dgrid), dim3(256), 0, s, (const TC*)a.o, (const TC*)a.d_o, delta, B, a.N, a.H, dh);
   if (dh == 16) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, 16>), grid, block, 0, s, a);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<TC, 16>), grid, block, 0, s, a);

@@ -341,7 +341,7 @@ extern "C" int dx_layernorm_bwd(const void* dy, int dy_dtype, const void* s_in, 
   DX_REQUIRE((film == nullptr) == (dfilm == nullptr), DX_ERR_ARG, "dx_layernorm_bwd: film and dfilm come together");
   // enough workgroups to fill 256 CUs, few enough that the per-channel atomics stay cheap
   int rpb = 32;
-  while (rpb < 512 && (long)dx_cdiv(N, rpb) * B > 2048) rpb *= 2;
+  while (rpb < 512 && (long)dx_cdiv(N, rpb) * B > 768) rpb *= 2;
   LNBwdArgs a{dy, s_in, mean, rstd, gamma, beta, film, ldf, lengths, skip_lengths, ds, dx_pre, dx_pre_lp, dgamma, dbeta, dfilm, lddf, N, B, rpb,
               p_pre, p_post, seed_pre, seed_post, relu_input};
   hipStream_t s = (hipStream_t)stream;

@@ -317,8 +317,9 @@ extern "C" int dx_scalar_embed_bwd(const float* dout, const float* const* feats,
   DX_REQUIRE(C == C128, DX_ERR_UNSUPPORTED, "dx_scalar_embed_bwd: C=%d (only 128)", C);
   ScalarEmbedBwdArgs a{};
   a.dout = dout; a.nfeat = nfeat; a.lengths = lengths; a.dbase = dbase; a.N = N;
-  int rpb = 16;
-  while (rpb < 256 && (long)dx_cdiv(N, rpb) * B > 4096) rpb *= 2;
+  // every workgroup ends with 512-1024 atomics on the same few addresses: few, fat workgroups
+  int rpb = 32;
+  while (rpb < 1024 && (long)dx_cdiv(N, rpb) * B > 512) rpb *= 2;
   a.rows_per_block = rpb;
   for (int f = 0; f < nfeat; ++f) { a.feat[f] = feats[f]; a.dw[f] = dws[f]; a.dbias[f] = dbiases[f]; }
   hipLaunchKernelGGL(scalar_embed_bwd_kernel, dim3(dx_cdiv(N, rpb), B), dim3(128), 0, (hipStream_t)stream, a);

@@ -170,6 +170,7 @@ class DaftExprt(nn.Module):
         self._packed, self._packed_version, self._param_version = {}, -1, 0
         self.always_repack = True   # safe default for external optimizers; the fused trainer turns it off
         self._anchor = None
+        self._side = self._side_stream = None
         self._step_id, self._site = 0, 0
         self._pos = None
         self.n_params = sum(int(np.prod(s)) for _, s, _ in self._table)
@@ -472,6 +473,19 @@ class DaftExprt(nn.Module):
         return (logits, films, (dur, energy, pitch), mel, weights), S
 
     # ------------------------------------------------------------------ backward building blocks
+    def _wgrad(self, dy, x, dw, db, lengths=None):
+        ''' weight / bias gradient on the side stream: these kernels are off the critical path of the backward pass
+            (nothing downstream reads dW before the optimizer step), so they overlap with the data-gradient chain. '''
+        side = self._side_stream
+        if side is None:
+            return ops.conv1d_wgrad(dy, x, dw, db, self.cd, lengths)
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)                      # dy / x were produced on the main stream
+        with torch.cuda.stream(side):
+            ops.conv1d_wgrad(dy, x, dw, db, self.cd, lengths)
+        dy.record_stream(side)                      # keep the allocator from recycling them under the side stream
+        x.record_stream(side)
+
     def _fft_block_bwd(self, W, s, du, dfilm):
         ''' du: grad wrt the block output (fp32).  Returns grad wrt the block input. dfilm: (B, 2C) view or None '''
         P, G, cd = self._P, self._G, self.cd
@@ -481,19 +495,19 @@ class DaftExprt(nn.Module):
                                     G[f'{f_pre}.layer_norm.weight'], G[f'{f_pre}.layer_norm.bias'], film=s.film, dfilm=dfilm,
                                     lengths=s.lengths, p_pre=s.p_conv, seed_pre=s.seeds[2], skip_lengths=s.lengths, lp_only=lp)
         da = ds2
-        ops.conv1d_wgrad(dz, s.h, G[f'{f_pre}.convs.2.conv.weight'], G[f'{f_pre}.convs.2.conv.bias'], cd, s.lengths)
+        self._wgrad(dz, s.h, G[f'{f_pre}.convs.2.conv.weight'], G[f'{f_pre}.convs.2.conv.bias'], s.lengths)
         dh = ops.conv1d(dz, W[f'T:{f_pre}.convs.2.conv.weight'], None, out_dtype=cd, relu_gate=s.h, skip_lengths=s.lengths)
-        ops.conv1d_wgrad(dh, s.a, G[f'{f_pre}.convs.0.conv.weight'], G[f'{f_pre}.convs.0.conv.bias'], cd, s.lengths)
+        self._wgrad(dh, s.a, G[f'{f_pre}.convs.0.conv.weight'], G[f'{f_pre}.convs.0.conv.bias'], s.lengths)
         ops.conv1d(dh, W[f'T:{f_pre}.convs.0.conv.weight'], None, out=da, accumulate=True, skip_lengths=s.lengths)
         ds1, dproj = ops.layernorm_bwd(da, s.s1, s.mean1, s.rstd1, P[f'{a_pre}.layer_norm.weight'], P[f'{a_pre}.layer_norm.bias'],
                                        G[f'{a_pre}.layer_norm.weight'], G[f'{a_pre}.layer_norm.bias'], lengths=s.lengths,
                                        p_pre=s.p_attn, seed_pre=s.seeds[1], skip_lengths=s.lengths, lp_only=lp)
         dx = ds1
         mha = f'{a_pre}.multi_head_attention'
-        ops.conv1d_wgrad(dproj, s.o, G[f'{mha}.out_proj.weight'], G[f'{mha}.out_proj.bias'], cd, s.lengths)
+        self._wgrad(dproj, s.o, G[f'{mha}.out_proj.weight'], G[f'{mha}.out_proj.bias'], s.lengths)
         d_o = ops.conv1d(dproj, W[f'T:{mha}.out_proj.weight'], None, out_dtype=cd, skip_lengths=s.lengths)
         dqkv = ops.attention_bwd(s.qkv, s.o, d_o, s.lse, s.lengths, s.cfg['attn_nb_heads'], s.p_attn, s.seeds[0])
-        ops.conv1d_wgrad(dqkv, s.x, G[f'{mha}.in_proj_weight'], G[f'{mha}.in_proj_bias'], cd, s.lengths)
+        self._wgrad(dqkv, s.x, G[f'{mha}.in_proj_weight'], G[f'{mha}.in_proj_bias'], s.lengths)
         ops.conv1d(dqkv, W[f'T:{mha}.in_proj_weight'], None, out=dx, accumulate=True, skip_lengths=s.lengths)
         return dx
 
@@ -503,7 +517,7 @@ class DaftExprt(nn.Module):
         dc, _ = ops.layernorm_bwd(dy, s.c, s.mean, s.rstd, P[f'{s.ln_name}.weight'], P[f'{s.ln_name}.bias'],
                                   G[f'{s.ln_name}.weight'], G[f'{s.ln_name}.bias'], film=s.film, dfilm=dfilm, lengths=s.lengths,
                                   d_dtype=s.c.dtype, p_post=s.p, seed_post=s.seed, relu_input=True, skip_lengths=s.skip)
-        ops.conv1d_wgrad(dc, s.x, G[f'{s.conv_name}.conv.weight'], G[f'{s.conv_name}.conv.bias'], self.cd, lengths_hint)
+        self._wgrad(dc, s.x, G[f'{s.conv_name}.conv.weight'], G[f'{s.conv_name}.conv.bias'], lengths_hint)
         if not need_dx:
             return None
         if dx_out is not None:
@@ -515,7 +529,16 @@ class DaftExprt(nn.Module):
             d_mel: (B, n_mel, T) like the output, or (B, T, n_mel) when d_mel_is_bt.
             section_done(name): called as soon as every gradient of a top-level module is final, in reverse
             registration order (frame_decoder first) -- the data-parallel reducer launches that slice's all-reduce. '''
-        done = section_done or (lambda name: None)
+        use_side = bool(int(__import__('os').environ.get('DX_WGRAD_SIDE_STREAM', '1')))
+        if use_side and self._side is None:
+            self._side = torch.cuda.Stream(device=S.enc_out.device)
+        self._side_stream = self._side if use_side else None
+
+        def done(name):
+            if self._side_stream is not None:       # the section's weight gradients live on the side stream
+                torch.cuda.current_stream().wait_stream(self._side_stream)
+            if section_done is not None:
+                section_done(name)
         hp, P, G = self.hp, self._P, self._G
         W = self._packed
         dev = S.enc_out.device
@@ -531,7 +554,7 @@ class DaftExprt(nn.Module):
         else:
             d_mel_bt = d_mel if d_mel_is_bt else d_mel.transpose(1, 2).contiguous()
             wname = f'{pre}.projection.linear_layer'
-            ops.conv1d_wgrad(d_mel_bt, dec_x, G[f'{wname}.weight'], G[f'{wname}.bias'], self.cd, S.gu.output_lengths)
+            self._wgrad(d_mel_bt, dec_x, G[f'{wname}.weight'], G[f'{wname}.bias'], S.gu.output_lengths)
             d_dec = ops.conv1d(d_mel_bt, W[f'T:{wname}.weight'], None, out_dtype=torch.float32, skip_lengths=S.gu.output_lengths)
         for blk in reversed(range(len(blocks))):
             d_dec = self._fft_block_bwd(W, blocks[blk], d_dec, dfilms[2][:, blk, :])
