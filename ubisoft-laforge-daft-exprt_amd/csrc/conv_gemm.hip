@@ -74,8 +74,14 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
 // barriers per chunk.  Epilogue: accumulators are staged through LDS (reusing the operand buffers) 64 rows at a time
 // and leave as whole 16-byte row segments (16 lanes cover a 128-channel row) -- the MFMA C layout would otherwise
 // emit 64 two-byte stores per lane.
+#ifndef DX_CONV_WPS
+#define DX_CONV_WPS 2
+#endif
+#ifndef DX_WGRAD_WPS
+#define DX_WGRAD_WPS 2
+#endif
 template <typename TA, typename TC, typename TO, typename TG, int TAPS>
-__global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(NTHREADS, DX_CONV_WPS) void conv_gemm_kernel(ConvArgs p) {
   constexpr int HALO = TAPS / 2;
   constexpr int AROWS = BM + TAPS - 1;
   constexpr int LDS_K = BK + Pad<TC>::value;
@@ -313,7 +319,7 @@ struct WgradArgs {
 // The (utterance, 64-position chunk) work items of a workgroup form one flat sequence; the global loads of item k+1
 // are issued into registers (raw element types) before the MFMAs of item k and converted when written to LDS.
 template <typename TA, typename TB, typename TC, int TAPS>
-__global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradArgs p) {
+__global__ __launch_bounds__(NTHREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(WgradArgs p) {
   constexpr int HALO = TAPS / 2, XROWS = WG_P + TAPS - 1;
   // row strides = 16 banks (mod 64) apart: the 4 rows x 2 halves x 4 chunks touched by one 32-lane group of a
   // transpose read (ds_read_b64_tr_b16) then fall on 64 distinct banks
