@@ -63,3 +63,29 @@ def bench_wgrad():
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'wgrad':
     bench_wgrad()
+
+
+def bench_ln():
+    dev = torch.device('cuda:0')
+    B, N = 48, 1000
+    lens = torch.randint(250, 1001, (B,), device=dev)
+    lens[0] = N
+    for C, dt in [(128, torch.float32), (1024, torch.bfloat16)]:
+        x = torch.randn(B, N, C, device=dev).to(dt)
+        res = torch.randn(B, N, C, device=dev) if C == 128 else None
+        g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        film = torch.randn(B, 2 * C, device=dev) if C == 128 else None
+        y, s, mean, rstd = ops.layernorm_fwd(x, g, b, residual=res, film=film, lengths=lens if C == 128 else None, save=True, save_s=(C == 128),
+                                             out_dtype=dt, skip_lengths=lens)
+        ms_f = timeit(lambda: ops.layernorm_fwd(x, g, b, residual=res, film=film, lengths=lens if C == 128 else None, save=True,
+                                                save_s=(C == 128), out_dtype=dt, skip_lengths=lens))
+        dy = torch.randn(B, N, C, device=dev).to(dt)
+        dg, db, dfilm = torch.zeros(C, device=dev), torch.zeros(C, device=dev), (torch.zeros(B, 2 * C, device=dev) if C == 128 else None)
+        sin = s if C == 128 else x
+        ms_b = timeit(lambda: ops.layernorm_bwd(dy, sin, mean, rstd, g, b, dg, db, film=film, dfilm=dfilm, lengths=lens if C == 128 else None,
+                                                d_dtype=dt, skip_lengths=lens, relu_input=(C != 128)))
+        print(f'ln C={C}: fwd {ms_f * 1e3:7.1f} us  bwd {ms_b * 1e3:7.1f} us')
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'ln':
+    bench_ln()

@@ -11,6 +11,8 @@
 // the backward pass) once.  The backward kernel walks a contiguous slab of rows of ONE utterance per
 // workgroup so that the per-channel reductions (dgamma, dbeta, dFiLM) stay in registers and cost one
 // atomic per channel per workgroup.
+#include <stdlib.h>
+
 #include "dx_common.h"
 
 namespace {
@@ -162,6 +164,7 @@ struct LNBwdArgs {
   int N; int B; int rows_per_block;
   float p_pre, p_post; uint64_t seed_pre, seed_post;
   int relu_input;            // s = relu(conv): the returned ds is additionally gated by (s > 0)
+  int debug;                 // DX_LN_DEBUG: 1 = skip the final atomics (ablation only)
 };
 
 // grid = (ceil(N / rows_per_block), B); 4 waves per block, wave w handles rows w, w+4, ... of the slab
@@ -192,6 +195,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
 #pragma unroll
   for (int i = 0; i < L::EPL; ++i) { acc_g[i] = acc_b[i] = acc_fg[i] = acc_fb[i] = 0.f; if (!a.film) fg[i] = 1.f; }
 
+  float g_nx[L::EPL], x_nx[L::EPL], mean_nx = 0.f, rstd_nx = 0.f;
+  auto fetch_row = [&](int n) {
+    const long row = (long)b * a.N + n;
+    const TG* dy = reinterpret_cast<const TG*>(a.dy) + row * C;
+    const TI* sp = reinterpret_cast<const TI*>(a.s) + row * C;
+#pragma unroll
+    for (int k = 0; k < L::NV; ++k) {
+      const int c0 = L::col(lane, k);
+      load_vec<TG, L::V>(dy + c0, g_nx + k * L::V);
+      load_vec<TI, L::V>(sp + c0, x_nx + k * L::V);
+    }
+    mean_nx = a.mean[row];
+    rstd_nx = a.rstd[row];
+  };
+  if (n_begin + wave < n_end && n_begin + wave < nskip) fetch_row(n_begin + wave);
+
   for (int n = n_begin + wave; n < n_end; n += 4) {
     const long row = (long)b * a.N + n;
     if (n >= nskip) {   // gradient rows past length + halo are exactly zero
@@ -208,18 +227,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
       }
       continue;
     }
-    const TG* dy = reinterpret_cast<const TG*>(a.dy) + row * C;
-    const TI* s = reinterpret_cast<const TI*>(a.s) + row * C;
-    const float mean = a.mean[row], rstd = a.rstd[row];
+    // this row's operands were fetched one iteration ago; issue the loads of the wave's next row before computing
     float g[L::EPL], xh[L::EPL];
+#pragma unroll
+    for (int j = 0; j < L::EPL; ++j) { g[j] = g_nx[j]; xh[j] = x_nx[j]; }
+    const float mean = mean_nx, rstd = rstd_nx;
+    if (n + 4 < n_end && n + 4 < nskip) fetch_row(n + 4);
     bool pos[L::EPL];
     const bool pad = n >= len;
-#pragma unroll
-    for (int k = 0; k < L::NV; ++k) {
-      const int c0 = L::col(lane, k);
-      load_vec<TG, L::V>(dy + c0, g + k * L::V);
-      load_vec<TI, L::V>(s + c0, xh + k * L::V);
-    }
     float m1 = 0.f, m2 = 0.f;
 #pragma unroll
     for (int k = 0; k < L::NV; ++k) {
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
     }
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 4 * C; idx += 256) {
+  for (int idx = threadIdx.x; idx < 4 * C && !(a.debug & 1); idx += 256) {
     const int which = idx / C, c = idx - which * C;
     const float t = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
     if (which == 0) atomicAdd(a.dgamma + c, t);
@@ -340,10 +355,12 @@ extern "C" int dx_layernorm_bwd(const void* dy, int dy_dtype, const void* s_in, 
   DX_REQUIRE(B > 0 && N > 0, DX_ERR_SHAPE, "dx_layernorm_bwd: empty shape");
   DX_REQUIRE((film == nullptr) == (dfilm == nullptr), DX_ERR_ARG, "dx_layernorm_bwd: film and dfilm come together");
   // enough workgroups to fill 256 CUs, few enough that the per-channel atomics stay cheap
+  static int dbg = getenv("DX_LN_DEBUG") ? atoi(getenv("DX_LN_DEBUG")) : 0;
+  static int maxblk = getenv("DX_LN_BLOCKS") ? atoi(getenv("DX_LN_BLOCKS")) : 768;
   int rpb = 32;
-  while (rpb < 512 && (long)dx_cdiv(N, rpb) * B > 768) rpb *= 2;
+  while (rpb < 1024 && (long)dx_cdiv(N, rpb) * B > maxblk) rpb *= 2;
   LNBwdArgs a{dy, s_in, mean, rstd, gamma, beta, film, ldf, lengths, skip_lengths, ds, dx_pre, dx_pre_lp, dgamma, dbeta, dfilm, lddf, N, B, rpb,
-              p_pre, p_post, seed_pre, seed_post, relu_input};
+              p_pre, p_post, seed_pre, seed_post, relu_input, dbg};
   hipStream_t s = (hipStream_t)stream;
   if (s_dtype == DX_F32 && dy_dtype == DX_F32 && d_dtype == DX_F32) return launch_bwd<float, float, float>(a, C, s);
   if (s_dtype == DX_BF16 && dy_dtype == DX_BF16 && d_dtype == DX_BF16) return launch_bwd<bf16_t, bf16_t, bf16_t>(a, C, s);
