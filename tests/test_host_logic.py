@@ -122,3 +122,29 @@ def test_product_fails_loudly_without_gpu():
     inputs = tuple(t for t in batch[:11])
     with pytest.raises(RuntimeError):
         m(inputs)
+
+
+def test_feature_reader_matches_reference(golden_dir):
+    ''' the on-disk feature reader vs the reference's DaftExprtDataLoader on the same files '''
+    from daft_exprt.data_loader import DaftExprtDataLoader
+    fx = np.load(os.path.join(golden_dir, 'data_loader.npz'))
+    hp = make_hparams()
+    hp.stats = {f'spk {i}': {'energy': {'mean': float(fx['stats_energy_mean'][i]), 'std': float(fx['stats_energy_std'][i])},
+                             'pitch': {'mean': float(fx['stats_pitch_mean'][i]), 'std': float(fx['stats_pitch_std'][i])}} for i in range(11)}
+    cwd = os.getcwd()
+    os.chdir(golden_dir)
+    try:
+        ds = DaftExprtDataLoader(os.path.join(golden_dir, 'train_list.txt'), hp, shuffle=True)
+        assert len(ds) == int(fx['n_items'])
+        for i in range(len(ds)):
+            item = ds[i]
+            assert item[10] == str(fx[f'item{i}_file'])            # same seeded shuffle order
+            assert item[8] == int(fx[f'item{i}_speaker'])
+            for j, nm in enumerate(['symbols', 'dur_float', 'dur_int', 'sym_energy', 'sym_pitch', 'frames_energy', 'frames_pitch', 'mel']):
+                want = fx[f'item{i}_{nm}']
+                got = item[j].numpy()
+                assert got.dtype == want.dtype and np.array_equal(got, want), (i, nm)
+        batch = DaftExprtDataCollate(hp)([ds[i] for i in range(len(ds))])
+        assert batch[8].shape == (5, 80, 30) and batch[5].tolist() == sorted(batch[5].tolist(), reverse=True)
+    finally:
+        os.chdir(cwd)

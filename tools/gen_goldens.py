@@ -300,6 +300,55 @@ def main():
     p2, ints = model.get_int_durations(p, hp)
     np.savez_compressed(os.path.join(OUT, 'get_int_durations.npz'), preds=preds, thresholded=np_(p2), ints=np_(ints))
 
+    # ------------------------------------------------------------------ F. on-disk feature reader (data_loader.py:11-137)
+    # a tiny pre-processed data set in the reference's file formats (written here, read by the reference loader)
+    from daft_exprt.data_loader import DaftExprtDataLoader
+    rng = np.random.RandomState(2024)
+    feat_root = os.path.join(OUT, 'features')
+    lines = []
+    hp = make_hparams(ref_hparams)
+    hp.stats = {f'spk {i}': {'energy': {'mean': 20. + i, 'std': 5. + 0.5 * i}, 'pitch': {'mean': 5.0 + 0.05 * i, 'std': 0.25 + 0.01 * i}}
+                for i in range(11)}
+    for u, (spk, L, T) in enumerate([(0, 6, 21), (3, 9, 30), (3, 4, 11), (7, 7, 25), (0, 5, 17)]):
+        d = os.path.join(feat_root, f'spk{spk:02d}')
+        os.makedirs(d, exist_ok=True)
+        name = f'utt{u:03d}'
+        cut = np.sort(rng.randint(0, T + 1, size=L - 1))
+        dur = np.diff(np.concatenate(([0], cut, [T])))
+        np.save(os.path.join(d, name + '.npy'), np.clip(rng.randn(80, T) * 1.2 - 1., np.log(1e-5), 2.).astype(np.float32))
+        t = 0.
+        with open(os.path.join(d, name + '.markers'), 'w') as f:
+            for l in range(L):
+                end = t + dur[l] * 256. / 22050. + (0.001 if dur[l] == 0 else 0.)
+                sym = hp.symbols[int(rng.randint(1, 76))]
+                f.write(f'{t:.6f}\t{end:.6f}\t{int(dur[l])}\t{sym}\tword{l}\t{l}\n')
+                t = end
+        for ext, n, zero_p in (('symbols_nrg', L, 0.2), ('frames_nrg', T, 0.1), ('symbols_f0', L, 0.3), ('frames_f0', T, 0.3)):
+            vals = rng.uniform(10., 40., size=n) if 'nrg' in ext else rng.uniform(4.5, 5.6, size=n)
+            vals[rng.rand(n) < zero_p] = 0.
+            with open(os.path.join(d, name + '.' + ext), 'w') as f:
+                f.write('\n'.join(f'{v:.5f}' for v in vals) + '\n')
+        lines.append(f'{os.path.join("features", f"spk{spk:02d}")}|{name}|{spk}')
+    list_file = os.path.join(OUT, 'train_list.txt')
+    with open(list_file, 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    cwd = os.getcwd()
+    os.chdir(OUT)   # list entries are relative to tests/golden
+    ds = DaftExprtDataLoader(list_file, hp, shuffle=True)
+    fx = {'n_items': np.int64(len(ds)), 'stats_energy_mean': np.array([hp.stats[f'spk {i}']['energy']['mean'] for i in range(11)]),
+          'stats_energy_std': np.array([hp.stats[f'spk {i}']['energy']['std'] for i in range(11)]),
+          'stats_pitch_mean': np.array([hp.stats[f'spk {i}']['pitch']['mean'] for i in range(11)]),
+          'stats_pitch_std': np.array([hp.stats[f'spk {i}']['pitch']['std'] for i in range(11)])}
+    for i in range(len(ds)):
+        item = ds[i]
+        for j, nm in enumerate(['symbols', 'dur_float', 'dur_int', 'sym_energy', 'sym_pitch', 'frames_energy', 'frames_pitch', 'mel']):
+            fx[f'item{i}_{nm}'] = np_(item[j])
+        fx[f'item{i}_speaker'] = np.int64(item[8])
+        fx[f'item{i}_file'] = np.array(item[10])
+    os.chdir(cwd)
+    np.savez_compressed(os.path.join(OUT, 'data_loader.npz'), **fx)
+    print('data_loader: order', [str(fx[f'item{i}_file']) for i in range(len(ds))])
+
     # ------------------------------------------------------------------ E. schedules
     its = np.array([0, 1, 2, 100, 4999, 5000, 9999, 10000, 10001, 20000, 40000, 123457, 370000])
     lr = np.array([update_learning_rate(hp, int(i)) if i > 0 else update_learning_rate(hp, 0) for i in its])

@@ -4,10 +4,84 @@
 sort by phoneme count (descending), right-zero-pad to the batch maxima, `output_lengths` follows the same
 permutation (NOT sorted by T), 13-tuple order consumed by `DaftExprt.parse_batch`.
 `SyntheticUtterances` generates the seeded synthetic utterances of SURVEY 8(d) (there are no corpora in the
-build / bench environment); the on-disk feature reader of `data_loader.py:11-137` is the next row of SURVEY 8(f).
+build / bench environment).  `DaftExprtDataLoader` reads the reference's pre-processed feature files.
 """
+import os
+import random
+
 import numpy as np
 import torch
+from torch.utils.data import DataLoader, Dataset
+from torch.utils.data.distributed import DistributedSampler
+
+
+def _read_floats(path):
+    with open(path, 'r', encoding='utf-8') as f:
+        return np.array([float(line) for line in f.read().split()], dtype=np.float64)
+
+
+class DaftExprtDataLoader(Dataset):
+    ''' reader of the reference's pre-processed feature files (`data_loader.py:11-137`).  One list line
+        `features_dir|feature_file|speaker_id` per utterance; per utterance: `<file>.npy` mel-spec (n_mel, T),
+        `<file>.markers` TSV rows `begin end int_dur symbol word word_idx`, and one-float-per-line text files
+        `.symbols_nrg .frames_nrg .symbols_f0 .frames_f0`.  Symbol-level energy / pitch are standardised with the
+        speaker statistics of `hparams.stats`, zeros (unvoiced / silent) are preserved; frame-level values stay raw.
+        The list is shuffled once with `random.seed(hparams.seed)` like the reference. '''
+    def __init__(self, data_file, hparams, shuffle=True):
+        assert os.path.isfile(data_file), f'no such list file "{data_file}"'
+        with open(data_file, 'r', encoding='utf-8') as f:
+            self.data = [line.strip().split('|') for line in f if line.strip()]
+        self.hparams = hparams
+        if shuffle:
+            random.seed(hparams.seed)
+            random.shuffle(self.data)
+
+    def _standardise(self, values, speaker_id, feature):
+        stats = self.hparams.stats[f'spk {speaker_id}'][feature]
+        zeros = values == 0.
+        values = (values - stats['mean']) / stats['std']
+        values[zeros] = 0.
+        return values
+
+    def __getitem__(self, index):
+        features_dir, feature_file, speaker_id = self.data[index][0], self.data[index][1], int(self.data[index][2])
+        base = os.path.join(features_dir, feature_file)
+        mel_spec = torch.from_numpy(np.load(base + '.npy'))
+        assert mel_spec.size(0) == self.hparams.n_mel_channels
+        symbols, durations_float, durations_int = [], [], []
+        with open(base + '.markers', 'r', encoding='utf-8') as f:
+            for line in f:
+                begin, end, int_dur, symbol, _, _ = line.strip().split('\t')
+                symbols.append(self.hparams.symbols.index(symbol))
+                durations_float.append(float(end) - float(begin))
+                durations_int.append(int(int_dur))
+        symbols = torch.IntTensor(symbols)
+        durations_float, durations_int = torch.FloatTensor(durations_float), torch.IntTensor(durations_int)
+        symbols_energy = torch.FloatTensor(self._standardise(_read_floats(base + '.symbols_nrg'), speaker_id, 'energy'))
+        symbols_pitch = torch.FloatTensor(self._standardise(_read_floats(base + '.symbols_f0'), speaker_id, 'pitch'))
+        frames_energy = torch.FloatTensor(_read_floats(base + '.frames_nrg'))
+        frames_pitch = torch.FloatTensor(_read_floats(base + '.frames_f0'))
+        T = mel_spec.size(1)
+        assert len(symbols_energy) == len(symbols) == len(symbols_pitch)
+        assert len(frames_energy) == T == len(frames_pitch) and int(durations_int.sum()) == T
+        return symbols, durations_float, durations_int, symbols_energy, symbols_pitch, frames_energy, frames_pitch, mel_spec, \
+            speaker_id, features_dir, feature_file
+
+    def __len__(self):
+        return len(self.data)
+
+
+def prepare_data_loaders(hparams, num_workers=1, drop_last=True):
+    ''' `data_loader.py:214-243`: train / validation loaders; `DistributedSampler(shuffle=False)` when distributed '''
+    train_set = DaftExprtDataLoader(hparams.training_files, hparams)
+    val_set = DaftExprtDataLoader(hparams.validation_files, hparams)
+    collate_fn = DaftExprtDataCollate(hparams)
+    sampler = DistributedSampler(train_set, shuffle=False) if getattr(hparams, 'multiprocessing_distributed', False) else None
+    train_loader = DataLoader(train_set, num_workers=num_workers, shuffle=(sampler is None), sampler=sampler,
+                              batch_size=hparams.batch_size, pin_memory=True, drop_last=drop_last, collate_fn=collate_fn)
+    val_loader = DataLoader(val_set, num_workers=num_workers, shuffle=False, batch_size=hparams.batch_size, pin_memory=True,
+                            drop_last=False, collate_fn=collate_fn)
+    return train_loader, sampler, val_loader, len(train_set)
 
 
 class DaftExprtDataCollate():
@@ -48,7 +122,7 @@ class DaftExprtDataCollate():
             frames_energy, frames_pitch, mel_specs, output_lengths, speaker_ids, feature_dirs, feature_files
 
 
-class SyntheticUtterances(torch.utils.data.Dataset):
+class SyntheticUtterances(Dataset):
     ''' seeded synthetic utterances with the statistics of SURVEY 8(d): L ~ U{40..160}, integer durations
         U{0..12} trimmed so that T <= t_max, mel ~ clip(N(-5, 2), ln 1e-5, 2), 30 % unvoiced frames. '''
     def __init__(self, hparams, n_items, seed=1234, t_min=1, t_max=1000, force_first_full=True, n_speakers=None,

@@ -25,7 +25,7 @@ import time
 import torch
 import torch.distributed as dist
 
-from daft_exprt.data_loader import DaftExprtDataCollate, SyntheticUtterances
+from daft_exprt.data_loader import DaftExprtDataCollate, SyntheticUtterances, prepare_data_loaders
 from daft_exprt.hparams import HyperParams
 from daft_exprt.loss import DaftExprtLoss, KEYS
 from daft_exprt.model import DaftExprt
@@ -143,7 +143,7 @@ def _loaders(hparams, rank, world):
     ''' training batches: on-disk features when `training_files` exists, else the seeded synthetic utterances '''
     collate = DaftExprtDataCollate(hparams)
     if os.path.isfile(str(hparams.training_files)):
-        raise NotImplementedError('on-disk feature reader: SURVEY 8(f) row 1 (next round); use synthetic data')
+        return prepare_data_loaders(hparams, num_workers=8)[0]
     n_items = getattr(hparams, 'synthetic_items', hparams.batch_size * hparams.accumulation_steps * world * 8)
     ds = SyntheticUtterances(hparams, n_items, seed=hparams.seed, force_first_full=False)
     idx = list(range(rank, n_items, world))   # DistributedSampler(shuffle=False) striding (data_loader.py:232)
