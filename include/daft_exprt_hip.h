@@ -57,6 +57,17 @@ int dx_conv1d(const void* x, int x_dtype, long ldx, const void* w_packed, int w_
               void* y, int y_dtype, long ldy, const void* relu_gate, int gate_dtype, const int64_t* mask_lengths,
               const int64_t* skip_lengths, int B, int N, int Cin, int Cout, int taps, int flags, void* stream);
 
+/* dx_conv1d with Cout = 128 and the following LayerNorm fused into its epilogue (a 128-row tile holds complete rows):
+ *   s = dropout_pre(conv(x) + bias) + residual;  y = LN(s) * gamma + beta;  y = film[b,:128] * y + film[b,128:];
+ *   y = 0 where n >= lengths[b]
+ * i.e. the attention out-projection + Dropout + residual + LayerNorm + mask (model.py:186-191, 259) and the second FF conv
+ * + Dropout + residual + LayerNorm + FiLM + mask (model.py:226-235, 262) in one launch.  Outputs: y fp32, y_lp optional
+ * bf16 copy, s_out / mean / rstd for dx_layernorm_bwd (NULL at inference).  lengths also drives the padding early-out. */
+int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const float* bias,
+                 const float* residual, const float* gamma, const float* beta, const float* film, long ldf,
+                 const int64_t* lengths, float* y, void* y_lp, float* s_out, float* mean, float* rstd, int B, int N,
+                 int Cin, int taps, float p_pre, uint64_t seed_pre, void* stream);
+
 /* Pack an fp32 (Cout, Cin, taps) PyTorch conv / (Cout, Cin) linear weight for dx_conv1d.
  *   transpose_flip = 0: out[tap][co][ci] = w[co][ci][tap]                (forward operand)
  *   transpose_flip = 1: out[tap][ci][co] = w[co][ci][taps-1-tap]         (data-gradient operand) */

@@ -15,11 +15,19 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, NTHREADS = 256;
+constexpr int BN = 128, BK = 32, NTHREADS = 256;
 
 template <typename TC> struct Pad;
 template <> struct Pad<bf16_t> { static constexpr int value = 8; };
 template <> struct Pad<float> { static constexpr int value = 4; };
+
+// LayerNorm epilogue (Cout == 128: a tile holds complete rows): s = dropout(conv) + residual; y = LN(s) [* FiLM] [masked]
+struct LNEpi {
+  const float* gamma; const float* beta; const float* residual; const float* film; long ldf;
+  float* y; void* y_lp; float* s_out; float* mean; float* rstd;
+  float p_pre; uint64_t seed_pre;
+  int enabled;
+};
 
 struct ConvArgs {
   const void* x; long ldx;
@@ -29,6 +37,7 @@ struct ConvArgs {
   const int64_t* mask_len;
   const int64_t* skip_len;
   int N, Cin, Cout, flags, B;
+  LNEpi ln;
 };
 
 template <typename T, int V> struct VecN;
@@ -80,8 +89,11 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
 #ifndef DX_WGRAD_WPS
 #define DX_WGRAD_WPS 2
 #endif
-template <typename TA, typename TC, typename TO, typename TG, int TAPS>
+// MI = 32-row MFMA tiles per wave along the position axis: 2 -> 128-row workgroup tile; 1 -> 64-row tile, used when
+// Cout <= 128 (one channel tile): twice the workgroups for the GEMMs whose grid would otherwise under-fill 256 CUs.
+template <typename TA, typename TC, typename TO, typename TG, int TAPS, int MI>
 __global__ __launch_bounds__(NTHREADS, DX_CONV_WPS) void conv_gemm_kernel(ConvArgs p) {
+  constexpr int BM = 64 * MI;
   constexpr int HALO = TAPS / 2;
   constexpr int AROWS = BM + TAPS - 1;
   constexpr int LDS_K = BK + Pad<TC>::value;
@@ -118,6 +130,19 @@ __global__ __launch_bounds__(NTHREADS, DX_CONV_WPS) void conv_gemm_kernel(ConvAr
   // padding early-out: a tile that starts past length + conv halo cannot reach a valid output -> zeros, no MFMA
   if (p.skip_len && n0 >= (int)p.skip_len[b] + 2) {
     if (accum) return;
+    if (p.ln.enabled) {
+      float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int c = tid; c < BM * (BN / 8); c += NTHREADS) {
+        const int n = n0 + (c >> 4), cl = (c & 15) * 8;
+        if (n >= N) continue;
+        const size_t off = ((size_t)b * N + n) * BN + cl;
+        store8<float>(p.ln.y + off, z);
+        if (p.ln.y_lp) store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + off, z);
+        if (p.ln.s_out) store8<float>(p.ln.s_out + off, z);
+        if (p.ln.mean && cl == 0) { p.ln.mean[(size_t)b * N + n] = 0.f; p.ln.rstd[(size_t)b * N + n] = 0.f; }
+      }
+      return;
+    }
     if (vec_out) {
       float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       for (int c = tid; c < BM * (BN / 8); c += NTHREADS) {
@@ -133,9 +158,9 @@ __global__ __launch_bounds__(NTHREADS, DX_CONV_WPS) void conv_gemm_kernel(ConvAr
     return;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -187,15 +212,15 @@ __global__ __launch_bounds__(NTHREADS, DX_CONV_WPS) void conv_gemm_kernel(ConvAr
     for (int tap = 0; tap < TAPS; ++tap) {
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ++ks) {
-        frag_t a[2], bf[2];
+        frag_t a[MI], bf[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-          a[i] = *reinterpret_cast<const frag_t*>(&As[(wm * 64 + i * 32 + l31 + tap) * LDS_K + ks * 16 + g * 8]);
+        for (int i = 0; i < MI; ++i)
+          a[i] = *reinterpret_cast<const frag_t*>(&As[(wm * 32 * MI + i * 32 + l31 + tap) * LDS_K + ks * 16 + g * 8]);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           bf[j] = *reinterpret_cast<const frag_t*>(&Ws[(tap * BN + wn * 64 + j * 32 + l31) * LDS_K + ks * 16 + g * 8]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) dx_mma(acc[i][j], a[i], bf[j]);
       }
@@ -210,7 +235,7 @@ __global__ __launch_bounds__(NTHREADS, DX_CONV_WPS) void conv_gemm_kernel(ConvAr
   // ---- epilogue
   if (vec_out) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
       // phase 1: bias + ReLU in the MFMA layout, accumulators -> LDS stage (64 rows x 128 channels, fp32)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -228,12 +253,55 @@ __global__ __launch_bounds__(NTHREADS, DX_CONV_WPS) void conv_gemm_kernel(ConvAr
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
         const int sr = (tid >> 4) + pass * 16;                     // stage row 0..63
-        const int n = n0 + (sr >> 5) * 64 + i * 32 + (sr & 31), cl = (tid & 15) * 8, co = co0 + cl;
+        const int n = n0 + (sr >> 5) * 32 * MI + i * 32 + (sr & 31), cl = (tid & 15) * 8, co = co0 + cl;
         if (n < N && co < Cout) {
           float v[8];
           const f32x4 lo = *reinterpret_cast<const f32x4*>(&stage[sr * STG_LD + cl]);
           const f32x4 hi = *reinterpret_cast<const f32x4*>(&stage[sr * STG_LD + cl + 4]);
           v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+          if (p.ln.enabled) {   // fused LayerNorm: 16 lanes hold one complete 128-channel row
+            const size_t rowg = (size_t)b * N + n, offl = rowg * BN + cl;
+            if (p.ln.p_pre > 0.f) {
+              const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(p.ln.seed_pre, 0);
+              const float sc = 1.f / (1.f - p.ln.p_pre);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = dx_keep(key, (uint32_t)rowg * BN + cl + e, th) ? v[e] * sc : 0.f;
+            }
+            {
+              const f32x8 r = raw_load8<float>(p.ln.residual + offl);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += r[e];
+            }
+            if (p.ln.s_out) store8<float>(p.ln.s_out + offl, v);
+            float sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += v[e];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            const float mean = sum * (1.f / BN);
+            float sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; sq += d * d; }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sq += __shfl_xor(sq, o, 64);
+            const float rstd = rsqrtf(sq * (1.f / BN) + 1e-5f);
+            if (p.ln.mean && cl == 0) { p.ln.mean[rowg] = mean; p.ln.rstd[rowg] = rstd; }
+            const f32x8 gm = raw_load8<float>(p.ln.gamma + cl), bt = raw_load8<float>(p.ln.beta + cl);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * gm[e] + bt[e];
+            if (p.ln.film) {
+              const f32x8 fg = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + cl), fb = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + BN + cl);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = fg[e] * v[e] + fb[e];
+            }
+            if (n >= len) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            store8<float>(p.ln.y + offl, v);
+            if (p.ln.y_lp) store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + offl, v);
+            continue;
+          }
           const size_t off = ((size_t)b * N + n) * p.ldy + co;
           if (G) {
             const typename VecN<TG, 8>::type gv = raw_load8<TG>(G + off);
@@ -263,10 +331,10 @@ __global__ __launch_bounds__(NTHREADS, DX_CONV_WPS) void conv_gemm_kernel(ConvAr
     if (co >= Cout) continue;
     const float bv = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wm * 64 + i * 32 + dx_acc_row(r, g);
+        const int n = n0 + wm * 32 * MI + i * 32 + dx_acc_row(r, g);
         if (n >= N) continue;
         float v = acc[i][j][r] + bv;
         if (relu) v = fmaxf(v, 0.f);
@@ -282,12 +350,14 @@ __global__ __launch_bounds__(NTHREADS, DX_CONV_WPS) void conv_gemm_kernel(ConvAr
 
 template <typename TA, typename TC, typename TO, typename TG>
 int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
-  const long ptiles = (long)dx_cdiv(a.N, BM) * B;
-  dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * dx_cdiv(a.Cout, BN))), block(NTHREADS);
-  if (taps == 1)
-    hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1>), grid, block, 0, s, a);
-  else
-    hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3>), grid, block, 0, s, a);
+  const int ztiles = dx_cdiv(a.Cout, BN);
+  const int mi = ztiles == 1 ? 1 : 2;                       // 64-row tiles for the narrow-output GEMMs
+  const long ptiles = (long)dx_cdiv(a.N, 64 * mi) * B;
+  dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * ztiles)), block(NTHREADS);
+  if (taps == 1 && mi == 1) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 1>), grid, block, 0, s, a);
+  else if (taps == 1) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 2>), grid, block, 0, s, a);
+  else if (mi == 1) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 1>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 2>), grid, block, 0, s, a);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
@@ -546,7 +616,7 @@ extern "C" int dx_conv1d(const void* x, int x_dtype, long ldx, const void* w_pac
   DX_REQUIRE(B > 0 && N > 0 && Cin > 0 && Cout > 0, DX_ERR_SHAPE, "dx_conv1d: empty shape B=%d N=%d Cin=%d Cout=%d", B, N, Cin, Cout);
   DX_REQUIRE(Cin % 8 == 0 && ldx % 8 == 0, DX_ERR_SHAPE, "dx_conv1d: Cin (%d) and ldx (%ld) must be multiples of 8", Cin, ldx);
   DX_REQUIRE(taps == 1 || taps == 3, DX_ERR_UNSUPPORTED, "dx_conv1d: taps=%d (only 1 and 3)", taps);
-  ConvArgs a{x, ldx, w_packed, bias, y, ldy, relu_gate, mask_lengths, skip_lengths, N, Cin, Cout, flags, B};
+  ConvArgs a{x, ldx, w_packed, bias, y, ldy, relu_gate, mask_lengths, skip_lengths, N, Cin, Cout, flags, B, LNEpi{}};
   hipStream_t s = (hipStream_t)stream;
   const int gd = relu_gate ? gate_dtype : y_dtype;
   if (w_dtype == DX_BF16) {
@@ -610,5 +680,25 @@ extern "C" int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const vo
     if (dy_dtype == DX_F32 && x_dtype == DX_F32) return launch_wgrad<float, float, float>(a, taps, s);
   }
   dx_set_error("dx_conv1d_wgrad: unsupported dtype combination dy=%d x=%d compute=%d", dy_dtype, x_dtype, compute_dtype);
+  return DX_ERR_DTYPE;
+}
+
+extern "C" int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const float* bias,
+                            const float* residual, const float* gamma, const float* beta, const float* film, long ldf,
+                            const int64_t* lengths, float* y, void* y_lp, float* s_out, float* mean, float* rstd, int B, int N,
+                            int Cin, int taps, float p_pre, uint64_t seed_pre, void* stream) {
+  DX_REQUIRE(x && w_packed && residual && gamma && beta && y, DX_ERR_ARG, "dx_conv1d_ln: null pointer");
+  DX_REQUIRE(B > 0 && N > 0 && Cin > 0, DX_ERR_SHAPE, "dx_conv1d_ln: empty shape");
+  DX_REQUIRE(Cin % 8 == 0 && ldx % 8 == 0, DX_ERR_SHAPE, "dx_conv1d_ln: Cin (%d) and ldx (%ld) must be multiples of 8", Cin, ldx);
+  DX_REQUIRE(taps == 1 || taps == 3, DX_ERR_UNSUPPORTED, "dx_conv1d_ln: taps=%d (only 1 and 3)", taps);
+  DX_REQUIRE((mean == nullptr) == (rstd == nullptr), DX_ERR_ARG, "dx_conv1d_ln: mean and rstd come together");
+  DX_REQUIRE(p_pre >= 0.f && p_pre < 1.f, DX_ERR_ARG, "dx_conv1d_ln: dropout p out of [0,1)");
+  ConvArgs a{x, ldx, w_packed, bias, nullptr, BN, nullptr, lengths, lengths, N, Cin, BN, 0, B,
+             LNEpi{gamma, beta, residual, film, ldf, y, y_lp, s_out, mean, rstd, p_pre, seed_pre, 1}};
+  hipStream_t s = (hipStream_t)stream;
+  if (w_dtype == DX_BF16 && x_dtype == DX_BF16) return launch_taps<bf16_t, bf16_t, float, float>(a, B, taps, s);
+  if (w_dtype == DX_BF16 && x_dtype == DX_F32) return launch_taps<float, bf16_t, float, float>(a, B, taps, s);
+  if (w_dtype == DX_F32 && x_dtype == DX_F32) return launch_taps<float, float, float, float>(a, B, taps, s);
+  dx_set_error("dx_conv1d_ln: unsupported dtype combination x=%d w=%d", x_dtype, w_dtype);
   return DX_ERR_DTYPE;
 }

@@ -318,20 +318,18 @@ class DaftExprt(nn.Module):
         qkv = ops.conv1d(xin, W[f'{a_pre}.multi_head_attention.in_proj_weight'], P[f'{a_pre}.multi_head_attention.in_proj_bias'],
                          out_dtype=cd, skip_lengths=lengths)
         o, lse = ops.attention_fwd(qkv, lengths, cfg['attn_nb_heads'], p_attn, seeds[0], need_lse=save)
-        proj = ops.conv1d(o, W[f'{a_pre}.multi_head_attention.out_proj.weight'], P[f'{a_pre}.multi_head_attention.out_proj.bias'],
-                          out_dtype=torch.float32, skip_lengths=lengths)
-        r = ops.layernorm_fwd(proj, P[f'{a_pre}.layer_norm.weight'], P[f'{a_pre}.layer_norm.bias'], residual=x, lengths=lengths,
-                              save=save, save_s=save, p_pre=p_attn, seed_pre=seeds[1], skip_lengths=lengths, lp_copy=lp)
-        (a, a_lp, s1, mean1, rstd1) = r if lp else (r[0], None) + tuple(r[1:])
+        # out-projection + Dropout + residual + LayerNorm + mask in ONE launch (the GEMM tile holds complete 128-ch rows)
+        a, a_lp, s1, mean1, rstd1 = ops.conv1d_ln(o, W[f'{a_pre}.multi_head_attention.out_proj.weight'],
+                                                  P[f'{a_pre}.multi_head_attention.out_proj.bias'], x, P[f'{a_pre}.layer_norm.weight'],
+                                                  P[f'{a_pre}.layer_norm.bias'], lengths, save=save, p_pre=p_attn, seed_pre=seeds[1],
+                                                  lp_copy=lp)
         ain = a_lp if lp else a
         h = ops.conv1d(ain, W[f'{f_pre}.convs.0.conv.weight'], P[f'{f_pre}.convs.0.conv.bias'], out_dtype=cd, relu=True,
                        skip_lengths=lengths)
-        z = ops.conv1d(h, W[f'{f_pre}.convs.2.conv.weight'], P[f'{f_pre}.convs.2.conv.bias'], out_dtype=torch.float32,
-                       skip_lengths=lengths)
-        r = ops.layernorm_fwd(z, P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'], residual=a, film=film,
-                              lengths=lengths, save=save, save_s=save, p_pre=p_conv, seed_pre=seeds[2], skip_lengths=lengths,
-                              lp_copy=lp)
-        (u, u_lp, s2, mean2, rstd2) = r if lp else (r[0], None) + tuple(r[1:])
+        # second FF conv + Dropout + residual + LayerNorm + FiLM + mask in ONE launch
+        u, u_lp, s2, mean2, rstd2 = ops.conv1d_ln(h, W[f'{f_pre}.convs.2.conv.weight'], P[f'{f_pre}.convs.2.conv.bias'], a,
+                                                  P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'], lengths, film=film,
+                                                  save=save, p_pre=p_conv, seed_pre=seeds[2], lp_copy=lp)
         if save:
             s.pre, s.cfg, s.x, s.film, s.lengths = pre, cfg, xin, film, lengths
             s.qkv, s.o, s.lse, s.s1, s.mean1, s.rstd1, s.a, s.h, s.s2, s.mean2, s.rstd2 = qkv, o, lse, s1, mean1, rstd1, ain, h, s2, mean2, rstd2

@@ -75,6 +75,26 @@ def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, m
     return out
 
 
+def conv1d_ln(x, w_packed, bias, residual, gamma, beta, lengths, film=None, save=False, p_pre=0., seed_pre=0, lp_copy=False):
+    ''' conv / linear to 128 channels with the following LayerNorm (+dropout, residual, FiLM, mask) fused into the epilogue.
+        Returns (y, y_lp, s_out, mean, rstd) '''
+    B, N, Cin = x.shape
+    taps, Cout, _ = w_packed.shape
+    assert Cout == 128 and x.stride(2) == 1 and residual.is_contiguous()
+    dev = x.device
+    y = torch.empty((B, N, 128), dtype=torch.float32, device=dev)
+    y_lp = torch.empty((B, N, 128), dtype=torch.bfloat16, device=dev) if lp_copy else None
+    s_out = torch.empty((B, N, 128), dtype=torch.float32, device=dev) if save else None
+    mean = torch.empty(B * N, dtype=torch.float32, device=dev) if save else None
+    rstd = torch.empty(B * N, dtype=torch.float32, device=dev) if save else None
+    with _Probe('conv_gemm', 2. * B * N * Cin * Cout * taps, N):
+        H.check(H.lib().dx_conv1d_ln(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(bias), H.ptr(residual),
+                                     H.ptr(gamma), H.ptr(beta), H.ptr(film), film.stride(0) if film is not None else 0, H.ptr(lengths),
+                                     H.ptr(y), H.ptr(y_lp), H.ptr(s_out), H.ptr(mean), H.ptr(rstd), B, N, Cin, taps, float(p_pre),
+                                     int(seed_pre), H.stream()))
+    return y, y_lp, s_out, mean, rstd
+
+
 def pack_table(entries, device):
     ''' entries: [(w fp32 tensor, out tensor, transpose_flip)] -> (device descriptor table, n, total_elems) for
         pack_weights_batched (one launch for every GEMM weight of the model) '''
