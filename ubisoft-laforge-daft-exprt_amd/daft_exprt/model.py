@@ -491,7 +491,8 @@ class DaftExprt(nn.Module):
         lp = cd == torch.bfloat16
         ds2, dz = ops.layernorm_bwd(du, s.s2, s.mean2, s.rstd2, P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'],
                                     G[f'{f_pre}.layer_norm.weight'], G[f'{f_pre}.layer_norm.bias'], film=s.film, dfilm=dfilm,
-                                    lengths=s.lengths, p_pre=s.p_conv, seed_pre=s.seeds[2], skip_lengths=s.lengths, lp_only=lp)
+                                    lengths=s.lengths, p_pre=s.p_conv, seed_pre=s.seeds[2], skip_lengths=s.lengths, lp_only=lp,
+                                    separate=True)   # dz is read by the side-stream wgrad while `da` is accumulated in place
         da = ds2
         self._wgrad(dz, s.h, G[f'{f_pre}.convs.2.conv.weight'], G[f'{f_pre}.convs.2.conv.bias'], s.lengths)
         dh = ops.conv1d(dz, W[f'T:{f_pre}.convs.2.conv.weight'], None, out_dtype=cd, relu_gate=s.h, skip_lengths=s.lengths)
@@ -499,7 +500,7 @@ class DaftExprt(nn.Module):
         ops.conv1d(dh, W[f'T:{f_pre}.convs.0.conv.weight'], None, out=da, accumulate=True, skip_lengths=s.lengths)
         ds1, dproj = ops.layernorm_bwd(da, s.s1, s.mean1, s.rstd1, P[f'{a_pre}.layer_norm.weight'], P[f'{a_pre}.layer_norm.bias'],
                                        G[f'{a_pre}.layer_norm.weight'], G[f'{a_pre}.layer_norm.bias'], lengths=s.lengths,
-                                       p_pre=s.p_attn, seed_pre=s.seeds[1], skip_lengths=s.lengths, lp_only=lp)
+                                       p_pre=s.p_attn, seed_pre=s.seeds[1], skip_lengths=s.lengths, lp_only=lp, separate=True)
         dx = ds1
         mha = f'{a_pre}.multi_head_attention'
         self._wgrad(dproj, s.o, G[f'{mha}.out_proj.weight'], G[f'{mha}.out_proj.bias'], s.lengths)

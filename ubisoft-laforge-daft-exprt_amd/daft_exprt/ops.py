@@ -150,12 +150,14 @@ def layernorm_fwd(x, gamma, beta, residual=None, film=None, lengths=None, out_dt
 
 
 def layernorm_bwd(dy, s_in, mean, rstd, gamma, beta, dgamma, dbeta, film=None, dfilm=None, lengths=None,
-                  d_dtype=torch.float32, p_pre=0., seed_pre=0, p_post=0., seed_post=0, relu_input=False, skip_lengths=None, lp_only=False):
+                  d_dtype=torch.float32, p_pre=0., seed_pre=0, p_post=0., seed_post=0, relu_input=False, skip_lengths=None, lp_only=False, separate=False):
     ''' returns (ds, dx_pre); dx_pre is ds itself when there is no pre-dropout. dgamma/dbeta/dfilm accumulate.
-        lp_only: dx_pre is returned as a bf16 tensor only (it feeds MFMA operands exclusively). '''
+        lp_only: dx_pre is returned as a bf16 tensor only (it feeds MFMA operands exclusively).
+        separate: dx_pre gets its own buffer even without pre-dropout (the caller accumulates into ds in place while
+        another stream still reads dx_pre). '''
     B, N, C = dy.shape
     ds = torch.empty((B, N, C), dtype=d_dtype, device=dy.device)
-    dx_pre = torch.empty_like(ds) if (p_pre > 0. and not lp_only) else None
+    dx_pre = torch.empty_like(ds) if ((p_pre > 0. or separate) and not lp_only) else None
     dx_lp = torch.empty((B, N, C), dtype=torch.bfloat16, device=dy.device) if lp_only else None
     ldf = film.stride(0) if film is not None else 0
     lddf = dfilm.stride(0) if dfilm is not None else 0
