@@ -112,7 +112,10 @@ int dx_layernorm_bwd(const void* dy, int dy_dtype, const void* s_in, int s_dtype
                      const int64_t* lengths, const int64_t* skip_lengths, void* ds, void* dx_pre,
                      void* dx_pre_lp /* optional bf16 copy of dx_pre (of ds when p_pre == 0) */, int d_dtype,
                      float* dgamma, float* dbeta, float* dfilm, long lddf, int B, int N, int C, float p_pre, uint64_t seed_pre,
-                     float p_post, uint64_t seed_post, int relu_input, void* stream);
+                     float p_post, uint64_t seed_post, int relu_input,
+                     float* ws /* NULL: fp32 atomics; else dx_layernorm_bwd_ws_floats(B,N,C) floats: deterministic two-stage reduction */,
+                     void* stream);
+long dx_layernorm_bwd_ws_floats(int B, int N, int C);
 
 /* ---- K4: multi-head self-attention with key-padding mask, flash-style on MFMA (d_head in {16, 64}).
  * Replaces nn.MultiheadAttention's core (model.py:182-186): S = (q/sqrt(d)) k^T, pad keys -> -inf, softmax,

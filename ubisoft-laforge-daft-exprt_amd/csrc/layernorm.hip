@@ -165,6 +165,7 @@ struct LNBwdArgs {
   float p_pre, p_post; uint64_t seed_pre, seed_post;
   int relu_input;            // s = relu(conv): the returned ds is additionally gated by (s > 0)
   int debug;                 // DX_LN_DEBUG: 1 = skip the final atomics (ablation only)
+  float* ws;                 // optional (B * chunks, 4, C) partial sums -> finished by ln_bwd_finish_kernel (no atomics)
 };
 
 // grid = (ceil(N / rows_per_block), B); 4 waves per block, wave w handles rows w, w+4, ... of the slab
@@ -295,9 +296,41 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
   for (int idx = threadIdx.x; idx < 4 * C && !(a.debug & 1); idx += 256) {
     const int which = idx / C, c = idx - which * C;
     const float t = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+    if (a.ws) { a.ws[((long)(b * gridDim.x + blockIdx.x) * 4 + which) * C + c] = t; continue; }
     if (which == 0) atomicAdd(a.dgamma + c, t);
     else if (which == 1) atomicAdd(a.dbeta + c, t);
     else if (a.dfilm) atomicAdd(a.dfilm + (long)b * a.lddf + (which == 3 ? C : 0) + c, t);
+  }
+}
+
+// Finishes the per-channel reductions of ln_bwd_kernel from its per-workgroup partial sums (deterministic, no atomics).
+// blocks [0, nA): dgamma / dbeta over all (utterance, chunk) partials; blocks [nA, ...): dfilm[b] over the chunks of b.
+__global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* __restrict__ ws, float* dgamma, float* dbeta, float* dfilm,
+                                                            long lddf, int B, int chunks, int C, int nA) {
+  __shared__ float red[4][64];
+  if ((int)blockIdx.x < nA) {
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;   // col in [0, 2C): gamma | beta
+    float acc = 0.f;
+    if (col < 2 * C) {
+      const int which = col / C, c = col - which * C;
+      const int total = B * chunks;
+      for (int p = grp; p < total; p += 4) acc += ws[((long)p * 4 + which) * C + c];
+    }
+    red[grp][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (grp == 0 && col < 2 * C) {
+      const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+      if (col < C) dgamma[col] += t; else dbeta[col - C] += t;
+    }
+  } else if (dfilm) {
+    const int per_b = (2 * C + 255) / 256;
+    const int r = blockIdx.x - nA, b = r / per_b, col = (r % per_b) * 256 + threadIdx.x;
+    if (col < 2 * C) {
+      const int which = 2 + col / C, c = col % C;
+      float acc = 0.f;
+      for (int k = 0; k < chunks; ++k) acc += ws[((long)(b * chunks + k) * 4 + which) * C + c];
+      dfilm[(long)b * lddf + col] += acc;
+    }
   }
 }
 
@@ -321,6 +354,11 @@ int launch_bwd(const LNBwdArgs& a, int C, hipStream_t s) {
     case 256: hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 256>), grid, block, 0, s, a); break;
     case 1024: hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 1024>), grid, block, 0, s, a); break;
     default: dx_set_error("dx_layernorm_bwd: C=%d unsupported (128, 256, 1024)", C); return DX_ERR_UNSUPPORTED;
+  }
+  if (a.ws) {
+    const int chunks = dx_cdiv(a.N, a.rows_per_block), nA = dx_cdiv(2 * C, 64);
+    const int nB = a.dfilm ? a.B * dx_cdiv(2 * C, 256) : 0;
+    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3(nA + nB), dim3(256), 0, s, a.ws, a.dgamma, a.dbeta, a.dfilm, a.lddf, a.B, chunks, C, nA);
   }
   DX_LAUNCH_CHECK();
   return DX_OK;
@@ -350,17 +388,17 @@ extern "C" int dx_layernorm_bwd(const void* dy, int dy_dtype, const void* s_in, 
                                 const float* rstd, const float* gamma, const float* beta, const float* film, long ldf,
                                 const int64_t* lengths, const int64_t* skip_lengths, void* ds, void* dx_pre, void* dx_pre_lp,
                                 int d_dtype, float* dgamma, float* dbeta, float* dfilm, long lddf, int B, int N, int C, float p_pre, uint64_t seed_pre,
-                                float p_post, uint64_t seed_post, int relu_input, void* stream) {
+                                float p_post, uint64_t seed_post, int relu_input, float* ws, void* stream) {
   DX_REQUIRE(dy && s_in && mean && rstd && gamma && beta && ds && dgamma && dbeta, DX_ERR_ARG, "dx_layernorm_bwd: null pointer");
   DX_REQUIRE(B > 0 && N > 0, DX_ERR_SHAPE, "dx_layernorm_bwd: empty shape");
   DX_REQUIRE((film == nullptr) == (dfilm == nullptr), DX_ERR_ARG, "dx_layernorm_bwd: film and dfilm come together");
   // enough workgroups to fill 256 CUs, few enough that the per-channel atomics stay cheap
   static int dbg = getenv("DX_LN_DEBUG") ? atoi(getenv("DX_LN_DEBUG")) : 0;
-  static int maxblk = getenv("DX_LN_BLOCKS") ? atoi(getenv("DX_LN_BLOCKS")) : 768;
+  const int maxblk = 768;   // keep in sync with dx_layernorm_bwd_ws_floats
   int rpb = 32;
   while (rpb < 1024 && (long)dx_cdiv(N, rpb) * B > maxblk) rpb *= 2;
   LNBwdArgs a{dy, s_in, mean, rstd, gamma, beta, film, ldf, lengths, skip_lengths, ds, dx_pre, dx_pre_lp, dgamma, dbeta, dfilm, lddf, N, B, rpb,
-              p_pre, p_post, seed_pre, seed_post, relu_input, dbg};
+              p_pre, p_post, seed_pre, seed_post, relu_input, dbg, ws};
   hipStream_t s = (hipStream_t)stream;
   if (s_dtype == DX_F32 && dy_dtype == DX_F32 && d_dtype == DX_F32) return launch_bwd<float, float, float>(a, C, s);
   if (s_dtype == DX_BF16 && dy_dtype == DX_BF16 && d_dtype == DX_BF16) return launch_bwd<bf16_t, bf16_t, bf16_t>(a, C, s);
@@ -368,4 +406,10 @@ extern "C" int dx_layernorm_bwd(const void* dy, int dy_dtype, const void* s_in, 
   if (s_dtype == DX_F32 && dy_dtype == DX_BF16 && d_dtype == DX_F32) return launch_bwd<float, bf16_t, float>(a, C, s);
   dx_set_error("dx_layernorm_bwd: unsupported dtypes s=%d dy=%d d=%d", s_dtype, dy_dtype, d_dtype);
   return DX_ERR_DTYPE;
+}
+
+extern "C" long dx_layernorm_bwd_ws_floats(int B, int N, int C) {
+  int rpb = 32;
+  while (rpb < 1024 && (long)dx_cdiv(N, rpb) * B > 768) rpb *= 2;
+  return (long)B * dx_cdiv(N, rpb) * 4 * C;
 }

@@ -87,7 +87,10 @@ __global__ __launch_bounds__(256) void gu_upsample_fwd_kernel(UpArgs a) {
   __shared__ float Wt[LC][TT + 1];
   __shared__ float part[8][TT];
   __shared__ float denom[TT];
+  __shared__ int lrange[2];   // [first, last] phoneme whose Gaussian is not exactly zero on this 32-frame tile
   const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * TT;
+  if (tid == 0) { lrange[0] = 1 << 30; lrange[1] = -1; }
+  __syncthreads();
   const int tt = tid & 31, lg = tid >> 5;          // phase 1/2: (frame, phoneme-group)
   const int L = a.L, T = a.T;
   const int len = (int)a.in_len[b];
@@ -96,11 +99,15 @@ __global__ __launch_bounds__(256) void gu_upsample_fwd_kernel(UpArgs a) {
   const float* sg = a.ranges + (long)b * L;
   // phase 1: denominators
   float s = 0.f;
+  int lo = 1 << 30, hi = -1;
   for (int l = lg; l < len; l += 8) {
     const float sd = sg[l], dlt = tc - mu[l];
-    s += expf(-(dlt * dlt) / (2.f * sd * sd) - logf(sd) - LOG_SQRT_2PI);
+    const float pv = expf(-(dlt * dlt) / (2.f * sd * sd) - logf(sd) - LOG_SQRT_2PI);
+    s += pv;
+    if (pv != 0.f) { lo = min(lo, l); hi = max(hi, l); }   // far-away Gaussians underflow to exactly 0 in fp32
   }
   part[lg][tt] = s;
+  if (hi >= 0) { atomicMin(&lrange[0], lo); atomicMax(&lrange[1], hi); }
   __syncthreads();
   if (tid < TT) {
     float d = 0.f;
@@ -126,8 +133,9 @@ __global__ __launch_bounds__(256) void gu_upsample_fwd_kernel(UpArgs a) {
       if (t0 + tt < T) a.weights[((long)b * L + l) * T + t0 + tt] = w;
     }
     __syncthreads();
-    const int lmax = min(min(L, l0 + LC), len);
-    for (int l = l0; l < lmax; ++l) {
+    // weights outside [lrange] are exactly zero on this tile: the contraction skips them (exact, ~10x less work)
+    const int lmax = min(min(min(L, l0 + LC), len), lrange[1] + 1);
+    for (int l = max(l0, lrange[0]); l < lmax; ++l) {
       const float w = Wt[l - l0][ft];
       const f32x4* xr = reinterpret_cast<const f32x4*>(a.xp + ((long)b * L + l) * D + cg * 16);
 #pragma unroll
@@ -165,9 +173,20 @@ struct UpBwd1Args {
 __global__ __launch_bounds__(256) void gu_upsample_bwd1_kernel(UpBwd1Args a) {
   __shared__ float G[TT][D + 1];
   __shared__ float part[8][TT];
+  __shared__ int lrange[2];
   const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * TT;
   const int L = a.L, T = a.T, len = (int)a.in_len[b];
   const int tvalid = a.out_len ? (int)a.out_len[b] : T;
+  if (tid == 0) { lrange[0] = 1 << 30; lrange[1] = -1; }
+  __syncthreads();
+  {   // phonemes with a non-zero weight on this tile (dw is only ever used multiplied by w, see bwd2)
+    const int tt = tid & 31, lg = tid >> 5;
+    int lo = 1 << 30, hi = -1;
+    if (t0 + tt < T)
+      for (int l = lg; l < len; l += 8)
+        if (a.weights[((long)b * L + l) * T + t0 + tt] != 0.f) { lo = min(lo, l); hi = max(hi, l); }
+    if (hi >= 0) { atomicMin(&lrange[0], lo); atomicMax(&lrange[1], hi); }
+  }
   for (int i = tid; i < TT * D; i += 256) {
     const int r = i / D, c = i - r * D, t = t0 + r;
     G[r][c] = (t < T && t < tvalid) ? a.g[((long)b * T + t) * D + c] : 0.f;
@@ -175,9 +194,10 @@ __global__ __launch_bounds__(256) void gu_upsample_bwd1_kernel(UpBwd1Args a) {
   __syncthreads();
   const int tt = tid & 31, lg = tid >> 5;
   float dacc = 0.f;
-  for (int l = lg; l < L; l += 8) {
+  const int lfirst = lrange[0], llast = min(lrange[1], len - 1);
+  for (int l = lfirst + lg; l <= llast; l += 8) {
     float dot = 0.f;
-    if (l < len) {
+    {
       const float* xr = a.xp + ((long)b * L + l) * D;
       for (int c = 0; c < D; ++c) dot = fmaf(G[tt][c], xr[c], dot);
     }
@@ -225,11 +245,25 @@ __global__ __launch_bounds__(128) void gu_upsample_bwd2_kernel(UpBwd2Args a) {
   const float* dwr = a.dw + row * T;
   const float* ds = a.dsum + (long)b * T;
   const float mu = a.means[row], sd = a.ranges[row];
+  // frames on which this phoneme's weight is not exactly zero (a band around its Gaussian mean)
+  __shared__ int trange[2];
+  if (c == 0) { trange[0] = 1 << 30; trange[1] = -1; }
+  __syncthreads();
+  {
+    int lo = 1 << 30, hi = -1;
+    for (int t = c; t < tvalid; t += 128) if (w[t] != 0.f) { lo = min(lo, t); hi = max(hi, t); }
+    if (hi >= 0) { atomicMin(&trange[0], lo); atomicMax(&trange[1], hi); }
+  }
+  __syncthreads();
+  const int tfirst = trange[0], tlast = trange[1];
   float acc = 0.f, dsig = 0.f;
-  for (int t = 0; t < tvalid; ++t) acc = fmaf(w[t], a.g[((long)b * T + t) * D + c], acc);
-  for (int t = c; t < T; t += 128) {
-    const float dlt = (float)t + 0.5f - mu;
-    dsig += w[t] * (dwr[t] - ds[t]) * (dlt * dlt / (sd * sd * sd) - 1.f / sd);
+  for (int t = tfirst; t <= tlast; ++t) acc = fmaf(w[t], a.g[((long)b * T + t) * D + c], acc);
+  for (int t = tfirst + c; t <= tlast; t += 128) {
+    const float wt = w[t];
+    if (wt != 0.f) {
+      const float dlt = (float)t + 0.5f - mu;
+      dsig += wt * (dwr[t] - ds[t]) * (dlt * dlt / (sd * sd * sd) - 1.f / sd);
+    }
   }
   dsig = dx_wave_sum(dsig);
   if ((c & 63) == 0) red[c >> 6] = dsig;

@@ -27,7 +27,7 @@ def header_prototypes():
     text = open(HEADER_PATH).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     protos = []
-    for m in re.finditer(r'\b(int|const char\*|size_t|void)\s+(dx_\w+)\s*\(([^;{]*?)\)\s*;', text, flags=re.S):
+    for m in re.finditer(r'\b(int|long|const char\*|size_t|void)\s+(dx_\w+)\s*\(([^;{]*?)\)\s*;', text, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         argtypes = []
         if args and args != 'void':
@@ -38,7 +38,7 @@ def header_prototypes():
                 else:
                     base = a.replace('const ', '').split()[0]
                     argtypes.append(_C[base])
-        restype = {'int': ctypes.c_int, 'const char*': ctypes.c_char_p, 'size_t': ctypes.c_size_t, 'void': None}[ret]
+        restype = {'int': ctypes.c_int, 'long': ctypes.c_long, 'const char*': ctypes.c_char_p, 'size_t': ctypes.c_size_t, 'void': None}[ret]
         protos.append((name, restype, argtypes))
     return protos
 

@@ -7,6 +7,7 @@ import torch
 from daft_exprt import _hip as H
 
 _INF = float('inf')
+DETERMINISTIC_LN = False
 
 # Optional per-kernel timing probe used by bench.py: {family: [(start_event, end_event, padded_flops, N), ...]}.
 # Events are recorded on torch's current stream, which is the stream every kernel is launched on.
@@ -161,10 +162,13 @@ def layernorm_bwd(dy, s_in, mean, rstd, gamma, beta, dgamma, dbeta, film=None, d
     dx_lp = torch.empty((B, N, C), dtype=torch.bfloat16, device=dy.device) if lp_only else None
     ldf = film.stride(0) if film is not None else 0
     lddf = dfilm.stride(0) if dfilm is not None else 0
+    # two-stage (atomic-free, run-to-run deterministic) reduction of dgamma/dbeta/dfilm; measured 7 % slower per step than
+    # the fp32 atomics (one more dependent launch per LayerNorm), so it is opt-in
+    ws = torch.empty(H.lib().dx_layernorm_bwd_ws_floats(B, N, C), dtype=torch.float32, device=dy.device) if DETERMINISTIC_LN else None
     H.check(H.lib().dx_layernorm_bwd(H.ptr(dy), H.dt(dy), H.ptr(s_in), H.dt(s_in), H.ptr(mean), H.ptr(rstd), H.ptr(gamma),
                                      H.ptr(beta), H.ptr(film), ldf, H.ptr(lengths), H.ptr(skip_lengths), H.ptr(ds), H.ptr(dx_pre), H.ptr(dx_lp), H.dt(ds),
                                      H.ptr(dgamma), H.ptr(dbeta), H.ptr(dfilm), lddf, B, N, C, float(p_pre), int(seed_pre),
-                                     float(p_post), int(seed_post), int(relu_input), H.stream()))
+                                     float(p_post), int(seed_post), int(relu_input), H.ptr(ws), H.stream()))
     if lp_only:
         return ds, dx_lp
     return ds, (dx_pre if dx_pre is not None else ds)
