@@ -89,3 +89,27 @@ def bench_ln():
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'ln':
     bench_ln()
+
+
+def bench_convln():
+    dev = torch.device('cuda:0')
+    B, N = 48, 1000
+    lens = torch.randint(250, 1001, (B,), device=dev)
+    lens[0] = N
+    for cin, taps in [(1024, 3), (128, 1)]:
+        x = torch.randn(B, N, cin, device=dev).to(torch.bfloat16)
+        w = torch.randn(128, cin, taps, device=dev) / (cin * taps) ** 0.5
+        wp = ops.pack_conv_weight(w, torch.bfloat16)
+        bias, g, bt = torch.zeros(128, device=dev), torch.ones(128, device=dev), torch.zeros(128, device=dev)
+        res = torch.randn(B, N, 128, device=dev)
+        film = torch.randn(B, 256, device=dev)
+        t_fused = timeit(lambda: ops.conv1d_ln(x, wp, bias, res, g, bt, lens, film=film, save=True, p_pre=0.1, seed_pre=5, lp_copy=True))
+        t_conv = timeit(lambda: ops.conv1d(x, wp, bias, out_dtype=torch.float32, skip_lengths=lens))
+        z = ops.conv1d(x, wp, bias, out_dtype=torch.float32, skip_lengths=lens)
+        t_ln = timeit(lambda: ops.layernorm_fwd(z, g, bt, residual=res, film=film, lengths=lens, save=True, save_s=True, p_pre=0.1, seed_pre=5,
+                                                skip_lengths=lens, lp_copy=True))
+        print(f'conv {cin}->128 k{taps}: fused conv+LN {t_fused * 1e3:6.1f} us | conv {t_conv * 1e3:6.1f} us + LN {t_ln * 1e3:6.1f} us')
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'convln':
+    bench_convln()
