@@ -92,8 +92,11 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
 // MI = 32-row MFMA tiles per wave along the position axis: 2 -> 128-row workgroup tile; 1 -> 64-row tile, used when
 // Cout <= 128 (one channel tile): twice the workgroups for the GEMMs whose grid would otherwise under-fill 256 CUs.
 // BK = channels per K chunk: 32, or 64 for the narrow-output kernels whose long serial K loop is latency-bound.
+#ifndef DX_CONV_WPS_NARROW
+#define DX_CONV_WPS_NARROW 4
+#endif
 template <typename TA, typename TC, typename TO, typename TG, int TAPS, int MI, int BK>
-__global__ __launch_bounds__(NTHREADS, DX_CONV_WPS) void conv_gemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(NTHREADS, MI == 1 ? DX_CONV_WPS_NARROW : DX_CONV_WPS) void conv_gemm_kernel(ConvArgs p) {
   constexpr int BM = 64 * MI, KC = BK / 8;   // KC = 8-element chunks per row of a K chunk
   constexpr int HALO = TAPS / 2;
   constexpr int AROWS = BM + TAPS - 1;
@@ -112,13 +115,18 @@ __global__ __launch_bounds__(NTHREADS, DX_CONV_WPS) void conv_gemm_kernel(ConvAr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, g = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware mapping (workgroup L runs on XCD L % 8): the Cout/128 workgroups that share one activation tile run
-  // back to back on the same XCD, so the tile is fetched from HBM once and re-read from that XCD's L2
+  // XCD-aware, weight-stationary order.  Workgroup L runs on XCD L % 8 (observed dispatch order).  Every workgroup
+  // streams the whole weight slice of its channel tile (taps x 128 x Cin, up to 786 KB) through LDS, so the slice must
+  // stay in that XCD's 4 MB L2 across workgroups: each XCD walks ALL of its position tiles for channel tile 0, then
+  // for channel tile 1, ...  (Measured: no difference vs the channel-tile-fastest order on MI355X -- the kernel is bound
+  // by its LDS->MFMA issue pattern at ~800 TFLOP/s, the known ceiling of a 128x128-tile two-barrier structure -- but this
+  // order keeps the weight working set of an XCD at one slice, which matters once the inner loop gets faster.)
   const int ztiles = dx_cdiv(p.Cout, BN), ptiles = dx_cdiv(p.N, BM);
   const int Lid = blockIdx.x, jj = Lid >> 3;
-  const int pt = (Lid & 7) + 8 * (jj / ztiles);
+  const int per_xcd = (ptiles * p.B + 7) >> 3;         // position tiles owned by one XCD
+  const int pt = (Lid & 7) + 8 * (jj % per_xcd);
   if (pt >= ptiles * p.B) return;
-  const int n0 = (pt % ptiles) * BM, b = pt / ptiles, co0 = (jj % ztiles) * BN;
+  const int n0 = (pt % ptiles) * BM, b = pt / ptiles, co0 = (jj / per_xcd) * BN;
   const int N = p.N, Cin = p.Cin, Cout = p.Cout;
   const TA* X = reinterpret_cast<const TA*>(p.x) + (size_t)b * N * p.ldx;
   const TC* W = reinterpret_cast<const TC*>(p.w);
