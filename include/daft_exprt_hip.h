@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DX_ABI_VERSION 1
+#define DX_ABI_VERSION 2
 
 enum { DX_F32 = 0, DX_BF16 = 1, DX_I64 = 2 };
 enum { DX_OK = 0, DX_ERR_ARG = -1, DX_ERR_SHAPE = -2, DX_ERR_DTYPE = -3, DX_ERR_LAUNCH = -4, DX_ERR_UNSUPPORTED = -5 };
@@ -79,13 +79,18 @@ int dx_pack_conv_weight(const float* w, void* out, int out_dtype, int Cout, int 
 int dx_pack_desc_size(void);
 int dx_pack_conv_weights_batched(const void* descs_dev, int n, long total_elems, int out_dtype, void* stream);
 
-/* Weight / bias gradient of dx_conv1d (and of nn.Linear with taps = 1), accumulated with fp32 atomics into
- * dw (Cout, Cin, taps) [PyTorch layout] and db (Cout) [NULL to skip]:
+/* Weight / bias gradient of dx_conv1d (and of nn.Linear with taps = 1), accumulated into dw (Cout, Cin, taps)
+ * [PyTorch layout, fp32] and db (Cout) [NULL to skip]:
  *   dw[co][ci][tap] += sum_{b,n} dy[b, n, co] * x[b, n + tap - taps/2, ci];   db[co] += sum_{b,n} dy[b, n, co]
  * dy (B, N, Cout) rows lddy apart, x (B, N, Cin) rows ldx apart; compute_dtype = MFMA operand type.
- * lengths (NULL = none): rows n >= lengths[b] + 2 of dy are known to be zero and are skipped. */
+ * lengths (NULL = none): rows n >= lengths[b] + 2 of dy are known to be zero and are skipped (the position axis is
+ * split over workgroups by valid rows).  ws: scratch of dx_conv1d_wgrad_ws_floats(...) floats (contents irrelevant, must
+ * stay untouched until the call has completed on `stream`): the per-workgroup partial sums go there and a second
+ * launch adds them to dw in a fixed order.  ws = NULL: partial sums are added to dw with fp32 atomics instead
+ * (slower, summation order varies run to run).  db always uses atomics (Cout values per workgroup). */
+long dx_conv1d_wgrad_ws_floats(int B, int N, int Cin, int Cout, int taps);
 int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const void* x, int x_dtype, long ldx,
-                    int compute_dtype, float* dw, float* db, const int64_t* lengths, int B, int N, int Cin,
+                    int compute_dtype, float* dw, float* db, const int64_t* lengths, float* ws, int B, int N, int Cin,
                     int Cout, int taps, void* stream);
 
 /* ---- K5: LayerNorm(C) over channel-last rows fused with its neighbours (C in {128, 256, 1024}):

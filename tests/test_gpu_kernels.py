@@ -103,10 +103,41 @@ def test_wgrad_matches_autograd_all_dtype_pairs():
         (O.conv1d_cl(x, w, b) * dy).sum().backward()
         for cd, dyt, xt, tol in ((torch.float32, torch.float32, torch.float32, 2e-5), (torch.bfloat16, torch.bfloat16, torch.float32, 2e-2),
                                  (torch.bfloat16, torch.float32, torch.bfloat16, 2e-2), (torch.bfloat16, torch.bfloat16, torch.bfloat16, 2e-2)):
-            dw = torch.zeros(Cout, Cin, taps, device=DEV) if taps == 3 else torch.zeros(Cout, Cin, device=DEV)
-            db = torch.zeros(Cout, device=DEV)
-            ops.conv1d_wgrad(dy.to(DEV).to(dyt), x.to(DEV).to(xt), dw, db, cd, lens.to(DEV))
-            ref = w.grad if taps == 3 else w.grad[:, :, 0]
-            assert float((dw.cpu() - ref).abs().max()) <= tol * float(ref.abs().max()), (taps, cd, dyt, xt)
-            assert float((db.cpu() - b.grad).abs().max()) <= tol * float(b.grad.abs().max()) + 1e-4, (taps, cd)
+            for use_ws in (True, False):                      # partial tiles + fixed-order reduce | fp32 atomics
+                ops.WGRAD_WORKSPACE = use_ws
+                dw = torch.zeros(Cout, Cin, taps, device=DEV) if taps == 3 else torch.zeros(Cout, Cin, device=DEV)
+                db = torch.zeros(Cout, device=DEV)
+                ops.conv1d_wgrad(dy.to(DEV).to(dyt), x.to(DEV).to(xt), dw, db, cd, lens.to(DEV))
+                ref = w.grad if taps == 3 else w.grad[:, :, 0]
+                assert float((dw.cpu() - ref).abs().max()) <= tol * float(ref.abs().max()), (taps, cd, dyt, xt, use_ws)
+                assert float((db.cpu() - b.grad).abs().max()) <= tol * float(b.grad.abs().max()) + 1e-4, (taps, cd, use_ws)
+            ops.WGRAD_WORKSPACE = True
         w.grad = None
+
+
+def test_wgrad_ragged_shapes_accumulate_and_fixed_order():
+    ''' channel counts that do not fill a tile, N not a multiple of the 128-position item, no lengths, dw += semantics,
+        and bit-identical results run to run on the workspace path '''
+    from daft_exprt import ops
+    from oracle import daft_exprt_cpu as O
+    g = torch.Generator().manual_seed(10)
+    for (B, N, Cin, Cout, taps, lens) in ((3, 333, 80, 200, 3, None), (2, 129, 136, 72, 1, None), (7, 1, 128, 128, 3, None),
+                                          (4, 515, 128, 384, 1, torch.tensor([515, 0, 130, 126]))):
+        x = torch.randn(B, N, Cin, generator=g)
+        dy = torch.randn(B, N, Cout, generator=g)
+        if lens is not None:
+            dy = dy * (torch.arange(N)[None, :, None] < (lens[:, None, None] + 2))
+        w = (torch.randn(Cout, Cin, taps, generator=g) / 10).requires_grad_(True)
+        b = torch.zeros(Cout, requires_grad=True)
+        (O.conv1d_cl(x, w, b) * dy).sum().backward()
+        ref = w.grad if taps == 3 else w.grad[:, :, 0]
+        init = torch.randn(ref.shape, generator=g)
+        outs = []
+        for _ in range(2):
+            dw, db = init.clone().to(DEV), torch.zeros(Cout, device=DEV)
+            ops.conv1d_wgrad(dy.to(DEV), x.to(DEV), dw, db, torch.float32, lens.to(DEV) if lens is not None else None)
+            outs.append(dw.cpu())
+        scale = float(ref.abs().max())
+        assert float((outs[0] - init - ref).abs().max()) <= 3e-5 * scale + 1e-5, (B, N, Cin, Cout, taps)
+        assert torch.equal(outs[0], outs[1])
+        assert float((db.cpu() - b.grad).abs().max()) <= 3e-5 * float(b.grad.abs().max()) + 1e-4

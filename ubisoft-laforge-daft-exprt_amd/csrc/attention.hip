@@ -64,7 +64,7 @@ template <int DH> struct Stage { static constexpr int KT = DH <= 16 ? 256 : 128;
 
 // =============================================================================== forward
 template <typename TC, int DH>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   constexpr int KT = Stage<DH>::KT;
   constexpr int LD = DH + APad<TC>::value, KS = DH / 16, MT = (DH + 31) / 32, WRAP = DH >= 32 ? 32 : 16;
   typedef typename Vec8<TC>::type frag_t;
@@ -103,9 +103,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) oT[mt][r] = 0.f;
   float m = -INFINITY, l = 0.f;
   const float c2 = a.scale * LOG2E;
-  const uint32_t th = athresh(a.p_drop), th16 = th >> 16;
-  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-  const uint32_t drop_key = dx_key32(a.seed, (uint32_t)(b * a.H + h)), drop_row = (uint32_t)q * (uint32_t)N;
+  const uint32_t th = athresh(a.p_drop);
+  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;   // applied once, to the output row
+  // dropout counter of (q, key) = ctr_lane + key-dependent part that is a scalar + compile-time constant (dx_common.h)
+  const uint32_t ctr_lane = ((uint32_t)q * (uint32_t)N + 4u * g) * DX_CTR_MUL + dx_key32(a.seed, (uint32_t)(b * a.H + h));
 
   for (int kt0 = 0; kt0 < len; kt0 += KT) {
     stage_tile<TC, DH, LD>(Ks, base + E, ld_g, kt0, KT, N, tid);
@@ -140,12 +141,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) { p[r] = fast_exp2<TC>(fmaf(s[r], c2, -m)); rs += p[r]; }
         rs += __shfl_xor(rs, 32, 64);
         l = l * alpha + rs;
-        if (th) {   // one hash decides two keys (16 bits each): key pair (2e, 2e+1) -> hash of the even key
+        if (th) {   // registers r, r + 1 hold the key pair (even, odd): one counter prefix, two fields
+          const uint32_t ctr_tile = (uint32_t)k0 * DX_CTR_MUL;
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
-            const uint32_t hsh = dx_mix32((drop_row + (uint32_t)(k0 + dx_acc_row(r, g))) * 0x9E3779B1u + drop_key);
-            p[r] = (hsh & 0xffffu) >= th16 ? p[r] * inv_keep : 0.f;
-            p[r + 1] = (hsh >> 16) >= th16 ? p[r + 1] * inv_keep : 0.f;
+            const uint32_t pre = dx_drop_prefix(ctr_lane + (ctr_tile + (uint32_t)((r & 3) + 8 * (r >> 2)) * DX_CTR_MUL));
+            p[r] = dx_drop_field(pre, DX_M24_EVEN) >= th ? p[r] : 0.f;
+            p[r + 1] = dx_drop_field(pre, DX_M24_ODD) >= th ? p[r + 1] : 0.f;
           }
         }
         frag_t pf[2] = {pack8<TC>(p), pack8<TC>(p + 8)};
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     __syncthreads();
   }
   if (q < N) {
-    const float inv_l = 1.f / l;
+    const float inv_l = inv_keep / l;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -199,7 +201,7 @@ __global__ void attn_delta_kernel(const TC* __restrict__ o, const TC* __restrict
 
 // =============================================================================== backward: dQ
 template <typename TC, int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   constexpr int KT = Stage<DH>::KT;
   constexpr int LD = DH + APad<TC>::value, KS = DH / 16, MT = (DH + 31) / 32, WRAP = DH >= 32 ? 32 : 16;
   typedef typename Vec8<TC>::type frag_t;
@@ -248,9 +250,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     if (q < N && g == 0) const_cast<float*>(a.delta)[stat] = delta_q;
     const float c2 = a.scale * LOG2E, lse2 = lse_q * LOG2E;
     const bool tile_q_valid = blockIdx.x * 128 + wave * 32 + 32 <= len;
-    const uint32_t th = athresh(a.p_drop), th16 = th >> 16;
+    const uint32_t th = athresh(a.p_drop);
     const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-    const uint32_t drop_key = dx_key32(a.seed, (uint32_t)(b * a.H + h)), drop_row = (uint32_t)q * (uint32_t)N;
+    const uint32_t ctr_lane = ((uint32_t)q * (uint32_t)N + 4u * g) * DX_CTR_MUL + dx_key32(a.seed, (uint32_t)(b * a.H + h));
 
     for (int kt0 = 0; kt0 < len; kt0 += KT) {
       stage_tile<TC, DH, LD>(Ks, base + E, ld_g, kt0, KT, N, tid);
@@ -272,19 +274,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
           }
           float ds[16];
           const bool interior = tile_q_valid && k0 + 32 <= len;   // wave-uniform: no masking needed
+          const uint32_t ctr_tile = (uint32_t)k0 * DX_CTR_MUL;
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
-            const int key = k0 + dx_acc_row(r, g);   // registers r, r+1 hold keys key, key+1 (same hash, see forward)
-            float ks0 = 1.f, ks1 = 1.f;
+            const int key = k0 + dx_acc_row(r, g);   // registers r, r+1 hold keys key, key+1 (one counter prefix, see forward)
+            float x0 = dp[r], x1 = dp[r + 1];
             if (th) {
-              const uint32_t hsh = dx_mix32((drop_row + (uint32_t)key) * 0x9E3779B1u + drop_key);
-              ks0 = (hsh & 0xffffu) >= th16 ? inv_keep : 0.f;
-              ks1 = (hsh >> 16) >= th16 ? inv_keep : 0.f;
+              const uint32_t pre = dx_drop_prefix(ctr_lane + (ctr_tile + (uint32_t)((r & 3) + 8 * (r >> 2)) * DX_CTR_MUL));
+              x0 = dx_drop_field(pre, DX_M24_EVEN) >= th ? x0 : 0.f;
+              x1 = dx_drop_field(pre, DX_M24_ODD) >= th ? x1 : 0.f;
             }
             float p0 = fast_exp2<TC>(fmaf(s[r], c2, -lse2)), p1 = fast_exp2<TC>(fmaf(s[r + 1], c2, -lse2));
             if (!interior) { p0 = (q_valid && key < len) ? p0 : 0.f; p1 = (q_valid && key + 1 < len) ? p1 : 0.f; }
-            ds[r] = p0 * (dp[r] * ks0 - delta_q);
-            ds[r + 1] = p1 * (dp[r + 1] * ks1 - delta_q);
+            ds[r] = p0 * fmaf(x0, inv_keep, -delta_q);
+            ds[r + 1] = p1 * fmaf(x1, inv_keep, -delta_q);
           }
           frag_t dsf[2] = {pack8<TC>(ds), pack8<TC>(ds + 8)};
 #pragma unroll
@@ -331,6 +334,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   const float* lse = a.lse + ((long)b * a.H + h) * N;
   const float* delta = a.delta + ((long)b * a.H + h) * N;
   const bool key_valid = key < len;
+  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;   // dV: applied once at the end
 
   f32x16 dvT[MT], dkT[MT];
 #pragma unroll
@@ -345,9 +349,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       kf[ks] = key < N ? *reinterpret_cast<const frag_t*>(base + E + (long)key * ld_g + ks * 16 + g * 8) : zero8<TC>();
       vf[ks] = key < N ? *reinterpret_cast<const frag_t*>(base + 2 * E + (long)key * ld_g + ks * 16 + g * 8) : zero8<TC>();
     }
-    const uint32_t th = athresh(a.p_drop), th16 = th >> 16;
-    const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-    const uint32_t drop_key = dx_key32(a.seed, (uint32_t)(b * a.H + h));
+    const uint32_t th = athresh(a.p_drop);
+    // counter(q, key) = ctr_lane + q-dependent scalar; the field multiplier is a lane constant (key parity)
+    const uint32_t ctr_q = (uint32_t)N * DX_CTR_MUL;
+    const uint32_t ctr_lane = (uint32_t)(key & ~1) * DX_CTR_MUL + dx_key32(a.seed, (uint32_t)(b * a.H + h)) + 4u * g * ctr_q;
+    const uint32_t mult_lane = (key & 1) ? DX_M24_ODD : DX_M24_EVEN;
     const float c2 = a.scale * LOG2E;
     const bool tile_k_valid = blockIdx.x * 128 + wave * 32 + 32 <= len;
 
@@ -382,13 +388,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
             const int qq = qt0 + row;
             float p = fast_exp2<TC>(fmaf(s[r], c2, -lse_s[row]));
             if (!interior) p = (key_valid && qq < len) ? p : 0.f;
-            float kscale = 1.f;
-            if (th) {   // same decision as the forward: the hash of the even key of the pair, low / high 16 bits
-              const uint32_t hsh = dx_mix32(((uint32_t)qq * (uint32_t)N + (uint32_t)(key & ~1)) * 0x9E3779B1u + drop_key);
-              kscale = ((key & 1) ? (hsh >> 16) : (hsh & 0xffffu)) >= th16 ? inv_keep : 0.f;
-            }
-            pd[r] = p * kscale;
-            ds[r] = p * (dp[r] * kscale - delta_s[row]);
+            bool keep = true;
+            if (th)     // same decision as the forward
+              keep = dx_drop_field(dx_drop_prefix(ctr_lane + (uint32_t)(qb + (r & 3) + 8 * (r >> 2)) * ctr_q), mult_lane) >= th;
+            pd[r] = keep ? p : 0.f;
+            ds[r] = p * fmaf(keep ? dp[r] : 0.f, inv_keep, -delta_s[row]);
           }
           frag_t pf[2] = {pack8<TC>(pd), pack8<TC>(pd + 8)};
           frag_t dsf[2] = {pack8<TC>(ds), pack8<TC>(ds + 8)};
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int d = mt * 32 + dx_acc_row(r, g);
         if (d < DH) {
-          dV[(long)key * ld_g + d] = (TC)dvT[mt][r];
+          dV[(long)key * ld_g + d] = (TC)(dvT[mt][r] * inv_keep);
           dK[(long)key * ld_g + d] = (TC)(dkT[mt][r] * a.scale);
         }
       }

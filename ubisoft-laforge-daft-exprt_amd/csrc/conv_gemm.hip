@@ -377,57 +377,72 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
 // ---- weight gradient ------------------------------------------------------------------------
 //   dW[co][ci][tap] += sum_{b, n} dY[b, n, co] * X[b, n + tap - taps/2, ci]        (fp32, PyTorch layout)
 //   db[co]          += sum_{b, n} dY[b, n, co]
-// GEMM with the positions as the contraction axis.  A workgroup owns a 128 (co) x 64 (ci) x taps output tile and a
-// slice of the utterances (split-K over the batch; partial tiles are combined with fp32 atomics).  Per step of 32
-// positions the dY tile [32][128] and the haloed X tile [34][64] are staged in LDS in their natural row-major
-// layout; both MFMA operands need "8 consecutive positions for one channel", which the LDS transpose read
-// (ds_read_b64_tr_b16, gather8) delivers without a software transpose; all taps reuse the same X tile at a row
-// offset.  Wave (wm, wn) accumulates 64 co x 32 ci x taps = 2*taps MFMA 32x32 tiles.
-constexpr int WG_CO = 128, WG_CI = 64;
-#ifndef DX_WG_P
-#define DX_WG_P 64
-#endif
-constexpr int WG_P = DX_WG_P;
+// GEMM with the positions as the contraction axis.  A 512-thread workgroup owns a 128 (co) x 64 (ci) x taps output
+// tile and a contiguous range of the flat list of 128-position items of the batch (split-K balanced over the VALID rows
+// of the batch, not over utterances: lengths differ by 10x inside a batch).  Its 8 waves form two groups of 4; group q
+// contracts rows [64q, 64q + 64) of every item from its own LDS stage, so a CU has 2 waves / SIMD and twice the loads
+// in flight for the same number of partial tiles.  Per item the dY tile [64][128] and the haloed X tile [66][64] of
+// each group are staged in LDS in their natural row-major layout; both MFMA operands need "8 consecutive positions for
+// one channel", which the LDS transpose read (ds_read_b64_tr_b16, gather8) delivers without a software transpose; all
+// taps reuse the same X tile at a row offset.  Wave (wm, wn) of a group accumulates 64 co x 32 ci x taps = 2*taps MFMA
+// 32x32 tiles.  At the end group 1 hands its accumulators to group 0 through LDS, and group 0 writes the partial tile to
+// a workspace in register order (coalesced); wgrad_reduce_kernel sums the partials of all splits into dW -- a fixed
+// summation order, no fp32 atomics on dW (measured: the atomics were 1/3 of the kernel).  Without a workspace the
+// partial tile is added with atomics.
+constexpr int WG_CO = 128, WG_CI = 64, WG_P = 64, WG_ITEM = 2 * WG_P, WG_THREADS = 512;
 
 struct WgradArgs {
   const void* dy; long lddy; const void* x; long ldx;
-  float* dw; float* db; const int64_t* lengths;
+  float* dw; float* db; const int64_t* lengths; float* ws;
   int B, N, Cin, Cout, nsplit, tiles_ci;
-  int map;
-  int debug;   // development ablation switches (DX_WGRAD_DEBUG): 1 = no atomics, 2 = no gathers/MFMA, 4 = no bias sums
+  int debug;   // development ablation switches (DX_WGRAD_DEBUG): 1 = no output, 2 = no gathers/MFMA, 4 = no bias sums
 };
 
-// The (utterance, 64-position chunk) work items of a workgroup form one flat sequence; the global loads of item k+1
-// are issued into registers (raw element types) before the MFMAs of item k and converted when written to LDS.
-template <typename TA, typename TB, typename TC, int TAPS>
-__global__ __launch_bounds__(NTHREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(WgradArgs p) {
-  constexpr int HALO = TAPS / 2, XROWS = WG_P + TAPS - 1;
+template <typename TC, int TAPS> struct WgradSmem {
+  static constexpr int XROWS = WG_P + TAPS - 1;
   // row strides = 16 banks (mod 64) apart: the 4 rows x 2 halves x 4 chunks touched by one 32-lane group of a
   // transpose read (ds_read_b64_tr_b16) then fall on 64 distinct banks
-  constexpr int LDA = WG_CO + 4 * Pad<TC>::value, LDB = WG_CI + 4 * Pad<TC>::value;
-  constexpr int A_PT = WG_P * (WG_CO / 8) / NTHREADS;
-  constexpr int B_CH = XROWS * (WG_CI / 8), B_PT = (B_CH + NTHREADS - 1) / NTHREADS;
+  static constexpr int LDA = WG_CO + 4 * Pad<TC>::value, LDB = WG_CI + 4 * Pad<TC>::value;
+  static constexpr int A_ELEMS = WG_P * LDA, B_ELEMS = XROWS * LDB;
+  static constexpr int STAGE_BYTES = 2 * (A_ELEMS + B_ELEMS) * (int)sizeof(TC);
+  static constexpr int TILE_FLOATS = TAPS * 2 * 16 * 256;          // one partial tile in register order
+  static constexpr int BYTES = STAGE_BYTES > TILE_FLOATS * 4 ? STAGE_BYTES : TILE_FLOATS * 4;
+};
+
+// The 128-position items of a workgroup form one flat sequence; the global loads of item k+1 are issued into
+// registers (raw element types) before the MFMAs of item k and converted when written to LDS.
+template <typename TA, typename TB, typename TC, int TAPS>
+__global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(WgradArgs p) {
+  typedef WgradSmem<TC, TAPS> SM;
+  constexpr int HALO = TAPS / 2, XROWS = SM::XROWS, LDA = SM::LDA, LDB = SM::LDB;
+  constexpr int A_PT = WG_ITEM * (WG_CO / 8) / WG_THREADS;                       // 4
+  constexpr int B_CH = 2 * XROWS * (WG_CI / 8), B_PT = (B_CH + WG_THREADS - 1) / WG_THREADS;
   typedef typename Vec8<TC>::type frag_t;
   typedef typename VecN<TA, 8>::type rawa_t;
   typedef typename VecN<TB, 8>::type rawb_t;
-  __shared__ __attribute__((aligned(16))) TC dYs[WG_P * LDA];
-  __shared__ __attribute__((aligned(16))) TC Xs[XROWS * LDB];
+  __shared__ __attribute__((aligned(16))) char smem[SM::BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-  // Work items = (batch slice, output tile), tile fastest.  map 1: XCD-aware -- workgroup L runs on XCD L % 8 (observed
-  // dispatch order), and each XCD is given a CONTIGUOUS range of work items so that the tiles of one batch slice
-  // (they re-read the same dY / X rows) share that XCD's L2.  map 0: plain order.
+  const int grp = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1, tig = tid & 255;
+  TC* dYs = reinterpret_cast<TC*>(smem) + grp * SM::A_ELEMS;
+  TC* Xs = reinterpret_cast<TC*>(smem) + 2 * SM::A_ELEMS + grp * SM::B_ELEMS;
   const int ntiles = dx_cdiv(p.Cout, WG_CO) * p.tiles_ci;
-  const int total = ntiles * p.nsplit;
-  int w = blockIdx.x;
-  if (p.map == 1) {
-    const int q = total >> 3, r = total & 7, xcd = w & 7, j = w >> 3;   // bijective for any total (guide T1)
-    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  }
-  const int split = w / ntiles, tile = w % ntiles;
+  const int split = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
   const int co0 = (tile / p.tiles_ci) * WG_CO, ci0 = (tile % p.tiles_ci) * WG_CI;
   const int N = p.N, Cin = p.Cin, Cout = p.Cout;
-  const int b_end = (int)((long)p.B * (split + 1) / p.nsplit);
+
+  // rows beyond len + halo carry exactly-zero gradients (masked upstream): not part of the item list
+  auto nlim_of = [&](int b) { return p.lengths ? min(N, (int)p.lengths[b] + 2) : N; };
+  int total = 0;
+  for (int b = 0; b < p.B; ++b) total += dx_cdiv(nlim_of(b), WG_ITEM);
+  const int i0 = (int)((long)total * split / p.nsplit), i1 = (int)((long)total * (split + 1) / p.nsplit);
+  int b = 0, n0 = 0, nlim = 0;
+  for (int cum = 0; b < p.B; ++b) {                 // locate item i0
+    nlim = nlim_of(b);
+    const int c = dx_cdiv(nlim, WG_ITEM);
+    if (i0 < cum + c) { n0 = (i0 - cum) * WG_ITEM; break; }
+    cum += c;
+  }
+  int left = i1 - i0;
 
   f32x16 acc[TAPS][2];
 #pragma unroll
@@ -436,8 +451,8 @@ __global__ __launch_bounds__(NTHREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wgra
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
-  // bias gradient = dY^T . 1: one extra MFMA per k-step against an all-ones B fragment (only in the ci0 == 0 tiles,
-  // only in the wn == 0 waves) instead of a serial LDS column-sum loop
+  // bias gradient = dY^T . 1: one extra MFMA per k-step against an all-ones B fragment (published only by the
+  // ci0 == 0 tiles' wn == 0 waves) instead of a serial LDS column-sum loop
   const bool do_bias = p.db && ci0 == 0 && wn == 0 && !(p.debug & 4);
   f32x16 bacc[2];
 #pragma unroll
@@ -448,66 +463,61 @@ __global__ __launch_bounds__(NTHREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wgra
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (TC)1.f;
 
-  // rows beyond len + halo carry exactly-zero gradients (masked upstream): skipped
-  auto nlim_of = [&](int b) { return p.lengths ? min(N, (int)p.lengths[b] + 2) : N; };
-  int b = (int)((long)p.B * split / p.nsplit), n0 = 0;
-  int nlim = b < b_end ? nlim_of(b) : 0;
-
   rawa_t ra[A_PT];
   rawb_t rb[B_PT];
-  auto fetch = [&](int fb, int fn0) {
+  auto fetch = [&](int fb, int fn0, int flim) {
     const TA* dY = reinterpret_cast<const TA*>(p.dy) + (size_t)fb * N * p.lddy;
     const TB* X = reinterpret_cast<const TB*>(p.x) + (size_t)fb * N * p.ldx;
 #pragma unroll
     for (int t = 0; t < A_PT; ++t) {
-      const int c = tid + t * NTHREADS;
-      const int r = c >> 4, kc = (c & 15) * 8;
-      const int n = fn0 + r, co = co0 + kc;
+      const int c = tid + t * WG_THREADS;
+      const int n = fn0 + (c >> 4), co = co0 + (c & 15) * 8;
 #pragma unroll
       for (int e = 0; e < 8; ++e) ra[t][e] = (TA)0.f;
-      if (n < N && co < Cout) ra[t] = raw_load8<TA>(dY + (size_t)n * p.lddy + co);
+      if (n < flim && co < Cout) ra[t] = raw_load8<TA>(dY + (size_t)n * p.lddy + co);   // rows >= flim are zero
     }
 #pragma unroll
     for (int t = 0; t < B_PT; ++t) {
-      const int c = tid + t * NTHREADS;
-      const int r = c >> 3, kc = (c & 7) * 8;
-      const int n = fn0 + r - HALO, ci = ci0 + kc;
+      const int c = tid + t * WG_THREADS;
+      const int q = c / (XROWS * 8), cc = c - q * (XROWS * 8);
+      const int n = fn0 + q * WG_P + (cc >> 3) - HALO, ci = ci0 + (cc & 7) * 8;
 #pragma unroll
       for (int e = 0; e < 8; ++e) rb[t][e] = (TB)0.f;
-      if (c < B_CH && n >= 0 && n < N && ci < Cin) rb[t] = raw_load8<TB>(X + (size_t)n * p.ldx + ci);
+      // x rows > flim only ever meet zero dy rows
+      if (c < B_CH && n >= 0 && n < N && n <= flim && ci < Cin) rb[t] = raw_load8<TB>(X + (size_t)n * p.ldx + ci);
     }
   };
   auto commit = [&]() {
+    TC* A = reinterpret_cast<TC*>(smem);
+    TC* Bm = reinterpret_cast<TC*>(smem) + 2 * SM::A_ELEMS;
 #pragma unroll
     for (int t = 0; t < A_PT; ++t) {
-      const int c = tid + t * NTHREADS;
-      *reinterpret_cast<frag_t*>(&dYs[(c >> 4) * LDA + (c & 15) * 8]) = cvt8<TA, TC>(ra[t]);
+      const int c = tid + t * WG_THREADS;
+      const int r = c >> 4;
+      *reinterpret_cast<frag_t*>(&A[(r >> 6) * SM::A_ELEMS + (r & 63) * LDA + (c & 15) * 8]) = cvt8<TA, TC>(ra[t]);
     }
 #pragma unroll
     for (int t = 0; t < B_PT; ++t) {
-      const int c = tid + t * NTHREADS;
-      if (c < B_CH) *reinterpret_cast<frag_t*>(&Xs[(c >> 3) * LDB + (c & 7) * 8]) = cvt8<TB, TC>(rb[t]);
+      const int c = tid + t * WG_THREADS;
+      const int q = c / (XROWS * 8), cc = c - q * (XROWS * 8);
+      if (c < B_CH) *reinterpret_cast<frag_t*>(&Bm[q * SM::B_ELEMS + (cc >> 3) * LDB + (cc & 7) * 8]) = cvt8<TB, TC>(rb[t]);
     }
   };
-  auto advance = [&]() {   // next (b, n0) work item; b == b_end when exhausted
-    n0 += WG_P;
-    while (b < b_end && n0 >= nlim) {
-      ++b; n0 = 0;
-      nlim = b < b_end ? nlim_of(b) : 0;
-    }
-  };
-  while (b < b_end && n0 >= nlim) { ++b; nlim = b < b_end ? nlim_of(b) : 0; }   // skip empty leading utterances
 
-  if (b < b_end) {
-    fetch(b, n0);
+  if (left > 0) {
+    fetch(b, n0, nlim);
     commit();
     __syncthreads();
   }
-  while (b < b_end) {
-    advance();
-    const bool more = b < b_end;
-    if (more) fetch(b, n0);
-    if (!(p.debug & 2))
+  while (left > 0) {
+    const bool live = n0 + grp * WG_P < nlim;       // this group's 64 rows hold at least one non-zero dy row
+    --left;
+    if (left > 0) {                                 // next item
+      n0 += WG_ITEM;
+      if (n0 >= nlim) { ++b; n0 = 0; nlim = nlim_of(b); }
+      fetch(b, n0, nlim);
+    }
+    if (live && !(p.debug & 2))
 #pragma unroll
     for (int ks = 0; ks < WG_P / 16; ++ks) {
       const int kA = ks * 16 + 8 * g, kB = kA + 4;
@@ -525,24 +535,50 @@ __global__ __launch_bounds__(NTHREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wgra
       }
     }
     __syncthreads();
-    if (more) {
+    if (left > 0) {
       commit();
       __syncthreads();
     }
   }
-  const int ci = ci0 + wn * 32 + l31;
-  if (ci < Cin && !(p.debug & 1)) {
+  // ---- group 1 -> LDS -> group 0 (the stages are dead after the loop's last barrier)
+  float* red = reinterpret_cast<float*>(smem);
+  if (grp == 1) {
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co0 + wm * 64 + i * 32 + dx_acc_row(r, g);
-          if (co < Cout) atomicAdd(p.dw + ((size_t)co * Cin + ci) * TAPS + t, acc[t][i][r]);
-        }
+        for (int r = 0; r < 16; ++r) red[((t * 2 + i) * 16 + r) * 256 + tig] = acc[t][i][r];
   }
-  if (do_bias && l31 == 0) {   // every column of bacc holds the same row sums; column 0 publishes them
+  __syncthreads();
+  if (grp == 0 && !(p.debug & 1)) {
+    if (p.ws) {
+      float* out = p.ws + ((size_t)split * ntiles + tile) * SM::TILE_FLOATS;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int slot = ((t * 2 + i) * 16 + r) * 256 + tig;
+            out[slot] = acc[t][i][r] + red[slot];
+          }
+    } else {
+      const int ci = ci0 + wn * 32 + l31;
+      if (ci < Cin) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int co = co0 + wm * 64 + i * 32 + dx_acc_row(r, g);
+              if (co < Cout) atomicAdd(p.dw + ((size_t)co * Cin + ci) * TAPS + t, acc[t][i][r] + red[((t * 2 + i) * 16 + r) * 256 + tig]);
+            }
+      }
+    }
+  }
+  if (do_bias && l31 == 0) {   // every column of bacc holds the same row sums; column 0 publishes them (both groups)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -553,14 +589,40 @@ __global__ __launch_bounds__(NTHREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wgra
   }
 }
 
+// dW += sum over the splits of the partial tiles (register order, see conv_wgrad_kernel); one thread per tile element
+template <int TAPS>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
+                                                           int ntiles, int tiles_ci, int Cout, int Cin) {
+  constexpr int TILE_FLOATS = TAPS * 2 * 16 * 256;
+  const int tile = blockIdx.x / (TAPS * 32), slot = blockIdx.x % (TAPS * 32), tig = threadIdx.x;
+  const int t = slot / 32, i = (slot >> 4) & 1, r = slot & 15;
+  const int lane = tig & 63, w4 = tig >> 6, wm = w4 >> 1, wn = w4 & 1;
+  const int co = (tile / tiles_ci) * WG_CO + wm * 64 + i * 32 + dx_acc_row(r, lane >> 5);
+  const int ci = (tile % tiles_ci) * WG_CI + wn * 32 + (lane & 31);
+  const float* src = ws + (size_t)tile * TILE_FLOATS + slot * 256 + tig;
+  float s0 = 0.f, s1 = 0.f;
+  int k = 0;
+  for (; k + 1 < nsplit; k += 2) {
+    s0 += src[(size_t)k * ntiles * TILE_FLOATS];
+    s1 += src[(size_t)(k + 1) * ntiles * TILE_FLOATS];
+  }
+  if (k < nsplit) s0 += src[(size_t)k * ntiles * TILE_FLOATS];
+  if (co < Cout && ci < Cin) dw[((size_t)co * Cin + ci) * TAPS + t] += s0 + s1;
+}
+
 template <typename TA, typename TB, typename TC>
 int launch_wgrad(const WgradArgs& a, int taps, hipStream_t s) {
   const int ntiles = dx_cdiv(a.Cout, WG_CO) * a.tiles_ci;
-  dim3 grid(ntiles * a.nsplit), block(NTHREADS);
-  if (taps == 1)
+  dim3 grid(ntiles * a.nsplit), block(WG_THREADS);
+  if (taps == 1) {
     hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 1>), grid, block, 0, s, a);
-  else
+    if (a.ws && !(a.debug & 1))
+      hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(ntiles * 32), dim3(256), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
+  } else {
     hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 3>), grid, block, 0, s, a);
+    if (a.ws && !(a.debug & 1))
+      hipLaunchKernelGGL((wgrad_reduce_kernel<3>), dim3(ntiles * 96), dim3(256), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
+  }
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
@@ -662,25 +724,34 @@ extern "C" int dx_pack_conv_weight(const float* w, void* out, int out_dtype, int
   return DX_OK;
 }
 
+// number of workgroup splits of the position axis for a wgrad problem (shared by the launcher and the workspace query)
+static int wgrad_nsplit(int B, int N, int Cin, int Cout) {
+  static int target = getenv("DX_WGRAD_BLOCKS") ? atoi(getenv("DX_WGRAD_BLOCKS")) : 256;
+  const int tiles = dx_cdiv(Cout, WG_CO) * dx_cdiv(Cin, WG_CI);
+  // enough workgroups to occupy the chip, but every split costs one more partial tile to write and re-read:
+  // keep >= ~4 items (128 positions each) of work per workgroup
+  int ns = target / tiles;
+  const long by_work = (long)B * dx_cdiv(N, WG_ITEM) / 4;
+  if (ns > by_work) ns = (int)by_work;
+  return ns < 1 ? 1 : ns;
+}
+
+extern "C" long dx_conv1d_wgrad_ws_floats(int B, int N, int Cin, int Cout, int taps) {
+  if (B <= 0 || N <= 0 || Cin <= 0 || Cout <= 0 || (taps != 1 && taps != 3)) return 0;
+  const long tiles = (long)dx_cdiv(Cout, WG_CO) * dx_cdiv(Cin, WG_CI);
+  return (long)wgrad_nsplit(B, N, Cin, Cout) * tiles * taps * 2 * 16 * 256;
+}
+
 extern "C" int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const void* x, int x_dtype, long ldx,
-                               int compute_dtype, float* dw, float* db, const int64_t* lengths, int B, int N, int Cin,
-                               int Cout, int taps, void* stream) {
+                               int compute_dtype, float* dw, float* db, const int64_t* lengths, float* ws, int B, int N,
+                               int Cin, int Cout, int taps, void* stream) {
   DX_REQUIRE(dy && x && dw, DX_ERR_ARG, "dx_conv1d_wgrad: null pointer");
   DX_REQUIRE(B > 0 && N > 0 && Cin > 0 && Cout > 0, DX_ERR_SHAPE, "dx_conv1d_wgrad: empty shape");
   DX_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0, DX_ERR_SHAPE,
              "dx_conv1d_wgrad: Cin, Cout and the row strides must be multiples of 8");
   DX_REQUIRE(taps == 1 || taps == 3, DX_ERR_UNSUPPORTED, "dx_conv1d_wgrad: taps=%d (only 1 and 3)", taps);
   static int dbg = getenv("DX_WGRAD_DEBUG") ? atoi(getenv("DX_WGRAD_DEBUG")) : 0;
-  static int wmap = getenv("DX_WGRAD_MAP") ? atoi(getenv("DX_WGRAD_MAP")) : 0;
-  WgradArgs a{dy, lddy, x, ldx, dw, db, lengths, B, N, Cin, Cout, 1, dx_cdiv(Cin, WG_CI), wmap, dbg};
-  const int tiles = dx_cdiv(Cout, WG_CO) * a.tiles_ci;
-  static int target = getenv("DX_WGRAD_BLOCKS") ? atoi(getenv("DX_WGRAD_BLOCKS")) : 256;
-  // split-K over the batch: enough workgroups to occupy the chip, but every extra split costs a full pass of fp32
-  // atomics over the weight tensor (~200 G atomics/s measured) -> keep >= ~12 stages of work per workgroup
-  int ns = target / tiles;
-  const int by_work = (int)((long)B * dx_cdiv(N, WG_P) / 12);
-  if (ns > by_work) ns = by_work;
-  a.nsplit = ns < 1 ? 1 : (ns > B ? B : ns);
+  WgradArgs a{dy, lddy, x, ldx, dw, db, lengths, ws, B, N, Cin, Cout, wgrad_nsplit(B, N, Cin, Cout), dx_cdiv(Cin, WG_CI), dbg};
   hipStream_t s = (hipStream_t)stream;
   if (compute_dtype == DX_BF16) {
     if (dy_dtype == DX_F32 && x_dtype == DX_F32) return launch_wgrad<float, float, bf16_t>(a, taps, s);

@@ -128,6 +128,8 @@ def _init_tensor(shape, init, gen):
     return u / math.sqrt(float(arg))   # torch default Linear / Conv1d bias and kaiming(a=sqrt 5) weight bound
 
 
+_SKIP_WGRAD = bool(int(__import__('os').environ.get('DX_SKIP_WGRAD', '0')))
+
 class _Node(nn.Module):
     ''' name-only container: reproduces the reference's module tree so that state_dict keys match '''
 
@@ -475,6 +477,8 @@ class DaftExprt(nn.Module):
         ''' weight / bias gradient on the side stream: these kernels are off the critical path of the backward pass
             (nothing downstream reads dW before the optimizer step), so they overlap with the data-gradient chain. '''
         side = self._side_stream
+        if _SKIP_WGRAD:                                 # development ablation: how much does the overlap cost the main stream?
+            return
         if side is None:
             return ops.conv1d_wgrad(dy, x, dw, db, self.cd, lengths)
         main = torch.cuda.current_stream()

@@ -1,6 +1,7 @@
 """Thin Python wrappers over the C ABI (include/daft_exprt_hip.h): allocate outputs with torch
 (device-memory plumbing only), pass raw pointers + the current HIP stream.  One function per entry point."""
 import ctypes
+import os
 
 import torch
 
@@ -8,6 +9,7 @@ from daft_exprt import _hip as H
 
 _INF = float('inf')
 DETERMINISTIC_LN = False
+WGRAD_WORKSPACE = bool(int(os.environ.get('DX_WGRAD_WORKSPACE', '1')))   # 0: fp32 atomics on dW instead of partial tiles + reduce
 
 # Optional per-kernel timing probe used by bench.py: {family: [(start_event, end_event, padded_flops, N), ...]}.
 # Events are recorded on torch's current stream, which is the stream every kernel is launched on.
@@ -121,9 +123,12 @@ def conv1d_wgrad(dy, x, dw, db, compute_dtype, lengths=None):
     Cin = x.shape[2]
     taps = dw.shape[2] if dw.dim() == 3 else 1
     assert dw.shape[0] == Cout and dw.shape[1] == Cin and dy.stride(2) == 1 and x.stride(2) == 1
+    # scratch for the per-workgroup partial tiles; allocated on the current stream (the caching allocator keeps it
+    # stream-ordered), ~25 MB for the wide convolutions
+    ws = torch.empty(H.lib().dx_conv1d_wgrad_ws_floats(B, N, Cin, Cout, taps), dtype=torch.float32, device=dy.device) if WGRAD_WORKSPACE else None
     with _Probe('conv_wgrad', 2. * B * N * Cin * Cout * taps, N):
       H.check(H.lib().dx_conv1d_wgrad(H.ptr(dy), H.dt(dy), dy.stride(1), H.ptr(x), H.dt(x), x.stride(1),
-                                    H._DT[compute_dtype], H.ptr(dw), H.ptr(db), H.ptr(lengths), B, N, Cin, Cout, taps,
+                                    H._DT[compute_dtype], H.ptr(dw), H.ptr(db), H.ptr(lengths), H.ptr(ws), B, N, Cin, Cout, taps,
                                     H.stream()))
 
 
