@@ -57,6 +57,28 @@ __device__ __forceinline__ void stage_tile(TC* dst, const TC* src, long ld_g, in
   }
 }
 
+// the same tile in two halves: global -> registers (issued one stage ahead, so the load latency hides under the MFMA /
+// softmax work of the current stage) and registers -> LDS
+template <typename TC, int DH, int ROWS> struct TileRegs {
+  static constexpr int CPR = DH / 8, PT = (ROWS * CPR + 255) / 256;
+  typename Vec8<TC>::type v[PT];
+  __device__ __forceinline__ void fetch(const TC* src, long ld_g, int row0, int n_lim, int tid) {
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const int c = tid + t * 256, r = c / CPR, kc = (c - r * CPR) * 8;
+      v[t] = zero8<TC>();
+      if (c < ROWS * CPR && row0 + r < n_lim) v[t] = *reinterpret_cast<const typename Vec8<TC>::type*>(src + (long)(row0 + r) * ld_g + kc);
+    }
+  }
+  template <int LD> __device__ __forceinline__ void commit(TC* dst, int tid) const {
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const int c = tid + t * 256, r = c / CPR, kc = (c - r * CPR) * 8;
+      if (c < ROWS * CPR) *reinterpret_cast<typename Vec8<TC>::type*>(dst + r * LD + kc) = v[t];
+    }
+  }
+};
+
 __device__ __forceinline__ uint32_t athresh(float p) { return p <= 0.f ? 0u : (uint32_t)(p * 4294967296.0); }
 
 // rows of the streamed axis per LDS stage: every stage exposes one global-load latency, so small heads take big stages
@@ -108,10 +130,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   // dropout counter of (q, key) = ctr_lane + key-dependent part that is a scalar + compile-time constant (dx_common.h)
   const uint32_t ctr_lane = ((uint32_t)q * (uint32_t)N + 4u * g) * DX_CTR_MUL + dx_key32(a.seed, (uint32_t)(b * a.H + h));
 
+  constexpr bool AHEAD = sizeof(TC) == 2;   // exact-fp32 mode: twice the registers per tile, loads stay in place
+  TileRegs<TC, DH, KT> kreg, vreg;
+  if (AHEAD) {
+    kreg.fetch(base + E, ld_g, 0, N, tid);
+    vreg.fetch(base + 2 * E, ld_g, 0, N, tid);
+  }
   for (int kt0 = 0; kt0 < len; kt0 += KT) {
-    stage_tile<TC, DH, LD>(Ks, base + E, ld_g, kt0, KT, N, tid);
-    stage_tile<TC, DH, LD>(Vs, base + 2 * E, ld_g, kt0, KT, N, tid);
+    if (!AHEAD) {
+      kreg.fetch(base + E, ld_g, kt0, N, tid);
+      vreg.fetch(base + 2 * E, ld_g, kt0, N, tid);
+    }
+    kreg.template commit<LD>(Ks, tid);
+    vreg.template commit<LD>(Vs, tid);
     __syncthreads();
+    if (AHEAD && kt0 + KT < len) {
+      kreg.fetch(base + E, ld_g, kt0 + KT, N, tid);
+      vreg.fetch(base + 2 * E, ld_g, kt0 + KT, N, tid);
+    }
 #pragma unroll
     for (int sub = 0; sub < KT / 32; ++sub) {
       const int k0 = kt0 + sub * 32;
@@ -254,10 +290,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
     const uint32_t ctr_lane = ((uint32_t)q * (uint32_t)N + 4u * g) * DX_CTR_MUL + dx_key32(a.seed, (uint32_t)(b * a.H + h));
 
+    constexpr bool AHEAD = sizeof(TC) == 2;
+    TileRegs<TC, DH, KT> kreg, vreg;
+    if (AHEAD) {
+      kreg.fetch(base + E, ld_g, 0, N, tid);
+      vreg.fetch(base + 2 * E, ld_g, 0, N, tid);
+    }
     for (int kt0 = 0; kt0 < len; kt0 += KT) {
-      stage_tile<TC, DH, LD>(Ks, base + E, ld_g, kt0, KT, N, tid);
-      stage_tile<TC, DH, LD>(Vs, base + 2 * E, ld_g, kt0, KT, N, tid);
+      if (!AHEAD) {
+        kreg.fetch(base + E, ld_g, kt0, N, tid);
+        vreg.fetch(base + 2 * E, ld_g, kt0, N, tid);
+      }
+      kreg.template commit<LD>(Ks, tid);
+      vreg.template commit<LD>(Vs, tid);
       __syncthreads();
+      if (AHEAD && kt0 + KT < len) {
+        kreg.fetch(base + E, ld_g, kt0 + KT, N, tid);
+        vreg.fetch(base + 2 * E, ld_g, kt0 + KT, N, tid);
+      }
 #pragma unroll
       for (int sub = 0; sub < KT / 32; ++sub) {
         const int k0 = kt0 + sub * 32;
@@ -278,12 +328,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
             const int key = k0 + dx_acc_row(r, g);   // registers r, r+1 hold keys key, key+1 (one counter prefix, see forward)
-            float x0 = dp[r], x1 = dp[r + 1];
-            if (th) {
-              const uint32_t pre = dx_drop_prefix(ctr_lane + (ctr_tile + (uint32_t)((r & 3) + 8 * (r >> 2)) * DX_CTR_MUL));
-              x0 = dx_drop_field(pre, DX_M24_EVEN) >= th ? x0 : 0.f;
-              x1 = dx_drop_field(pre, DX_M24_ODD) >= th ? x1 : 0.f;
-            }
+            // th == 0 keeps everything; no branch around the hash (backward = training)
+            const uint32_t pre = dx_drop_prefix(ctr_lane + (ctr_tile + (uint32_t)((r & 3) + 8 * (r >> 2)) * DX_CTR_MUL));
+            const float x0 = dx_drop_field(pre, DX_M24_EVEN) >= th ? dp[r] : 0.f;
+            const float x1 = dx_drop_field(pre, DX_M24_ODD) >= th ? dp[r + 1] : 0.f;
             float p0 = fast_exp2<TC>(fmaf(s[r], c2, -lse2)), p1 = fast_exp2<TC>(fmaf(s[r + 1], c2, -lse2));
             if (!interior) { p0 = (q_valid && key < len) ? p0 : 0.f; p1 = (q_valid && key + 1 < len) ? p1 : 0.f; }
             ds[r] = p0 * fmaf(x0, inv_keep, -delta_q);
@@ -315,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 
 // =============================================================================== backward: dK, dV
 template <typename TC, int DH>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, DH <= 16 ? 3 : 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   constexpr int KT = Stage<DH>::KT;
   constexpr int LD = DH + APad<TC>::value, KS = DH / 16, MT = (DH + 31) / 32, WRAP = DH >= 32 ? 32 : 16;
   typedef typename Vec8<TC>::type frag_t;
@@ -354,19 +402,41 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     const uint32_t ctr_q = (uint32_t)N * DX_CTR_MUL;
     const uint32_t ctr_lane = (uint32_t)(key & ~1) * DX_CTR_MUL + dx_key32(a.seed, (uint32_t)(b * a.H + h)) + 4u * g * ctr_q;
     const uint32_t mult_lane = (key & 1) ? DX_M24_ODD : DX_M24_EVEN;
+    uint32_t ctr_row[16];   // wave-uniform (SGPR) per-register query offsets of the counter
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ctr_row[r] = __builtin_amdgcn_readfirstlane((uint32_t)((r & 3) + 8 * (r >> 2)) * ctr_q);
     const float c2 = a.scale * LOG2E;
     const bool tile_k_valid = blockIdx.x * 128 + wave * 32 + 32 <= len;
 
+    TileRegs<TC, DH, KT> qreg, doreg;
+    float lse_r = 0.f, delta_r = 0.f;
+    auto fetch_stats = [&](int qt0) {
+      const int qq = qt0 + tid;
+      lse_r = (tid < KT && qq < N) ? lse[qq] * LOG2E : 0.f;   // log2 domain, see fast_exp2
+      delta_r = (tid < KT && qq < N) ? delta[qq] : 0.f;
+    };
+    constexpr bool AHEAD = sizeof(TC) == 2;
+    if (AHEAD) {
+      qreg.fetch(base, ld_g, 0, N, tid);
+      doreg.fetch(dO, E, 0, N, tid);
+      fetch_stats(0);
+    }
     for (int qt0 = 0; qt0 < len; qt0 += KT) {
-      stage_tile<TC, DH, LD>(Qs, base, ld_g, qt0, KT, N, tid);
-      stage_tile<TC, DH, LD>(dOs, dO, E, qt0, KT, N, tid);
-      if (tid < KT) {
-        const int qq = qt0 + tid;
-        lse_s[tid] = qq < N ? lse[qq] * LOG2E : 0.f;   // log2 domain, see fast_exp2
-        delta_s[tid] = qq < N ? delta[qq] : 0.f;
+      if (!AHEAD) {
+        qreg.fetch(base, ld_g, qt0, N, tid);
+        doreg.fetch(dO, E, qt0, N, tid);
+        fetch_stats(qt0);
       }
+      qreg.template commit<LD>(Qs, tid);
+      doreg.template commit<LD>(dOs, tid);
+      if (tid < KT) { lse_s[tid] = lse_r; delta_s[tid] = delta_r; }
       __syncthreads();
-#pragma unroll
+      if (AHEAD && qt0 + KT < len) {
+        qreg.fetch(base, ld_g, qt0 + KT, N, tid);
+        doreg.fetch(dO, E, qt0 + KT, N, tid);
+        fetch_stats(qt0 + KT);
+      }
+#pragma unroll (DH <= 16 ? 1 : 2)
       for (int sub = 0; sub < KT / 32; ++sub) {
         const int qb = qt0 + sub * 32;
         if (qb < len) {
@@ -382,15 +452,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
           }
           float pd[16], ds[16];
           const bool interior = tile_k_valid && qb + 32 <= len;   // wave-uniform
+          const uint32_t ctr_sub = ctr_lane + __builtin_amdgcn_readfirstlane((uint32_t)qb * ctr_q);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = sub * 32 + dx_acc_row(r, g);
             const int qq = qt0 + row;
             float p = fast_exp2<TC>(fmaf(s[r], c2, -lse_s[row]));
             if (!interior) p = (key_valid && qq < len) ? p : 0.f;
-            bool keep = true;
-            if (th)     // same decision as the forward
-              keep = dx_drop_field(dx_drop_prefix(ctr_lane + (uint32_t)(qb + (r & 3) + 8 * (r >> 2)) * ctr_q), mult_lane) >= th;
+            // same decision as the forward (th == 0 keeps everything; no branch around the hash: backward = training)
+            const bool keep = dx_drop_field(dx_drop_prefix(ctr_sub + ctr_row[r]), mult_lane) >= th;
             pd[r] = keep ? p : 0.f;
             ds[r] = p * fmaf(keep ? dp[r] : 0.f, inv_keep, -delta_s[row]);
           }
