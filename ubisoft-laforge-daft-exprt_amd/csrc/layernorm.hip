@@ -168,11 +168,20 @@ struct LNBwdArgs {
   float* ws;                 // optional (B * chunks, 4, C) partial sums -> finished by ln_bwd_finish_kernel (no atomics)
 };
 
-// grid = (ceil(N / rows_per_block), B); 4 waves per block, wave w handles rows w, w+4, ... of the slab
-template <typename TI, typename TG, typename TD, int C>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
+// raw (unconverted) 4-element row segment: the prefetched next row stays in its storage type
+template <typename T, int V> struct RawVec { typedef T type __attribute__((ext_vector_type(V))); };
+
+// grid = (ceil(N / rows_per_block), B); 4 waves per block, wave w handles rows w, w+4, ... of the slab.
+// FILM: the forward applied y = film_gamma * LN + film_beta (per-utterance gradients dfilm).  Register budget: the
+// next row of dy / s is prefetched in its STORAGE type (half the registers of fp32 for the bf16 tensors), and for
+// C = 1024 gamma / beta are re-read per row (L1-resident, 8 KB) instead of living in 32 registers -- the first version
+// held everything in fp32 registers: 292 VGPRs, one wave per SIMD, 1.5 TB/s.
+template <typename TI, typename TG, typename TD, int C, bool FILM>
+__global__ __launch_bounds__(256, C >= 1024 ? (FILM ? 1 : 3) : 4) void ln_bwd_kernel(LNBwdArgs a) {
   typedef Lay<C> L;
-  __shared__ float red[4][4][C];  // [wave][dgamma, dbeta, dfilm_g, dfilm_b][C]
+  constexpr bool REG_PARAMS = C <= 256;
+  constexpr int NRED = FILM ? 4 : 2;
+  __shared__ float red[4][NRED][C];  // [wave][dgamma, dbeta (, dfilm_g, dfilm_b)][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
   const int n_begin = blockIdx.x * a.rows_per_block;
@@ -184,28 +193,36 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
   const float sc_post = a.p_post > 0.f ? 1.f / (1.f - a.p_post) : 1.f;
   const int nskip = a.skip ? (int)a.skip[b] + 2 : a.N;
 
-  float gam[L::EPL], bet[L::EPL], fg[L::EPL];
-  float acc_g[L::EPL], acc_b[L::EPL], acc_fg[L::EPL], acc_fb[L::EPL];
+  constexpr int NP = REG_PARAMS ? L::EPL : 1, NF = FILM ? L::EPL : 1;
+  float gam[NP], bet[NP], fg[NF];
+  float acc_g[L::EPL], acc_b[L::EPL], acc_fg[NF], acc_fb[NF];
+  if (REG_PARAMS) {
 #pragma unroll
-  for (int k = 0; k < L::NV; ++k) {
-    const int c0 = L::col(lane, k);
-    load_vec<float, L::V>(a.gamma + c0, gam + k * L::V);
-    load_vec<float, L::V>(a.beta + c0, bet + k * L::V);
-    if (a.film) load_vec<float, L::V>(a.film + (long)b * a.ldf + c0, fg + k * L::V);
+    for (int k = 0; k < L::NV; ++k) {
+      load_vec<float, L::V>(a.gamma + L::col(lane, k), gam + (REG_PARAMS ? k * L::V : 0));
+      load_vec<float, L::V>(a.beta + L::col(lane, k), bet + (REG_PARAMS ? k * L::V : 0));
+    }
+  }
+  if (FILM) {
+#pragma unroll
+    for (int k = 0; k < L::NV; ++k) load_vec<float, L::V>(a.film + (long)b * a.ldf + L::col(lane, k), fg + (FILM ? k * L::V : 0));
   }
 #pragma unroll
-  for (int i = 0; i < L::EPL; ++i) { acc_g[i] = acc_b[i] = acc_fg[i] = acc_fb[i] = 0.f; if (!a.film) fg[i] = 1.f; }
+  for (int i = 0; i < L::EPL; ++i) { acc_g[i] = 0.f; acc_b[i] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < NF; ++i) { acc_fg[i] = 0.f; acc_fb[i] = 0.f; }
 
-  float g_nx[L::EPL], x_nx[L::EPL], mean_nx = 0.f, rstd_nx = 0.f;
+  typename RawVec<TG, L::V>::type g_nx[L::NV];
+  typename RawVec<TI, L::V>::type x_nx[L::NV];
+  float mean_nx = 0.f, rstd_nx = 0.f;
   auto fetch_row = [&](int n) {
     const long row = (long)b * a.N + n;
     const TG* dy = reinterpret_cast<const TG*>(a.dy) + row * C;
     const TI* sp = reinterpret_cast<const TI*>(a.s) + row * C;
 #pragma unroll
     for (int k = 0; k < L::NV; ++k) {
-      const int c0 = L::col(lane, k);
-      load_vec<TG, L::V>(dy + c0, g_nx + k * L::V);
-      load_vec<TI, L::V>(sp + c0, x_nx + k * L::V);
+      g_nx[k] = *reinterpret_cast<const typename RawVec<TG, L::V>::type*>(dy + L::col(lane, k));
+      x_nx[k] = *reinterpret_cast<const typename RawVec<TI, L::V>::type*>(sp + L::col(lane, k));
     }
     mean_nx = a.mean[row];
     rstd_nx = a.rstd[row];
@@ -231,32 +248,41 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
     // this row's operands were fetched one iteration ago; issue the loads of the wave's next row before computing
     float g[L::EPL], xh[L::EPL];
 #pragma unroll
-    for (int j = 0; j < L::EPL; ++j) { g[j] = g_nx[j]; xh[j] = x_nx[j]; }
+    for (int k = 0; k < L::NV; ++k)
+#pragma unroll
+      for (int i = 0; i < L::V; ++i) { g[k * L::V + i] = (float)g_nx[k][i]; xh[k * L::V + i] = (float)x_nx[k][i]; }
     const float mean = mean_nx, rstd = rstd_nx;
     if (n + 4 < n_end && n + 4 < nskip) fetch_row(n + 4);
-    bool pos[L::EPL];
+    uint32_t pos = 0;   // bit j: s[j] > 0 (ReLU gate), EPL <= 16
     const bool pad = n >= len;
     float m1 = 0.f, m2 = 0.f;
 #pragma unroll
     for (int k = 0; k < L::NV; ++k) {
+      float gk[L::V], bk[L::V];
+      if (!REG_PARAMS) {
+        load_vec<float, L::V>(a.gamma + L::col(lane, k), gk);
+        load_vec<float, L::V>(a.beta + L::col(lane, k), bk);
+      }
 #pragma unroll
       for (int i = 0; i < L::V; ++i) {
         const int j = k * L::V + i;
         const int c = L::col(lane, k) + i;
+        const float gmj = REG_PARAMS ? gam[REG_PARAMS ? j : 0] : gk[i], btj = REG_PARAMS ? bet[REG_PARAMS ? j : 0] : bk[i];
         float gy = pad ? 0.f : g[j];
-        pos[j] = xh[j] > 0.f;
+        pos |= (xh[j] > 0.f ? 1u : 0u) << j;
         xh[j] = (xh[j] - mean) * rstd;
-        float ln = xh[j] * gam[j] + bet[j];                 // LayerNorm output before dropout_post / FiLM
         float keep_post = 1.f;
         if (th_post) keep_post = dx_keep(key_post, (uint32_t)row * C + c, th_post) ? sc_post : 0.f;
-        if (a.film) {                                       // y = fg * (ln * keep) + fb
-          acc_fg[j] += gy * ln * keep_post;
-          acc_fb[j] += gy;
+        if (FILM) {                                         // y = fg * (ln * keep) + fb
+          const float ln = xh[j] * gmj + btj;               // LayerNorm output before dropout_post / FiLM
+          acc_fg[FILM ? j : 0] += gy * ln * keep_post;
+          acc_fb[FILM ? j : 0] += gy;
+          gy *= fg[FILM ? j : 0];
         }
-        gy = gy * fg[j] * keep_post;                        // grad wrt ln
+        gy *= keep_post;                                    // grad wrt ln
         acc_g[j] += gy * xh[j];
         acc_b[j] += gy;
-        const float gx = gy * gam[j];
+        const float gx = gy * gmj;
         g[j] = gx;
         m1 += gx;
         m2 += gx * xh[j];
@@ -274,7 +300,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
       for (int i = 0; i < L::V; ++i) {
         const int j = k * L::V + i;
         o[i] = rstd * (g[j] - m1 - xh[j] * m2);
-        if (a.relu_input && !pos[j]) o[i] = 0.f;
+        if (a.relu_input && !((pos >> j) & 1u)) o[i] = 0.f;
         o2[i] = o[i];
         if (th_pre) o2[i] = dx_keep(key_pre, (uint32_t)row * C + c0 + i, th_pre) ? o[i] * sc_pre : 0.f;
       }
@@ -289,20 +315,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < L::V; ++i) {
       const int j = k * L::V + i, c = L::col(lane, k) + i;
-      red[wave][0][c] = acc_g[j]; red[wave][1][c] = acc_b[j]; red[wave][2][c] = acc_fg[j]; red[wave][3][c] = acc_fb[j];
+      red[wave][0][c] = acc_g[j]; red[wave][1][c] = acc_b[j];
+      if (FILM) { red[wave][FILM ? 2 : 0][c] = acc_fg[FILM ? j : 0]; red[wave][FILM ? 3 : 0][c] = acc_fb[FILM ? j : 0]; }
     }
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 4 * C && !(a.debug & 1); idx += 256) {
+  for (int idx = threadIdx.x; idx < NRED * C && !(a.debug & 1); idx += 256) {
     const int which = idx / C, c = idx - which * C;
     const float t = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
     if (a.ws) { a.ws[((long)(b * gridDim.x + blockIdx.x) * 4 + which) * C + c] = t; continue; }
     if (which == 0) atomicAdd(a.dgamma + c, t);
     else if (which == 1) atomicAdd(a.dbeta + c, t);
-    else if (a.dfilm) atomicAdd(a.dfilm + (long)b * a.lddf + (which == 3 ? C : 0) + c, t);
+    else atomicAdd(a.dfilm + (long)b * a.lddf + (which == 3 ? C : 0) + c, t);
+  }
+  if (a.ws && !FILM) {   // the finish kernel reads all four slots
+    for (int idx = threadIdx.x; idx < 2 * C; idx += 256) a.ws[((long)(b * gridDim.x + blockIdx.x) * 4 + 2) * C + idx] = 0.f;
   }
 }
-
 // Finishes the per-channel reductions of ln_bwd_kernel from its per-workgroup partial sums (deterministic, no atomics).
 // blocks [0, nA): dgamma / dbeta over all (utterance, chunk) partials; blocks [nA, ...): dfilm[b] over the chunks of b.
 __global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* __restrict__ ws, float* dgamma, float* dbeta, float* dfilm,
@@ -349,10 +378,20 @@ int launch_fwd(const LNArgs& a, int C, hipStream_t s) {
 template <typename TI, typename TG, typename TD>
 int launch_bwd(const LNBwdArgs& a, int C, hipStream_t s) {
   dim3 grid(dx_cdiv(a.N, a.rows_per_block), a.B), block(256);
+  const bool film = a.film != nullptr;
   switch (C) {
-    case 128: hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 128>), grid, block, 0, s, a); break;
-    case 256: hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 256>), grid, block, 0, s, a); break;
-    case 1024: hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 1024>), grid, block, 0, s, a); break;
+    case 128:
+      if (film) hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 128, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 128, false>), grid, block, 0, s, a);
+      break;
+    case 256:
+      if (film) hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 256, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 256, false>), grid, block, 0, s, a);
+      break;
+    case 1024:
+      if (film) hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 1024, true>), grid, block, 0, s, a);   // not on the model's path
+      else hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 1024, false>), grid, block, 0, s, a);
+      break;
     default: dx_set_error("dx_layernorm_bwd: C=%d unsupported (128, 256, 1024)", C); return DX_ERR_UNSUPPORTED;
   }
   if (a.ws) {
