@@ -357,9 +357,234 @@ __global__ __launch_bounds__(NTHREADS, MI == 1 ? DX_CONV_WPS_NARROW : DX_CONV_WP
   }
 }
 
+// ---- weight-stationary variant for short contractions (Cin = 128, Cout a multiple of 256: the FF block's 128 -> 1024
+// conv and the data gradient of its 1024 -> 128 partner).  With K = taps * Cin <= 384 the tiled kernel above spends a
+// workgroup's life waiting: 4 K-chunks of 0.3 us of MFMA work, each behind a ~1.5 us global -> LDS round trip, plus a
+// prologue and an epilogue (measured 26 % MFMA utilisation at 3 workgroups / CU).  Here a 512-thread workgroup owns 256
+// output channels for its lifetime: wave w keeps the weights of channels [32w, 32w + 32) for the WHOLE contraction in
+// registers as ready-made MFMA B fragments (taps * 8 k-steps * 4 VGPRs = 96), so the weights are read once per
+// workgroup instead of once per position tile and never touch LDS.  128-position tiles of the input stream past:
+// the A tile (130 x 128) is double-buffered in LDS, fetched into registers one tile ahead, and shared by the 8 waves;
+// per k-step a wave reads 4 A fragments for 4 MFMAs (128 rows x 32 channels).  One barrier per tile.  The epilogue is
+// wave-private: each wave stages its 64 x 32 block through its own LDS patch and leaves as 16-byte row segments, so no
+// wave waits for another between tiles.  The live position tiles of the batch (skip_lengths) are split evenly over the
+// workgroups of a channel block; dead tiles are zero-filled in a second pass.
+constexpr int WR_THREADS = 512, WR_BN = 256, WR_BM = 128;
+#ifndef WR_ABL
+#define WR_ABL 0   // compile-time ablation (development): 1 no MFMA, 2 no epilogue, 4 no global stores
+#endif
+template <typename TO, typename TG, int TAPS, bool RELU>
+__global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, int ngrp) {
+  typedef bf16_t TC;
+  constexpr int BM = WR_BM, HALO = TAPS / 2, AROWS = BM + TAPS - 1, CIN = 128, LDK = CIN + Pad<TC>::value, KCH = CIN / 8;
+  constexpr int KSTEPS = CIN / 16;
+  constexpr int A_CH = AROWS * KCH, A_PT = (A_CH + WR_THREADS - 1) / WR_THREADS;
+  constexpr int STG_LD = 32 + 4, STG_FLOATS = 64 * STG_LD;
+  constexpr int A_BYTES = AROWS * LDK * (int)sizeof(TC);
+  typedef typename Vec8<TC>::type frag_t;
+  __shared__ __attribute__((aligned(16))) char smem[2 * A_BYTES + 8 * STG_FLOATS * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, g = lane >> 5;
+  float* stage = reinterpret_cast<float*>(smem + 2 * A_BYTES) + wave * STG_FLOATS;
+  const int ztiles = p.Cout / WR_BN, ptiles = dx_cdiv(p.N, BM);
+  const int grp = blockIdx.x / ztiles, co0 = (blockIdx.x % ztiles) * WR_BN + wave * 32;
+  const int N = p.N, Cout = p.Cout;
+  const TC* W = reinterpret_cast<const TC*>(p.w);
+  TO* Y = reinterpret_cast<TO*>(p.y);
+  const TG* G = reinterpret_cast<const TG*>(p.gate);
+
+  // ---- this wave's weights, once: B fragment of k-step (tap, ks) = W[tap][co0 + l31][16 ks + 8 g .. + 8]
+  frag_t wreg[TAPS][KSTEPS];
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+      wreg[tap][ks] = *reinterpret_cast<const frag_t*>(W + ((size_t)tap * Cout + co0 + l31) * CIN + ks * 16 + g * 8);
+  const float bv = p.bias ? p.bias[co0 + l31] : 0.f;
+
+  // ---- this workgroup's share of the live position tiles (flat list over the batch)
+  auto live_of = [&](int b) { return p.skip_len ? min(ptiles, dx_cdiv(min(N, (int)p.skip_len[b] + 2), BM)) : ptiles; };
+  int total = 0;
+  for (int b = 0; b < p.B; ++b) total += live_of(b);
+  const int i0 = (int)((long)total * grp / ngrp), i1 = (int)((long)total * (grp + 1) / ngrp);
+  int b = 0, pt = 0, nlive = 0;
+  for (int cum = 0; b < p.B; ++b) {
+    nlive = live_of(b);
+    if (i0 < cum + nlive) { pt = i0 - cum; break; }
+    cum += nlive;
+  }
+  int left = i1 - i0;
+
+  bf16x8 ra[A_PT];
+  auto fetch = [&](int fb, int fpt) {
+    const TC* X = reinterpret_cast<const TC*>(p.x) + (size_t)fb * N * p.ldx;
+#pragma unroll
+    for (int t = 0; t < A_PT; ++t) {
+      const int c = tid + t * WR_THREADS;
+      const int n = fpt * BM + (c >> 4) - HALO;
+      ra[t] = zero8<TC>();
+      if (c < A_CH && n >= 0 && n < N) ra[t] = *reinterpret_cast<const bf16x8*>(X + (size_t)n * p.ldx + (c & 15) * 8);
+    }
+  };
+  auto commit = [&](int buf) {
+    TC* As = reinterpret_cast<TC*>(smem + buf * A_BYTES);
+#pragma unroll
+    for (int t = 0; t < A_PT; ++t) {
+      const int c = tid + t * WR_THREADS;
+      if (c < A_CH) *reinterpret_cast<bf16x8*>(&As[(c >> 4) * LDK + (c & 15) * 8]) = ra[t];
+    }
+  };
+
+  // Software pipeline inside a wave: the matrix pipe runs asynchronously, so the epilogue of one 64-row half (VALU +
+  // LDS + stores) is issued in slices BETWEEN the MFMAs of the other half:
+  //   phase A(t): MFMAs of rows 0..63 of tile t    ||  epilogue of rows 64..127 of tile t-1
+  //   phase B(t): MFMAs of rows 64..127 of tile t  ||  epilogue of rows 0..63 of tile t
+  // (measured before: MFMA loop 22 us + epilogue 15 us back to back; the two waves of a SIMD ran them in lockstep)
+  struct Epi { size_t base; int n0, len; };   // base = element offset of row n0 of the utterance in y / gate
+  // slice kk (0 .. TAPS*KSTEPS-1) of the epilogue of accumulator pair acc[2h], acc[2h+1] of the tile described by e
+  const int srow = lane >> 2, scl = (lane & 3) * 8;          // this lane's row / channel segment within a 16-row output pass
+  const size_t lane_off = (size_t)srow * p.ldy + co0 + scl;
+  auto epi_slice = [&](int kk, const f32x16* ac, const Epi& e, int h) {
+    constexpr int NS = TAPS * KSTEPS;            // slices available (24 or 8)
+    constexpr int WS = NS >= 24 ? 8 : 2;         // slices that carry the 32 stage writes
+    constexpr int PER = 32 / WS;
+    if (kk < WS) {
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int idx = kk * PER + q, i = idx >> 4, r = idx & 15;
+        float v = ac[i][r] + bv;
+        if (RELU) v = fmaxf(v, 0.f);
+        stage[(i * 32 + dx_acc_row(r, g)) * STG_LD + l31] = v;
+      }
+      if (kk == WS - 1) __builtin_amdgcn_wave_barrier();
+      return;
+    }
+    constexpr int GAP = (NS - WS) / 4;           // one output pass every GAP slices
+    if ((kk - WS) % GAP != 0 || (kk - WS) / GAP >= 4) return;
+    const int pass = (kk - WS) / GAP;
+    const int sr = srow + pass * 16;
+    const int n = e.n0 + h * 64 + sr;
+    if (n < N) {
+      float v[8];
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(&stage[sr * STG_LD + scl]);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(&stage[sr * STG_LD + scl + 4]);
+      v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+      const size_t off = e.base + (size_t)(h * 64 + pass * 16) * p.ldy + lane_off;
+      if (G) {
+        const typename VecN<TG, 8>::type gv = raw_load8<TG>(G + off);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = ((float)gv[q] > 0.f) ? v[q] : 0.f;
+      }
+      if (n >= e.len) {                          // rare (mask_lengths): whole row to zero
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = 0.f;
+      }
+      if (!(WR_ABL & 4)) store8<TO>(Y + off, v);
+    }
+    if (pass == 3) __builtin_amdgcn_wave_barrier();
+  };
+
+  int buf = 0;
+  if (left > 0) {
+    fetch(b, pt);
+    commit(0);
+  }
+  __syncthreads();
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  Epi prev{0, N, 0};   // n0 = N: nothing to store before the first tile
+  while (left > 0) {
+    const Epi cur{((size_t)b * N + (size_t)pt * BM) * p.ldy, pt * BM, p.mask_len ? (int)p.mask_len[b] : N};
+    const TC* As = reinterpret_cast<const TC*>(smem + buf * A_BYTES);
+    --left;
+    if (left > 0) {
+      if (++pt >= nlive) { ++b; pt = 0; nlive = live_of(b); }
+      fetch(b, pt);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // epilogue partner: phase A drains acc[2..3] of the previous tile, phase B drains acc[0..1] of this tile
+      const Epi& ep = h == 0 ? prev : cur;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h * 2 + i][r] = 0.f;   // drained one phase ago
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          frag_t a[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const frag_t*>(&As[(h * 64 + i * 32 + l31 + tap) * LDK + ks * 16 + g * 8]);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) { if (!(WR_ABL & 1)) dx_mma(acc[h * 2 + i], a[i], wreg[tap][ks]); }
+          if (!(WR_ABL & 2)) epi_slice(tap * KSTEPS + ks, &acc[h == 0 ? 2 : 0], ep, h == 0 ? 1 : 0);
+        }
+      }
+    }
+    prev = cur;
+    if (left > 0) commit(buf ^ 1);
+    buf ^= 1;
+    __syncthreads();
+  }
+  {   // drain: rows 64..127 of the last tile
+#pragma unroll
+    for (int kk = 0; kk < TAPS * KSTEPS; ++kk) epi_slice(kk, &acc[2], prev, 1);
+  }
+
+  // ---- dead tiles (start past length + conv halo): zeros, no reads; split evenly like the live ones
+  if (p.skip_len) {
+    const int cblk = (blockIdx.x % ztiles) * WR_BN;
+    const int dead = ptiles * p.B - total;
+    const int j0 = (int)((long)dead * grp / ngrp), j1 = (int)((long)dead * (grp + 1) / ngrp);
+    int db = 0, dpt = 0, cum = 0;
+    for (; db < p.B; ++db) {
+      const int nd = ptiles - live_of(db);
+      if (j0 < cum + nd) { dpt = live_of(db) + (j0 - cum); break; }
+      cum += nd;
+    }
+    const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = j0; j < j1; ++j) {
+      for (int c = tid; c < BM * (WR_BN / 8); c += WR_THREADS) {
+        const int n = dpt * BM + (c >> 5), co = cblk + (c & 31) * 8;
+        if (n < N) store8<TO>(Y + ((size_t)db * N + n) * p.ldy + co, z);
+      }
+      if (++dpt >= ptiles) { ++db; while (db < p.B && live_of(db) >= ptiles) ++db; dpt = db < p.B ? live_of(db) : 0; }
+    }
+  }
+}
+
+// weight-stationary dispatch: bf16 operands, plain row-major vectorised output, no fused LayerNorm / accumulate
+template <typename TA, typename TC, typename TO, typename TG>
+bool try_weight_stationary(const ConvArgs& a, int B, int taps, hipStream_t s) {
+  if constexpr (sizeof(TC) != 2 || sizeof(TA) != 2) return false;
+  else {
+    static int enabled = getenv("DX_CONV_WST") ? atoi(getenv("DX_CONV_WST")) : 1;
+    if (!enabled || a.ln.enabled || (a.flags & (DX_CONV_TRANSPOSED_OUT | DX_CONV_ACCUMULATE))) return false;
+    if (a.Cin != 128 || a.Cout % WR_BN || a.ldy % 8 || a.ldx % 8) return false;
+    const int ztiles = a.Cout / WR_BN;
+    // about one workgroup per CU; more position groups than tiles only adds weight loads
+    const long tiles = (long)dx_cdiv(a.N, WR_BM) * B;
+    int ngrp = 256 / ztiles;
+    if (ngrp > tiles) ngrp = (int)tiles;
+    if (ngrp < 1) ngrp = 1;
+    dim3 grid(ngrp * ztiles), block(WR_THREADS);
+    const bool relu = a.flags & DX_CONV_RELU;
+    if (taps == 3 && relu) hipLaunchKernelGGL((conv_wreg_kernel<TO, TG, 3, true>), grid, block, 0, s, a, ngrp);
+    else if (taps == 3) hipLaunchKernelGGL((conv_wreg_kernel<TO, TG, 3, false>), grid, block, 0, s, a, ngrp);
+    else if (relu) hipLaunchKernelGGL((conv_wreg_kernel<TO, TG, 1, true>), grid, block, 0, s, a, ngrp);
+    else hipLaunchKernelGGL((conv_wreg_kernel<TO, TG, 1, false>), grid, block, 0, s, a, ngrp);
+    return true;
+  }
+}
+
 template <typename TA, typename TC, typename TO, typename TG>
 int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
   const int ztiles = dx_cdiv(a.Cout, BN);
+  if (try_weight_stationary<TA, TC, TO, TG>(a, B, taps, s)) { DX_LAUNCH_CHECK(); return DX_OK; }
   const int mi = ztiles == 1 ? 1 : 2;                       // 64-row tiles for the narrow-output GEMMs
   const long ptiles = (long)dx_cdiv(a.N, 64 * mi) * B;
   dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * ztiles)), block(NTHREADS);
