@@ -69,6 +69,7 @@ __global__ __launch_bounds__(128) void scalar_embed_bwd_kernel(ScalarEmbedBwdArg
   float aw[3][3], ab[3];
 #pragma unroll
   for (int f = 0; f < 3; ++f) { ab[f] = 0.f; aw[f][0] = aw[f][1] = aw[f][2] = 0.f; }
+#pragma unroll 4
   for (int n = n0; n < n1; ++n) {
     const long row = (long)b * a.N + n;
     const float g = n < len ? a.dout[row * C128 + c] : 0.f;
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(256) void linear_small_bwd_dx_kernel(const float* _
     const long m = i / K; const int k = (int)(i - m * K);
     float acc = 0.f;
     if (!mask_len || (int)(m % N) < (int)mask_len[m / N]) {
+#pragma unroll 8
       for (int o = o0; o < o1; ++o) {
         float g = dy[m * O + o];
         if (relu && !(y[m * O + o] > 0.f)) g = 0.f;
@@ -263,6 +265,7 @@ __global__ __launch_bounds__(256) void linear_small_bwd_dw_kernel(const float* _
   const int o = (int)(idx / K), k = (int)(idx - (long)o * K);
   const long m0 = (long)blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
   float acc = 0.f, accb = 0.f;
+#pragma unroll 8
   for (long m = m0; m < m1; ++m) {
     if (mask_len && (int)(m % N) >= (int)mask_len[m / N]) continue;
     float g = dy[m * O + o];
@@ -319,7 +322,7 @@ extern "C" int dx_scalar_embed_bwd(const float* dout, const float* const* feats,
   a.dout = dout; a.nfeat = nfeat; a.lengths = lengths; a.dbase = dbase; a.N = N;
   // every workgroup ends with 512-1024 atomics on the same few addresses: few, fat workgroups
   int rpb = 32;
-  while (rpb < 1024 && (long)dx_cdiv(N, rpb) * B > 512) rpb *= 2;
+  while (rpb < 1024 && (long)dx_cdiv(N, rpb) * B > 2048) rpb *= 2;   // ~6 two-wave workgroups per CU: the row loop is latency bound
   a.rows_per_block = rpb;
   for (int f = 0; f < nfeat; ++f) { a.feat[f] = feats[f]; a.dw[f] = dws[f]; a.dbias[f] = dbiases[f]; }
   hipLaunchKernelGGL(scalar_embed_bwd_kernel, dim3(dx_cdiv(N, rpb), B), dim3(128), 0, (hipStream_t)stream, a);

@@ -56,20 +56,30 @@ __global__ __launch_bounds__(256) void gu_prepare_kernel(PrepArgs a) {
   }
 }
 
-// ---------------------------------------------------------------- means: exact int64 prefix sums (one thread per utterance)
-__global__ void gu_means_kernel(const int64_t* __restrict__ dur_int, float* __restrict__ means, int64_t* __restrict__ totals,
-                                int B, int L) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  int64_t cum = 0;
-  for (int l = 0; l < L; ++l) {
-    const int64_t d = dur_int[(long)b * L + l];
-    float mu = (float)d / 2.f;
-    if (l > 0) mu += (float)cum;
-    means[(long)b * L + l] = mu;
-    cum += d;
+// ---------------------------------------------------------------- means: exact int64 prefix sums (one wave per utterance)
+// mu[l] = d[l] / 2 + sum_{k<l} d[k]   (`model.py:632-640`: cumsum of the integer durations, centre of each segment)
+__global__ __launch_bounds__(64) void gu_means_kernel(const int64_t* __restrict__ dur_int, float* __restrict__ means,
+                                                       int64_t* __restrict__ totals, int B, int L) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  long long carry = 0;
+  for (int l0 = 0; l0 < L; l0 += 64) {
+    const int l = l0 + lane;
+    const long long d = l < L ? (long long)dur_int[(long)b * L + l] : 0;
+    long long incl = d;                       // inclusive wave scan, exact in int64
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const long long up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    const long long excl = carry + incl - d;
+    if (l < L) {
+      float mu = (float)d / 2.f;
+      if (l > 0) mu += (float)excl;
+      means[(long)b * L + l] = mu;
+    }
+    carry += __shfl(incl, 63, 64);
   }
-  totals[b] = cum;
+  if (lane == 0) totals[b] = carry;
 }
 
 // ---------------------------------------------------------------- upsample forward
@@ -294,7 +304,7 @@ extern "C" int dx_gu_prepare(const float* enc, const float* dur_float, const flo
 
 extern "C" int dx_gu_means(const int64_t* durations_int, float* means, int64_t* totals, int B, int L, void* stream) {
   DX_REQUIRE(durations_int && means && totals, DX_ERR_ARG, "dx_gu_means: null pointer");
-  hipLaunchKernelGGL(gu_means_kernel, dim3(dx_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, durations_int, means, totals, B, L);
+  hipLaunchKernelGGL(gu_means_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, durations_int, means, totals, B, L);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
