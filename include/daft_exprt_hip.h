@@ -74,10 +74,11 @@ int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_packed, int
 int dx_pack_conv_weight(const float* w, void* out, int out_dtype, int Cout, int Cin, int taps, int transpose_flip,
                         void* stream);
 /* Every GEMM weight of the model in one launch.  descs_dev: DEVICE array of n records
- * {const float* w; void* out; int Cout, Cin, taps, transpose_flip; long begin;} (dx_pack_desc_size() bytes each, begin =
- * running sum of Cout*Cin*taps); total_elems = sum of all element counts. */
+ * {const float* w; void* out; int Cout, Cin, taps, transpose_flip; long begin;} (dx_pack_desc_size() bytes each); a
+ * workgroup packs one 32 (Cout) x 32 (Cin) brick of one weight (all taps): begin = running sum of
+ * ceil(Cout / 32) * ceil(Cin / 32) over the records before this one, total_bricks = that sum over all records. */
 int dx_pack_desc_size(void);
-int dx_pack_conv_weights_batched(const void* descs_dev, int n, long total_elems, int out_dtype, void* stream);
+int dx_pack_conv_weights_batched(const void* descs_dev, int n, long total_bricks, int out_dtype, void* stream);
 
 /* Weight / bias gradient of dx_conv1d (and of nn.Linear with taps = 1), accumulated into dw (Cout, Cin, taps)
  * [PyTorch layout, fp32] and db (Cout) [NULL to skip]:

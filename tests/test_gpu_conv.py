@@ -81,3 +81,65 @@ def test_pack_transpose_flip_is_conv_data_gradient():
     dx = ops.conv1d(dy.to(dev), wd, None)
     torch.cuda.synchronize()
     assert (dx.cpu() - x.grad).abs().max().item() < 2e-5 * x.grad.abs().max().item() + 1e-5
+
+
+DEV = torch.device('cuda:0')
+
+
+def test_batched_weight_pack_matches_single_pack():
+    ''' every brick edge case of dx_pack_conv_weights_batched: channel counts below / not a multiple of the 32-wide brick,
+        both tap counts, both layouts, fp32 and bf16 operands '''
+    from daft_exprt import ops
+    g = torch.Generator().manual_seed(3)
+    shapes = [(80, 128, 1), (200, 80, 3), (8, 8, 3), (1024, 128, 3), (33, 40, 1), (128, 1024, 3)]
+    for dtype in (torch.bfloat16, torch.float32):
+        ws = [torch.randn((co, ci, t) if t > 1 else (co, ci), generator=g).to(DEV) for co, ci, t in shapes]
+        entries, refs = [], []
+        for w, (co, ci, t) in zip(ws, shapes):
+            for tf in (False, True):
+                out = torch.full((t, ci, co) if tf else (t, co, ci), float('nan'), dtype=dtype, device=DEV)
+                entries.append((w, out, tf))
+                refs.append(ops.pack_conv_weight(w, dtype, transpose_flip=tf))
+        table = ops.pack_table(entries, DEV)
+        ops.pack_weights_batched(*table, dtype)
+        for (w, out, tf), ref in zip(entries, refs):
+            assert torch.equal(out, ref), (tuple(w.shape), tf, dtype)
+
+
+@pytest.mark.parametrize('taps', [1, 3])
+@pytest.mark.parametrize('shape', [(3, 300, 512), (1, 77, 256), (5, 128, 1024), (48, 129, 256), (2, 1000, 1024)])
+def test_conv_weights_in_registers_kernel(shape, taps):
+    ''' the Cin = 128 / Cout % 256 == 0 bf16 path (conv_wreg_kernel): ragged N, single utterance, more workgroups than
+        position tiles, ReLU, gate, mask_lengths, and skip_lengths with dead tiles (written as zeros, live rows = full conv) '''
+    from daft_exprt import ops
+    B, N, Cout = shape
+    g = torch.Generator().manual_seed(B * 1000 + N + taps)
+    x = torch.randn(B, N, 128, generator=g)
+    w = torch.randn(Cout, 128, taps, generator=g) / (128 * taps) ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    lens = torch.randint(1, N + 1, (B,), generator=g)
+    lens[0] = N if B > 1 else max(1, N // 3)
+    gate = torch.randn(B, N, Cout, generator=g)
+    xb = x.to(DEV).to(torch.bfloat16)
+    full = O.conv1d_cl(xb.float().cpu(), w.to(torch.bfloat16).float(), bias)
+    wp = ops.pack_conv_weight(w.to(DEV), torch.bfloat16)
+    n_idx = torch.arange(N)[None, :, None]
+    cases = [dict(relu=True), dict(gate=True), dict(mask=True, relu=True), dict(skip=True), dict(skip=True, gate=True, out=torch.float32)]
+    for c in cases:
+        od = c.get('out', torch.bfloat16)
+        ref = torch.relu(full) if c.get('relu') else full
+        if c.get('gate'):
+            ref = ref * (gate > 0)
+        if c.get('mask'):
+            ref = ref * (n_idx < lens[:, None, None])
+        y = ops.conv1d(xb, wp, bias.to(DEV), out_dtype=od, relu=bool(c.get('relu')),
+                       relu_gate=gate.to(DEV).to(od) if c.get('gate') else None,
+                       mask_lengths=lens.to(DEV) if c.get('mask') else None,
+                       skip_lengths=lens.to(DEV) if c.get('skip') else None).float().cpu()
+        scale = float(full.abs().max())
+        if c.get('skip'):   # tiles that start at or past len + 2 are zeros; everything before them is the full convolution
+            dead = (n_idx // 128) * 128 >= (lens[:, None, None] + 2)
+            assert float((y * dead).abs().max()) == 0., c
+            ref = ref * (~dead)
+        tol = (1e-2 if od == torch.bfloat16 else 1e-4) * scale    # operands are pre-rounded: only the output rounding remains
+        assert float((y - ref).abs().max()) <= tol, (shape, taps, c, float((y - ref).abs().max()), tol)

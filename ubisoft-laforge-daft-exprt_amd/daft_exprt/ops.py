@@ -99,7 +99,7 @@ def conv1d_ln(x, w_packed, bias, residual, gamma, beta, lengths, film=None, save
 
 
 def pack_table(entries, device):
-    ''' entries: [(w fp32 tensor, out tensor, transpose_flip)] -> (device descriptor table, n, total_elems) for
+    ''' entries: [(w fp32 tensor, out tensor, transpose_flip)] -> (device descriptor table, n, total_bricks) for
         pack_weights_batched (one launch for every GEMM weight of the model) '''
     import numpy as np
     dt = np.dtype([('w', '<u8'), ('out', '<u8'), ('Cout', '<i4'), ('Cin', '<i4'), ('taps', '<i4'), ('tf', '<i4'), ('begin', '<i8')])
@@ -108,7 +108,7 @@ def pack_table(entries, device):
     for i, (w, out, tf) in enumerate(entries):
         taps = w.shape[2] if w.dim() == 3 else 1
         arr[i] = (w.data_ptr(), out.data_ptr(), w.shape[0], w.shape[1], taps, int(tf), begin)
-        begin += w.numel()
+        begin += ((w.shape[0] + 31) // 32) * ((w.shape[1] + 31) // 32)   # 32 x 32 bricks, see dx_pack_conv_weights_batched
     table = torch.from_numpy(arr.view(np.uint8).copy()).to(device)
     return table, len(entries), begin
 
