@@ -964,10 +964,16 @@ extern "C" int dx_pack_conv_weight(const float* w, void* out, int out_dtype, int
 
 // number of workgroup splits of the position axis for a wgrad problem (shared by the launcher and the workspace query)
 static int wgrad_nsplit(int B, int N, int Cin, int Cout) {
-  static int target = getenv("DX_WGRAD_BLOCKS") ? atoi(getenv("DX_WGRAD_BLOCKS")) : 256;
+  // Workgroup target: the weight gradients run on a side stream UNDER the data-gradient chain, so the question is not
+  // how fast they finish alone but how little they slow the main stream down.  Measured per training step (B = 48,
+  // T <= 1000): 384 -> 10.97 ms, 256 -> 10.77, 128 -> 10.59, 96 -> 10.57, 64 -> 10.56, 48 -> 11.24, 32 -> 13.1:
+  // ~96 fat 8-wave workgroups (fewer partial tiles, 5/8 of the CUs left to the GEMM / attention kernels) win.
+  // The side stream's share must grow with the batch or it becomes the critical path (B = 128: 256 -> 22.8 ms, 96 -> 23.2).
+  static int fixed = getenv("DX_WGRAD_BLOCKS") ? atoi(getenv("DX_WGRAD_BLOCKS")) : 0;
+  const long rows = (long)B * N;
+  const int target = fixed > 0 ? fixed : (int)(rows <= 48000 ? 96 : (rows >= 128000 ? 256 : 96 + (rows - 48000) / 500));
   const int tiles = dx_cdiv(Cout, WG_CO) * dx_cdiv(Cin, WG_CI);
-  // enough workgroups to occupy the chip, but every split costs one more partial tile to write and re-read:
-  // keep >= ~4 items (128 positions each) of work per workgroup
+  // every split costs one more partial tile to write and re-read: keep >= ~4 items (128 positions each) per workgroup
   int ns = target / tiles;
   const long by_work = (long)B * dx_cdiv(N, WG_ITEM) / 4;
   if (ns > by_work) ns = (int)by_work;
