@@ -602,19 +602,19 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
 // ---- weight gradient ------------------------------------------------------------------------
 //   dW[co][ci][tap] += sum_{b, n} dY[b, n, co] * X[b, n + tap - taps/2, ci]        (fp32, PyTorch layout)
 //   db[co]          += sum_{b, n} dY[b, n, co]
-// GEMM with the positions as the contraction axis.  A 512-thread workgroup owns a 128 (co) x 64 (ci) x taps output
-// tile and a contiguous range of the flat list of 128-position items of the batch (split-K balanced over the VALID rows
-// of the batch, not over utterances: lengths differ by 10x inside a batch).  Its 8 waves form two groups of 4; group q
-// contracts rows [64q, 64q + 64) of every item from its own LDS stage, so a CU has 2 waves / SIMD and twice the loads
-// in flight for the same number of partial tiles.  Per item the dY tile [64][128] and the haloed X tile [66][64] of
-// each group are staged in LDS in their natural row-major layout; both MFMA operands need "8 consecutive positions for
-// one channel", which the LDS transpose read (ds_read_b64_tr_b16, gather8) delivers without a software transpose; all
-// taps reuse the same X tile at a row offset.  Wave (wm, wn) of a group accumulates 64 co x 32 ci x taps = 2*taps MFMA
-// 32x32 tiles.  At the end group 1 hands its accumulators to group 0 through LDS, and group 0 writes the partial tile to
-// a workspace in register order (coalesced); wgrad_reduce_kernel sums the partials of all splits into dW -- a fixed
-// summation order, no fp32 atomics on dW (measured: the atomics were 1/3 of the kernel).  Without a workspace the
-// partial tile is added with atomics.
-constexpr int WG_CO = 128, WG_CI = 64, WG_P = 64, WG_ITEM = 2 * WG_P, WG_THREADS = 512;
+// GEMM with the positions as the contraction axis.  These kernels are bound by streaming their operands: every output
+// tile re-reads the rows of dY and X it contracts, so the tile is as large as the accumulators allow -- a 512-thread
+// workgroup owns 128 (co) x 128 (ci) x taps outputs (wave (wm, wn) of 2 x 4 holds 64 co x 32 ci x taps = 2*taps MFMA
+// 32x32 tiles), which for the 128 <-> 1024 convolutions reads the wide operand ONCE and the narrow one 8 times (the
+// first version's 128 x 64 tiles: 2 and 16 times).  The flat list of VALID 64-row items of the batch is split evenly
+// over the workgroups of a tile (split-K balanced over valid rows, not utterances: lengths differ by 10x inside a batch).
+// Per item the dY tile [64][128] and the haloed X tile [66][128] are staged in LDS in their natural row-major layout
+// (fetched into registers one item ahead); both MFMA operands need "8 consecutive positions for one channel", which the
+// LDS transpose read (ds_read_b64_tr_b16, gather8) delivers without a software transpose; all taps reuse the same X
+// tile at a row offset.  The partial tile goes to a workspace in register order (coalesced) and wgrad_reduce_kernel
+// sums the partials of all splits into dW -- a fixed summation order, no fp32 atomics on dW (measured: the atomics
+// were 1/3 of the kernel).  Without a workspace the partial tile is added with atomics.
+constexpr int WG_CO = 128, WG_CI = 128, WG_P = 64, WG_THREADS = 512;
 
 struct WgradArgs {
   const void* dy; long lddy; const void* x; long ldx;
@@ -629,27 +629,22 @@ template <typename TC, int TAPS> struct WgradSmem {
   // transpose read (ds_read_b64_tr_b16) then fall on 64 distinct banks
   static constexpr int LDA = WG_CO + 4 * Pad<TC>::value, LDB = WG_CI + 4 * Pad<TC>::value;
   static constexpr int A_ELEMS = WG_P * LDA, B_ELEMS = XROWS * LDB;
-  static constexpr int STAGE_BYTES = 2 * (A_ELEMS + B_ELEMS) * (int)sizeof(TC);
-  static constexpr int TILE_FLOATS = TAPS * 2 * 16 * 256;          // one partial tile in register order
-  static constexpr int BYTES = STAGE_BYTES > TILE_FLOATS * 4 ? STAGE_BYTES : TILE_FLOATS * 4;
+  static constexpr int TILE_FLOATS = TAPS * 2 * 16 * WG_THREADS;   // one partial tile in register order
 };
 
-// The 128-position items of a workgroup form one flat sequence; the global loads of item k+1 are issued into
-// registers (raw element types) before the MFMAs of item k and converted when written to LDS.
 template <typename TA, typename TB, typename TC, int TAPS>
 __global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(WgradArgs p) {
   typedef WgradSmem<TC, TAPS> SM;
   constexpr int HALO = TAPS / 2, XROWS = SM::XROWS, LDA = SM::LDA, LDB = SM::LDB;
-  constexpr int A_PT = WG_ITEM * (WG_CO / 8) / WG_THREADS;                       // 4
-  constexpr int B_CH = 2 * XROWS * (WG_CI / 8), B_PT = (B_CH + WG_THREADS - 1) / WG_THREADS;
+  constexpr int A_PT = WG_P * (WG_CO / 8) / WG_THREADS;                                 // 2
+  constexpr int B_CH = XROWS * (WG_CI / 8), B_PT = (B_CH + WG_THREADS - 1) / WG_THREADS;
   typedef typename Vec8<TC>::type frag_t;
   typedef typename VecN<TA, 8>::type rawa_t;
   typedef typename VecN<TB, 8>::type rawb_t;
-  __shared__ __attribute__((aligned(16))) char smem[SM::BYTES];
+  __shared__ __attribute__((aligned(16))) TC dYs[SM::A_ELEMS];
+  __shared__ __attribute__((aligned(16))) TC Xs[SM::B_ELEMS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
-  const int grp = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1, tig = tid & 255;
-  TC* dYs = reinterpret_cast<TC*>(smem) + grp * SM::A_ELEMS;
-  TC* Xs = reinterpret_cast<TC*>(smem) + 2 * SM::A_ELEMS + grp * SM::B_ELEMS;
+  const int wm = wave >> 2, wn = wave & 3;
   const int ntiles = dx_cdiv(p.Cout, WG_CO) * p.tiles_ci;
   const int split = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
   const int co0 = (tile / p.tiles_ci) * WG_CO, ci0 = (tile % p.tiles_ci) * WG_CI;
@@ -658,13 +653,13 @@ __global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wg
   // rows beyond len + halo carry exactly-zero gradients (masked upstream): not part of the item list
   auto nlim_of = [&](int b) { return p.lengths ? min(N, (int)p.lengths[b] + 2) : N; };
   int total = 0;
-  for (int b = 0; b < p.B; ++b) total += dx_cdiv(nlim_of(b), WG_ITEM);
+  for (int b = 0; b < p.B; ++b) total += dx_cdiv(nlim_of(b), WG_P);
   const int i0 = (int)((long)total * split / p.nsplit), i1 = (int)((long)total * (split + 1) / p.nsplit);
   int b = 0, n0 = 0, nlim = 0;
   for (int cum = 0; b < p.B; ++b) {                 // locate item i0
     nlim = nlim_of(b);
-    const int c = dx_cdiv(nlim, WG_ITEM);
-    if (i0 < cum + c) { n0 = (i0 - cum) * WG_ITEM; break; }
+    const int c = dx_cdiv(nlim, WG_P);
+    if (i0 < cum + c) { n0 = (i0 - cum) * WG_P; break; }
     cum += c;
   }
   int left = i1 - i0;
@@ -704,8 +699,7 @@ __global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wg
 #pragma unroll
     for (int t = 0; t < B_PT; ++t) {
       const int c = tid + t * WG_THREADS;
-      const int q = c / (XROWS * 8), cc = c - q * (XROWS * 8);
-      const int n = fn0 + q * WG_P + (cc >> 3) - HALO, ci = ci0 + (cc & 7) * 8;
+      const int n = fn0 + (c >> 4) - HALO, ci = ci0 + (c & 15) * 8;
 #pragma unroll
       for (int e = 0; e < 8; ++e) rb[t][e] = (TB)0.f;
       // x rows > flim only ever meet zero dy rows
@@ -713,19 +707,15 @@ __global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wg
     }
   };
   auto commit = [&]() {
-    TC* A = reinterpret_cast<TC*>(smem);
-    TC* Bm = reinterpret_cast<TC*>(smem) + 2 * SM::A_ELEMS;
 #pragma unroll
     for (int t = 0; t < A_PT; ++t) {
       const int c = tid + t * WG_THREADS;
-      const int r = c >> 4;
-      *reinterpret_cast<frag_t*>(&A[(r >> 6) * SM::A_ELEMS + (r & 63) * LDA + (c & 15) * 8]) = cvt8<TA, TC>(ra[t]);
+      *reinterpret_cast<frag_t*>(&dYs[(c >> 4) * LDA + (c & 15) * 8]) = cvt8<TA, TC>(ra[t]);
     }
 #pragma unroll
     for (int t = 0; t < B_PT; ++t) {
       const int c = tid + t * WG_THREADS;
-      const int q = c / (XROWS * 8), cc = c - q * (XROWS * 8);
-      if (c < B_CH) *reinterpret_cast<frag_t*>(&Bm[q * SM::B_ELEMS + (cc >> 3) * LDB + (cc & 7) * 8]) = cvt8<TB, TC>(rb[t]);
+      if (c < B_CH) *reinterpret_cast<frag_t*>(&Xs[(c >> 4) * LDB + (c & 15) * 8]) = cvt8<TB, TC>(rb[t]);
     }
   };
 
@@ -735,14 +725,13 @@ __global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wg
     __syncthreads();
   }
   while (left > 0) {
-    const bool live = n0 + grp * WG_P < nlim;       // this group's 64 rows hold at least one non-zero dy row
     --left;
     if (left > 0) {                                 // next item
-      n0 += WG_ITEM;
+      n0 += WG_P;
       if (n0 >= nlim) { ++b; n0 = 0; nlim = nlim_of(b); }
       fetch(b, n0, nlim);
     }
-    if (live && !(p.debug & 2))
+    if (!(p.debug & 2))
 #pragma unroll
     for (int ks = 0; ks < WG_P / 16; ++ks) {
       const int kA = ks * 16 + 8 * g, kB = kA + 4;
@@ -765,18 +754,7 @@ __global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wg
       __syncthreads();
     }
   }
-  // ---- group 1 -> LDS -> group 0 (the stages are dead after the loop's last barrier)
-  float* red = reinterpret_cast<float*>(smem);
-  if (grp == 1) {
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[((t * 2 + i) * 16 + r) * 256 + tig] = acc[t][i][r];
-  }
-  __syncthreads();
-  if (grp == 0 && !(p.debug & 1)) {
+  if (!(p.debug & 1)) {
     if (p.ws) {
       float* out = p.ws + ((size_t)split * ntiles + tile) * SM::TILE_FLOATS;
 #pragma unroll
@@ -784,10 +762,7 @@ __global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wg
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int slot = ((t * 2 + i) * 16 + r) * 256 + tig;
-            out[slot] = acc[t][i][r] + red[slot];
-          }
+          for (int r = 0; r < 16; ++r) out[((t * 2 + i) * 16 + r) * WG_THREADS + tid] = acc[t][i][r];
     } else {
       const int ci = ci0 + wn * 32 + l31;
       if (ci < Cin) {
@@ -798,12 +773,12 @@ __global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wg
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int co = co0 + wm * 64 + i * 32 + dx_acc_row(r, g);
-              if (co < Cout) atomicAdd(p.dw + ((size_t)co * Cin + ci) * TAPS + t, acc[t][i][r] + red[((t * 2 + i) * 16 + r) * 256 + tig]);
+              if (co < Cout) atomicAdd(p.dw + ((size_t)co * Cin + ci) * TAPS + t, acc[t][i][r]);
             }
       }
     }
   }
-  if (do_bias && l31 == 0) {   // every column of bacc holds the same row sums; column 0 publishes them (both groups)
+  if (do_bias && l31 == 0) {   // every column of bacc holds the same row sums; column 0 publishes them
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -816,15 +791,15 @@ __global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wg
 
 // dW += sum over the splits of the partial tiles (register order, see conv_wgrad_kernel); one thread per tile element
 template <int TAPS>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
-                                                           int ntiles, int tiles_ci, int Cout, int Cin) {
-  constexpr int TILE_FLOATS = TAPS * 2 * 16 * 256;
-  const int tile = blockIdx.x / (TAPS * 32), slot = blockIdx.x % (TAPS * 32), tig = threadIdx.x;
+__global__ __launch_bounds__(WG_THREADS) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
+                                                                  int ntiles, int tiles_ci, int Cout, int Cin) {
+  constexpr int TILE_FLOATS = TAPS * 2 * 16 * WG_THREADS;
+  const int tile = blockIdx.x / (TAPS * 32), slot = blockIdx.x % (TAPS * 32), tid = threadIdx.x;
   const int t = slot / 32, i = (slot >> 4) & 1, r = slot & 15;
-  const int lane = tig & 63, w4 = tig >> 6, wm = w4 >> 1, wn = w4 & 1;
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
   const int co = (tile / tiles_ci) * WG_CO + wm * 64 + i * 32 + dx_acc_row(r, lane >> 5);
   const int ci = (tile % tiles_ci) * WG_CI + wn * 32 + (lane & 31);
-  const float* src = ws + (size_t)tile * TILE_FLOATS + slot * 256 + tig;
+  const float* src = ws + (size_t)tile * TILE_FLOATS + slot * WG_THREADS + tid;
   float s0 = 0.f, s1 = 0.f;
   int k = 0;
   for (; k + 1 < nsplit; k += 2) {
@@ -842,11 +817,11 @@ int launch_wgrad(const WgradArgs& a, int taps, hipStream_t s) {
   if (taps == 1) {
     hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 1>), grid, block, 0, s, a);
     if (a.ws && !(a.debug & 1))
-      hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(ntiles * 32), dim3(256), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
+      hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(ntiles * 32), dim3(WG_THREADS), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
   } else {
     hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 3>), grid, block, 0, s, a);
     if (a.ws && !(a.debug & 1))
-      hipLaunchKernelGGL((wgrad_reduce_kernel<3>), dim3(ntiles * 96), dim3(256), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
+      hipLaunchKernelGGL((wgrad_reduce_kernel<3>), dim3(ntiles * 96), dim3(WG_THREADS), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
   }
   DX_LAUNCH_CHECK();
   return DX_OK;
@@ -965,17 +940,15 @@ extern "C" int dx_pack_conv_weight(const float* w, void* out, int out_dtype, int
 // number of workgroup splits of the position axis for a wgrad problem (shared by the launcher and the workspace query)
 static int wgrad_nsplit(int B, int N, int Cin, int Cout) {
   // Workgroup target: the weight gradients run on a side stream UNDER the data-gradient chain, so the question is not
-  // how fast they finish alone but how little they slow the main stream down.  Measured per training step (B = 48,
-  // T <= 1000): 384 -> 10.97 ms, 256 -> 10.77, 128 -> 10.59, 96 -> 10.57, 64 -> 10.56, 48 -> 11.24, 32 -> 13.1:
-  // ~96 fat 8-wave workgroups (fewer partial tiles, 5/8 of the CUs left to the GEMM / attention kernels) win.
-  // The side stream's share must grow with the batch or it becomes the critical path (B = 128: 256 -> 22.8 ms, 96 -> 23.2).
+  // how fast they finish alone but how little they slow the main stream down.  Measured per training step with the
+  // 128 x 128 tiles (B = 48, T <= 1000): 64 -> 10.73 ms, 128 -> 10.46, 160 -> 10.45, 192 -> 10.30, 224 -> 10.35,
+  // 256 -> 10.42, 320 -> 10.69; B = 128: 192 -> 22.1, 256 -> 22.5, 384 -> 23.2.  3/4 of the CUs, 8 waves each.
   static int fixed = getenv("DX_WGRAD_BLOCKS") ? atoi(getenv("DX_WGRAD_BLOCKS")) : 0;
-  const long rows = (long)B * N;
-  const int target = fixed > 0 ? fixed : (int)(rows <= 48000 ? 96 : (rows >= 128000 ? 256 : 96 + (rows - 48000) / 500));
+  const int target = fixed > 0 ? fixed : 192;
   const int tiles = dx_cdiv(Cout, WG_CO) * dx_cdiv(Cin, WG_CI);
-  // every split costs one more partial tile to write and re-read: keep >= ~4 items (128 positions each) per workgroup
+  // every split costs one more partial tile to write and re-read: keep >= ~8 items (64 positions each) per workgroup
   int ns = target / tiles;
-  const long by_work = (long)B * dx_cdiv(N, WG_ITEM) / 4;
+  const long by_work = (long)B * dx_cdiv(N, WG_P) / 8;
   if (ns > by_work) ns = (int)by_work;
   return ns < 1 ? 1 : ns;
 }
@@ -983,7 +956,7 @@ static int wgrad_nsplit(int B, int N, int Cin, int Cout) {
 extern "C" long dx_conv1d_wgrad_ws_floats(int B, int N, int Cin, int Cout, int taps) {
   if (B <= 0 || N <= 0 || Cin <= 0 || Cout <= 0 || (taps != 1 && taps != 3)) return 0;
   const long tiles = (long)dx_cdiv(Cout, WG_CO) * dx_cdiv(Cin, WG_CI);
-  return (long)wgrad_nsplit(B, N, Cin, Cout) * tiles * taps * 2 * 16 * 256;
+  return (long)wgrad_nsplit(B, N, Cin, Cout) * tiles * taps * 2 * 16 * WG_THREADS;
 }
 
 extern "C" int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const void* x, int x_dtype, long ldx,
