@@ -68,6 +68,21 @@ int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_packed, int
                  const int64_t* lengths, float* y, void* y_lp, float* s_out, float* mean, float* rstd, int B, int N,
                  int Cin, int taps, float p_pre, uint64_t seed_pre, void* stream);
 
+/* Data gradient of a conv / linear INTO a 128-channel residual stream, fused with the BACKWARD of the LayerNorm that
+ * consumed that stream in the forward pass (autograd of model.py:189-191 resp. 226-235 + 259/262, i.e. what
+ * dx_conv1d(..., ACCUMULATE) followed by dx_layernorm_bwd compute in two launches and two extra passes over the tensor):
+ *   g  = y_inout + conv(x, w_packed)            (x = gradient of the conv's output, w_packed = transpose_flip packing)
+ *   g  = 0 where n >= lengths[b];  FiLM: dfilm[b] += (sum_n g * LN, sum_n g), g *= film_gamma[b]
+ *   dgamma += sum g * xhat, dbeta += sum g;  ds = rstd * (g*gamma - mean_c(g*gamma) - xhat * mean_c(g*gamma*xhat))
+ *   y_inout <- ds (fp32, the residual gradient that flows on);  dx_pre_lp <- dropout_pre(ds) as bf16 (MFMA operand of the
+ *   previous layer's data / weight gradient).   s_in / mean / rstd: saved by dx_conv1d_ln / dx_layernorm_fwd.
+ * Cout is 128 by construction.  lengths also drives the padding early-out (rows >= lengths[b] + 2 stay zero). */
+int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, float* y_inout,
+                    const float* s_in, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    const float* film, long ldf, const int64_t* lengths, void* dx_pre_lp, float* dgamma, float* dbeta,
+                    float* dfilm, long lddf, int B, int N, int Cin, int taps, float p_pre, uint64_t seed_pre,
+                    void* stream);
+
 /* Pack an fp32 (Cout, Cin, taps) PyTorch conv / (Cout, Cin) linear weight for dx_conv1d.
  *   transpose_flip = 0: out[tap][co][ci] = w[co][ci][tap]                (forward operand)
  *   transpose_flip = 1: out[tap][ci][co] = w[co][ci][taps-1-tap]         (data-gradient operand) */

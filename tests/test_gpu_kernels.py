@@ -141,3 +141,42 @@ def test_wgrad_ragged_shapes_accumulate_and_fixed_order():
         assert float((outs[0] - init - ref).abs().max()) <= 3e-5 * scale + 1e-5, (B, N, Cin, Cout, taps)
         assert torch.equal(outs[0], outs[1])
         assert float((db.cpu() - b.grad).abs().max()) <= 3e-5 * float(b.grad.abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize('taps,cin,film,p', [(3, 1024, False, 0.1), (1, 384, True, 0.2), (3, 128, True, 0.), (1, 128, False, 0.)])
+def test_conv_lnbwd_fusion_matches_two_launches(taps, cin, film, p):
+    ''' dx_conv1d_lnbwd == dx_conv1d(ACCUMULATE) followed by dx_layernorm_bwd (same dropout counter stream), including
+        ragged lengths, dead tiles past length + 2, FiLM gradients and the per-channel reductions '''
+    from daft_exprt import ops
+    g = torch.Generator().manual_seed(taps * 100 + cin)
+    B, N = 4, 333
+    lens = torch.tensor([333, 120, 63, 1]).to(DEV)
+    dyin = torch.randn(B, N, cin, generator=g).to(DEV)
+    w = (torch.randn(cin, 128, taps, generator=g) / (cin * taps) ** 0.5).to(DEV)     # forward conv 128 -> cin
+    n_idx = torch.arange(N, device=DEV)[None, :, None]
+    res = torch.randn(B, N, 128, generator=g).to(DEV) * (n_idx < lens[:, None, None] + 2)   # zero past length + halo, as upstream
+    s_in = torch.randn(B, N, 128, generator=g).to(DEV)
+    gamma, beta = torch.randn(128, generator=g).to(DEV), torch.randn(128, generator=g).to(DEV)
+    fl = torch.randn(B, 256, generator=g).to(DEV) if film else None
+    mean = s_in.mean(-1).reshape(-1).contiguous()
+    rstd = (1. / torch.sqrt(s_in.var(-1, unbiased=False) + 1e-5)).reshape(-1).contiguous()
+    for cd, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+        wp = ops.pack_conv_weight(w, cd, transpose_flip=True)
+        x = dyin.to(cd) * (n_idx < lens[:, None, None] + 2)
+        # two launches
+        y0 = res.clone()
+        ops.conv1d(x, wp, None, out=y0, accumulate=True, skip_lengths=lens)
+        dg0, db0 = torch.zeros(128, device=DEV), torch.zeros(128, device=DEV)
+        df0 = torch.zeros(B, 256, device=DEV) if film else None
+        ds0, dx0 = ops.layernorm_bwd(y0, s_in, mean, rstd, gamma, beta, dg0, db0, film=fl, dfilm=df0, lengths=lens, p_pre=p, seed_pre=77,
+                                     skip_lengths=lens, lp_only=True)
+        # one launch
+        y1 = res.clone()
+        dg1, db1 = torch.zeros(128, device=DEV), torch.zeros(128, device=DEV)
+        df1 = torch.zeros(B, 256, device=DEV) if film else None
+        dx1 = ops.conv1d_lnbwd(x, wp, y1, s_in, mean, rstd, gamma, beta, lens, dg1, db1, film=fl, dfilm=df1, p_pre=p, seed_pre=77)
+        sc = float(ds0.abs().max())
+        assert float((y1 - ds0).abs().max()) <= tol * sc, (cd, float((y1 - ds0).abs().max()), sc)
+        assert float((dx1.float() - dx0.float()).abs().max()) <= max(tol, 1e-2) * sc   # bf16 output rounding
+        for a, b_ in ((dg1, dg0), (db1, db0)) + (((df1, df0),) if film else ()):
+            assert float((a - b_).abs().max()) <= max(tol, 1e-4) * float(b_.abs().max()) + 1e-4

@@ -22,11 +22,16 @@ template <> struct Pad<bf16_t> { static constexpr int value = 8; };
 template <> struct Pad<float> { static constexpr int value = 4; };
 
 // LayerNorm epilogue (Cout == 128: a tile holds complete rows): s = dropout(conv) + residual; y = LN(s) [* FiLM] [masked]
+// (LN template parameter of conv_gemm_kernel: 0 none, 1 forward LayerNorm, 2 backward LayerNorm)
+// Backward (dx_conv1d_lnbwd, the data-gradient GEMM that completes dL/dy of a LayerNorm carries that LayerNorm's
+// backward): y = residual gradient in / ds out (in place), y_lp = bf16 dx_pre out, s_out = the saved LayerNorm
+// input (read), mean / rstd read, dgamma / dbeta / dfilm accumulated with one atomic per channel per workgroup.
 struct LNEpi {
   const float* gamma; const float* beta; const float* residual; const float* film; long ldf;
   float* y; void* y_lp; float* s_out; float* mean; float* rstd;
   float p_pre; uint64_t seed_pre;
   int enabled;
+  float* dgamma; float* dbeta; float* dfilm; long lddf;
 };
 
 struct ConvArgs {
@@ -95,8 +100,8 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
 #ifndef DX_CONV_WPS_NARROW
 #define DX_CONV_WPS_NARROW 4
 #endif
-template <typename TA, typename TC, typename TO, typename TG, int TAPS, int MI, int BK>
-__global__ __launch_bounds__(NTHREADS, MI == 1 ? DX_CONV_WPS_NARROW : DX_CONV_WPS) void conv_gemm_kernel(ConvArgs p) {
+template <typename TA, typename TC, typename TO, typename TG, int TAPS, int MI, int BK, int LN = 0>
+__global__ __launch_bounds__(NTHREADS, MI == 1 ? (LN == 2 ? 3 : DX_CONV_WPS_NARROW) : DX_CONV_WPS) void conv_gemm_kernel(ConvArgs p) {
   constexpr int BM = 64 * MI, KC = BK / 8;   // KC = 8-element chunks per row of a K chunk
   constexpr int HALO = TAPS / 2;
   constexpr int AROWS = BM + TAPS - 1;
@@ -138,8 +143,19 @@ __global__ __launch_bounds__(NTHREADS, MI == 1 ? DX_CONV_WPS_NARROW : DX_CONV_WP
 
   // padding early-out: a tile that starts past length + conv halo cannot reach a valid output -> zeros, no MFMA
   if (p.skip_len && n0 >= (int)p.skip_len[b] + 2) {
+    if (LN == 2) {   // incoming residual gradient rows are zero there and stay; the bf16 dx_pre rows must exist as zeros
+      float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int c = tid; c < BM * (BN / 8); c += NTHREADS) {
+        const int n = n0 + (c >> 4), cl = (c & 15) * 8;
+        if (n >= N) continue;
+        const size_t off = ((size_t)b * N + n) * BN + cl;
+        store8<float>(p.ln.y + off, z);
+        store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + off, z);
+      }
+      return;
+    }
     if (accum) return;
-    if (p.ln.enabled) {
+    if (LN == 1) {
       float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       for (int c = tid; c < BM * (BN / 8); c += NTHREADS) {
         const int n = n0 + (c >> 4), cl = (c & 15) * 8;
@@ -242,6 +258,11 @@ __global__ __launch_bounds__(NTHREADS, MI == 1 ? DX_CONV_WPS_NARROW : DX_CONV_WP
   }
 
   // ---- epilogue
+  float csum[LN == 2 ? 4 : 1][8];   // LN backward: this thread's column sums (dgamma, dbeta, dfilm_g, dfilm_b) over its rows
+#pragma unroll
+  for (int q = 0; q < (LN == 2 ? 4 : 1); ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[q][e] = 0.f;
   if (vec_out) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -268,7 +289,52 @@ __global__ __launch_bounds__(NTHREADS, MI == 1 ? DX_CONV_WPS_NARROW : DX_CONV_WP
           const f32x4 lo = *reinterpret_cast<const f32x4*>(&stage[sr * STG_LD + cl]);
           const f32x4 hi = *reinterpret_cast<const f32x4*>(&stage[sr * STG_LD + cl + 4]);
           v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-          if (p.ln.enabled) {   // fused LayerNorm: 16 lanes hold one complete 128-channel row
+          if (LN == 2) {        // fused LayerNorm BACKWARD: v + residual gradient = dL/d(LN output) of this row
+            const size_t rowg = (size_t)b * N + n, offl = rowg * BN + cl;
+            {
+              const f32x8 r = raw_load8<float>(p.ln.y + offl);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = n < len ? v[e] + r[e] : 0.f;     // masked_fill rows carry no gradient
+            }
+            const f32x8 sv = raw_load8<float>(p.ln.s_out + offl);
+            const float mean = p.ln.mean[rowg], rstd = p.ln.rstd[rowg];
+            const f32x8 gm = raw_load8<float>(p.ln.gamma + cl);
+            float xh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xh[e] = (sv[e] - mean) * rstd;
+            if (p.ln.film) {                                      // y = fg * LN + fb
+              const f32x8 fg = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + cl), bt = raw_load8<float>(p.ln.beta + cl);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                csum[2][e] += v[e] * (xh[e] * gm[e] + bt[e]);
+                csum[3][e] += v[e];
+                v[e] *= fg[e];
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              csum[0][e] += v[e] * xh[e];
+              csum[1][e] += v[e];
+              v[e] *= gm[e];
+              s1 += v[e];
+              s2 += v[e] * xh[e];
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            s1 *= 1.f / BN; s2 *= 1.f / BN;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = rstd * (v[e] - s1 - xh[e] * s2);
+            store8<float>(p.ln.y + offl, v);                      // ds, in place of the residual gradient
+            if (p.ln.p_pre > 0.f) {
+              const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(p.ln.seed_pre, 0);
+              const float sc = 1.f / (1.f - p.ln.p_pre);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = dx_keep(key, (uint32_t)rowg * BN + cl + e, th) ? v[e] * sc : 0.f;
+            }
+            store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + offl, v);
+            continue;
+          }
+          if (LN == 1) {        // fused LayerNorm: 16 lanes hold one complete 128-channel row
             const size_t rowg = (size_t)b * N + n, offl = rowg * BN + cl;
             if (p.ln.p_pre > 0.f) {
               const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(p.ln.seed_pre, 0);
@@ -330,6 +396,22 @@ __global__ __launch_bounds__(NTHREADS, MI == 1 ? DX_CONV_WPS_NARROW : DX_CONV_WP
         }
       }
       __syncthreads();
+    }
+    if (LN == 2) {   // column sums: 16 row-threads per channel segment -> LDS -> one atomic per channel per workgroup
+      const int nq = p.ln.film ? 4 : 2;
+      for (int q = 0; q < nq; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) stage[(q * 16 + (tid >> 4)) * BN + (tid & 15) * 8 + e] = csum[q][e];
+      __syncthreads();
+      for (int idx = tid; idx < nq * BN; idx += NTHREADS) {
+        const int q = idx / BN, c = idx - q * BN;
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += stage[(q * 16 + r) * BN + c];
+        if (q == 0) atomicAdd(p.ln.dgamma + c, t);
+        else if (q == 1) atomicAdd(p.ln.dbeta + c, t);
+        else atomicAdd(p.ln.dfilm + (size_t)b * p.ln.lddf + (q == 3 ? BN : 0) + c, t);
+      }
     }
     return;
   }
@@ -581,21 +663,28 @@ bool try_weight_stationary(const ConvArgs& a, int B, int taps, hipStream_t s) {
   }
 }
 
-template <typename TA, typename TC, typename TO, typename TG>
+template <typename TA, typename TC, typename TO, typename TG, int LN = 0>
 int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
   const int ztiles = dx_cdiv(a.Cout, BN);
-  if (try_weight_stationary<TA, TC, TO, TG>(a, B, taps, s)) { DX_LAUNCH_CHECK(); return DX_OK; }
-  const int mi = ztiles == 1 ? 1 : 2;                       // 64-row tiles for the narrow-output GEMMs
-  const long ptiles = (long)dx_cdiv(a.N, 64 * mi) * B;
-  dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * ztiles)), block(NTHREADS);
-  const bool deep = false;   // 64-deep chunks measured slower (register pressure): 75 vs 69.5 us on 1024->128
-  if (taps == 1 && mi == 1) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 1, 32>), grid, block, 0, s, a);
-  else if (taps == 1) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 2, 32>), grid, block, 0, s, a);
-  else if (deep) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 1, 64>), grid, block, 0, s, a);
-  else if (mi == 1) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 1, 32>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 2, 32>), grid, block, 0, s, a);
-  DX_LAUNCH_CHECK();
-  return DX_OK;
+  if constexpr (LN != 0) {   // LayerNorm epilogues: one channel tile (Cout = 128), 64-row tiles
+    const long ptiles = (long)dx_cdiv(a.N, 64) * B;
+    dim3 grid((unsigned)(((ptiles + 7) / 8) * 8)), block(NTHREADS);
+    if (taps == 1) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 1, 32, LN>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 1, 32, LN>), grid, block, 0, s, a);
+    DX_LAUNCH_CHECK();
+    return DX_OK;
+  } else {
+    if (try_weight_stationary<TA, TC, TO, TG>(a, B, taps, s)) { DX_LAUNCH_CHECK(); return DX_OK; }
+    const int mi = ztiles == 1 ? 1 : 2;                       // 64-row tiles for the narrow-output GEMMs
+    const long ptiles = (long)dx_cdiv(a.N, 64 * mi) * B;
+    dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * ztiles)), block(NTHREADS);
+    if (taps == 1 && mi == 1) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 1, 32>), grid, block, 0, s, a);
+    else if (taps == 1) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 2, 32>), grid, block, 0, s, a);
+    else if (mi == 1) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 1, 32>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 2, 32>), grid, block, 0, s, a);
+    DX_LAUNCH_CHECK();
+    return DX_OK;
+  }
 }
 
 
@@ -995,9 +1084,32 @@ extern "C" int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_
   ConvArgs a{x, ldx, w_packed, bias, nullptr, BN, nullptr, lengths, lengths, N, Cin, BN, 0, B,
              LNEpi{gamma, beta, residual, film, ldf, y, y_lp, s_out, mean, rstd, p_pre, seed_pre, 1}};
   hipStream_t s = (hipStream_t)stream;
-  if (w_dtype == DX_BF16 && x_dtype == DX_BF16) return launch_taps<bf16_t, bf16_t, float, float>(a, B, taps, s);
-  if (w_dtype == DX_BF16 && x_dtype == DX_F32) return launch_taps<float, bf16_t, float, float>(a, B, taps, s);
-  if (w_dtype == DX_F32 && x_dtype == DX_F32) return launch_taps<float, float, float, float>(a, B, taps, s);
+  if (w_dtype == DX_BF16 && x_dtype == DX_BF16) return launch_taps<bf16_t, bf16_t, float, float, 1>(a, B, taps, s);
+  if (w_dtype == DX_BF16 && x_dtype == DX_F32) return launch_taps<float, bf16_t, float, float, 1>(a, B, taps, s);
+  if (w_dtype == DX_F32 && x_dtype == DX_F32) return launch_taps<float, float, float, float, 1>(a, B, taps, s);
   dx_set_error("dx_conv1d_ln: unsupported dtype combination x=%d w=%d", x_dtype, w_dtype);
+  return DX_ERR_DTYPE;
+}
+
+extern "C" int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, float* y_inout,
+                               const float* s_in, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, const float* film, long ldf, const int64_t* lengths, void* dx_pre_lp,
+                               float* dgamma, float* dbeta, float* dfilm, long lddf, int B, int N, int Cin, int taps,
+                               float p_pre, uint64_t seed_pre, void* stream) {
+  DX_REQUIRE(x && w_packed && y_inout && s_in && mean && rstd && gamma && beta && lengths && dx_pre_lp && dgamma && dbeta,
+             DX_ERR_ARG, "dx_conv1d_lnbwd: null pointer");
+  DX_REQUIRE((film == nullptr) == (dfilm == nullptr), DX_ERR_ARG, "dx_conv1d_lnbwd: film and dfilm come together");
+  DX_REQUIRE(B > 0 && N > 0 && Cin > 0, DX_ERR_SHAPE, "dx_conv1d_lnbwd: empty shape");
+  DX_REQUIRE(Cin % 8 == 0 && ldx % 8 == 0, DX_ERR_SHAPE, "dx_conv1d_lnbwd: Cin (%d) and ldx (%ld) must be multiples of 8", Cin, ldx);
+  DX_REQUIRE(taps == 1 || taps == 3, DX_ERR_UNSUPPORTED, "dx_conv1d_lnbwd: taps=%d (only 1 and 3)", taps);
+  DX_REQUIRE(p_pre >= 0.f && p_pre < 1.f, DX_ERR_ARG, "dx_conv1d_lnbwd: dropout p out of [0,1)");
+  ConvArgs a{x, ldx, w_packed, nullptr, y_inout, BN, nullptr, lengths, lengths, N, Cin, BN, 0, B,
+             LNEpi{gamma, beta, nullptr, film, ldf, y_inout, dx_pre_lp, const_cast<float*>(s_in), const_cast<float*>(mean),
+                   const_cast<float*>(rstd), p_pre, seed_pre, 2, dgamma, dbeta, dfilm, lddf}};
+  hipStream_t s = (hipStream_t)stream;
+  if (w_dtype == DX_BF16 && x_dtype == DX_BF16) return launch_taps<bf16_t, bf16_t, float, float, 2>(a, B, taps, s);
+  if (w_dtype == DX_BF16 && x_dtype == DX_F32) return launch_taps<float, bf16_t, float, float, 2>(a, B, taps, s);
+  if (w_dtype == DX_F32 && x_dtype == DX_F32) return launch_taps<float, float, float, float, 2>(a, B, taps, s);
+  dx_set_error("dx_conv1d_lnbwd: unsupported dtype combination x=%d w=%d", x_dtype, w_dtype);
   return DX_ERR_DTYPE;
 }

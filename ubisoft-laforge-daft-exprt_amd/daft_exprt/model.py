@@ -173,6 +173,7 @@ class DaftExprt(nn.Module):
         self.always_repack = True   # safe default for external optimizers; the fused trainer turns it off
         self._anchor = None
         self._side = self._side_stream = None
+        self.fuse_ln_backward = bool(int(__import__('os').environ.get('DX_FUSE_LN_BWD', '1')))   # see _fft_block_bwd
         self._step_id, self._site = 0, 0
         self._pos = None
         self.n_params = sum(int(np.prod(s)) for _, s, _ in self._table)
@@ -488,31 +489,61 @@ class DaftExprt(nn.Module):
         dy.record_stream(side)                      # keep the allocator from recycling them under the side stream
         x.record_stream(side)
 
-    def _fft_block_bwd(self, W, s, du, dfilm):
-        ''' du: grad wrt the block output (fp32).  Returns grad wrt the block input. dfilm: (B, 2C) view or None '''
+    def _fft_stack_bwd(self, W, blocks, du, dfilms):
+        ''' backward through a stack of FFT blocks, top block first.  dfilms: (B, nb_blocks, 2C) gradient view or None '''
+        pre = None
+        for blk in reversed(range(len(blocks))):
+            below = blocks[blk - 1] if blk > 0 else None
+            dfilm = dfilms[:, blk, :] if dfilms is not None else None
+            dfilm_below = dfilms[:, blk - 1, :] if (dfilms is not None and blk > 0) else None
+            du, pre = self._fft_block_bwd(W, blocks[blk], du, dfilm, pre, below, dfilm_below)
+        return du
+
+    def _fft_block_bwd(self, W, s, du, dfilm, pre=None, below=None, dfilm_below=None):
+        ''' du: grad wrt the block output (fp32).  Returns (grad wrt the block input, pre-computed LN2 backward of the block
+            below or None).  dfilm: (B, 2C) view or None.  With bf16 operands the two data-gradient GEMMs that write into
+            the residual gradient (FF conv1, QKV projection) carry the backward of the LayerNorm they feed
+            (`ops.conv1d_lnbwd`): the attention LayerNorm of this block and the FF LayerNorm of the block below. '''
         P, G, cd = self._P, self._G, self.cd
         a_pre, f_pre = f'{s.pre}.attention', f'{s.pre}.feed_forward'
         lp = cd == torch.bfloat16
-        ds2, dz = ops.layernorm_bwd(du, s.s2, s.mean2, s.rstd2, P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'],
-                                    G[f'{f_pre}.layer_norm.weight'], G[f'{f_pre}.layer_norm.bias'], film=s.film, dfilm=dfilm,
-                                    lengths=s.lengths, p_pre=s.p_conv, seed_pre=s.seeds[2], skip_lengths=s.lengths, lp_only=lp,
-                                    separate=True)   # dz is read by the side-stream wgrad while `da` is accumulated in place
+        fuse = lp and self.fuse_ln_backward
+        if pre is None:
+            ds2, dz = ops.layernorm_bwd(du, s.s2, s.mean2, s.rstd2, P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'],
+                                        G[f'{f_pre}.layer_norm.weight'], G[f'{f_pre}.layer_norm.bias'], film=s.film, dfilm=dfilm,
+                                        lengths=s.lengths, p_pre=s.p_conv, seed_pre=s.seeds[2], skip_lengths=s.lengths, lp_only=lp,
+                                        separate=True)   # dz is read by the side-stream wgrad while `da` is accumulated in place
+        else:
+            ds2, dz = pre                                # done in the epilogue of the block above's QKV data gradient
         da = ds2
         self._wgrad(dz, s.h, G[f'{f_pre}.convs.2.conv.weight'], G[f'{f_pre}.convs.2.conv.bias'], s.lengths)
         dh = ops.conv1d(dz, W[f'T:{f_pre}.convs.2.conv.weight'], None, out_dtype=cd, relu_gate=s.h, skip_lengths=s.lengths)
         self._wgrad(dh, s.a, G[f'{f_pre}.convs.0.conv.weight'], G[f'{f_pre}.convs.0.conv.bias'], s.lengths)
-        ops.conv1d(dh, W[f'T:{f_pre}.convs.0.conv.weight'], None, out=da, accumulate=True, skip_lengths=s.lengths)
-        ds1, dproj = ops.layernorm_bwd(da, s.s1, s.mean1, s.rstd1, P[f'{a_pre}.layer_norm.weight'], P[f'{a_pre}.layer_norm.bias'],
-                                       G[f'{a_pre}.layer_norm.weight'], G[f'{a_pre}.layer_norm.bias'], lengths=s.lengths,
-                                       p_pre=s.p_attn, seed_pre=s.seeds[1], skip_lengths=s.lengths, lp_only=lp, separate=True)
+        if fuse:
+            dproj = ops.conv1d_lnbwd(dh, W[f'T:{f_pre}.convs.0.conv.weight'], da, s.s1, s.mean1, s.rstd1,
+                                     P[f'{a_pre}.layer_norm.weight'], P[f'{a_pre}.layer_norm.bias'], s.lengths,
+                                     G[f'{a_pre}.layer_norm.weight'], G[f'{a_pre}.layer_norm.bias'], p_pre=s.p_attn, seed_pre=s.seeds[1])
+            ds1 = da
+        else:
+            ops.conv1d(dh, W[f'T:{f_pre}.convs.0.conv.weight'], None, out=da, accumulate=True, skip_lengths=s.lengths)
+            ds1, dproj = ops.layernorm_bwd(da, s.s1, s.mean1, s.rstd1, P[f'{a_pre}.layer_norm.weight'], P[f'{a_pre}.layer_norm.bias'],
+                                           G[f'{a_pre}.layer_norm.weight'], G[f'{a_pre}.layer_norm.bias'], lengths=s.lengths,
+                                           p_pre=s.p_attn, seed_pre=s.seeds[1], skip_lengths=s.lengths, lp_only=lp, separate=True)
         dx = ds1
         mha = f'{a_pre}.multi_head_attention'
         self._wgrad(dproj, s.o, G[f'{mha}.out_proj.weight'], G[f'{mha}.out_proj.bias'], s.lengths)
         d_o = ops.conv1d(dproj, W[f'T:{mha}.out_proj.weight'], None, out_dtype=cd, skip_lengths=s.lengths)
         dqkv = ops.attention_bwd(s.qkv, s.o, d_o, s.lse, s.lengths, s.cfg['attn_nb_heads'], s.p_attn, s.seeds[0])
         self._wgrad(dqkv, s.x, G[f'{mha}.in_proj_weight'], G[f'{mha}.in_proj_bias'], s.lengths)
+        if fuse and below is not None:
+            fb = f'{below.pre}.feed_forward'
+            dz_below = ops.conv1d_lnbwd(dqkv, W[f'T:{mha}.in_proj_weight'], dx, below.s2, below.mean2, below.rstd2,
+                                        P[f'{fb}.layer_norm.weight'], P[f'{fb}.layer_norm.bias'], below.lengths,
+                                        G[f'{fb}.layer_norm.weight'], G[f'{fb}.layer_norm.bias'], film=below.film, dfilm=dfilm_below,
+                                        p_pre=below.p_conv, seed_pre=below.seeds[2])
+            return dx, (dx, dz_below)
         ops.conv1d(dqkv, W[f'T:{mha}.in_proj_weight'], None, out=dx, accumulate=True, skip_lengths=s.lengths)
-        return dx
+        return dx, None
 
     def _conv_ln_bwd(self, W, s, dy, dfilm=None, need_dx=True, dx_out=None, lengths_hint=None):
         ''' backward of `_conv_ln_fwd`; returns grad wrt its input (dtype = the input's) '''
@@ -559,8 +590,7 @@ class DaftExprt(nn.Module):
             wname = f'{pre}.projection.linear_layer'
             self._wgrad(d_mel_bt, dec_x, G[f'{wname}.weight'], G[f'{wname}.bias'], S.gu.output_lengths)
             d_dec = ops.conv1d(d_mel_bt, W[f'T:{wname}.weight'], None, out_dtype=torch.float32, skip_lengths=S.gu.output_lengths)
-        for blk in reversed(range(len(blocks))):
-            d_dec = self._fft_block_bwd(W, blocks[blk], d_dec, dfilms[2][:, blk, :])
+        d_dec = self._fft_stack_bwd(W, blocks, d_dec, dfilms[2])
         done('frame_decoder')
         # ---- Gaussian upsampling (ground-truth durations / energy / pitch: no gradient into the predictor here)
         g = S.gu
@@ -594,8 +624,7 @@ class DaftExprt(nn.Module):
                     dx = self._conv_ln_bwd(W, s1, dx)
         done('prosody_predictor')
         # ---- phoneme encoder
-        for blk in reversed(range(len(S.enc))):
-            d_enc = self._fft_block_bwd(W, S.enc[blk], d_enc, dfilms[0][:, blk, :])
+        d_enc = self._fft_stack_bwd(W, S.enc, d_enc, dfilms[0])
         ops.embed_pos_bwd(S.symbols, d_enc, S.input_lengths, G['phoneme_encoder.symbols_embedding.weight'])
         done('phoneme_encoder')
         # ---- speaker classifier (+ gradient reversal, model.py:27-38)
@@ -625,8 +654,7 @@ class DaftExprt(nn.Module):
         ops.add_(d_emb, dz)
         # ---- prosody encoder trunk
         dx = ops.masked_mean_bwd(d_emb, pe.output_lengths, pe.T)
-        for blk in reversed(range(len(pe.blocks))):
-            dx = self._fft_block_bwd(W, pe.blocks[blk], dx, None)
+        dx = self._fft_stack_bwd(W, pe.blocks, dx, None)
         dl3 = ops.scalar_embed_bwd(dx, [pe.frames_energy, pe.frames_pitch],
                                    [G[f'{pre}.energy_embedding.conv.weight'], G[f'{pre}.pitch_embedding.conv.weight']],
                                    [G[f'{pre}.energy_embedding.conv.bias'], G[f'{pre}.pitch_embedding.conv.bias']],

@@ -98,6 +98,25 @@ def conv1d_ln(x, w_packed, bias, residual, gamma, beta, lengths, film=None, save
     return y, y_lp, s_out, mean, rstd
 
 
+def conv1d_lnbwd(x, w_packed, y_inout, s_in, mean, rstd, gamma, beta, lengths, dgamma, dbeta, film=None, dfilm=None,
+                 p_pre=0., seed_pre=0):
+    ''' data gradient of a conv / linear into a 128-channel residual stream + the backward of the LayerNorm that consumed
+        that stream, one launch (see dx_conv1d_lnbwd).  y_inout (B, N, 128) fp32: residual gradient in, ds out (in place).
+        Returns the bf16 dropout_pre(ds).  dgamma / dbeta / dfilm accumulate. '''
+    B, N, Cin = x.shape
+    taps, Cout, _ = w_packed.shape
+    assert Cout == 128 and x.stride(2) == 1 and y_inout.is_contiguous() and y_inout.dtype == torch.float32
+    dx_lp = torch.empty((B, N, 128), dtype=torch.bfloat16, device=x.device)
+    ldf = film.stride(0) if film is not None else 0
+    lddf = dfilm.stride(0) if dfilm is not None else 0
+    with _Probe('conv_gemm', 2. * B * N * Cin * Cout * taps, N):
+        H.check(H.lib().dx_conv1d_lnbwd(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(y_inout), H.ptr(s_in),
+                                        H.ptr(mean), H.ptr(rstd), H.ptr(gamma), H.ptr(beta), H.ptr(film), ldf, H.ptr(lengths),
+                                        H.ptr(dx_lp), H.ptr(dgamma), H.ptr(dbeta), H.ptr(dfilm), lddf, B, N, Cin, taps,
+                                        float(p_pre), int(seed_pre), H.stream()))
+    return dx_lp
+
+
 def pack_table(entries, device):
     ''' entries: [(w fp32 tensor, out tensor, transpose_flip)] -> (device descriptor table, n, total_bricks) for
         pack_weights_batched (one launch for every GEMM weight of the model) '''
