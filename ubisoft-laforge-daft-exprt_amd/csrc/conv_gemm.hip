@@ -878,25 +878,38 @@ __global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wg
   }
 }
 
-// dW += sum over the splits of the partial tiles (register order, see conv_wgrad_kernel); one thread per tile element
+// dW += sum over the splits of the partial tiles (register order, see conv_wgrad_kernel).  One thread per 4 consecutive
+// tile elements (= 4 consecutive lanes of one accumulator register: same co, 4 consecutive ci), 16-byte loads, four
+// splits in flight per thread (the first version read one float per thread per split: 1.3 TB/s).
 template <int TAPS>
-__global__ __launch_bounds__(WG_THREADS) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
-                                                                  int ntiles, int tiles_ci, int Cout, int Cin) {
-  constexpr int TILE_FLOATS = TAPS * 2 * 16 * WG_THREADS;
-  const int tile = blockIdx.x / (TAPS * 32), slot = blockIdx.x % (TAPS * 32), tid = threadIdx.x;
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
+                                                           int ntiles, int tiles_ci, int Cout, int Cin) {
+  constexpr int TILE_FLOATS = TAPS * 2 * 16 * WG_THREADS, QUADS = TILE_FLOATS / 4;
+  const long q = blockIdx.x * 256L + threadIdx.x;
+  if (q >= (long)ntiles * QUADS) return;
+  const int tile = (int)(q / QUADS), e0 = (int)(q - (long)tile * QUADS) * 4;      // element offset inside the tile
+  const int slot = e0 / WG_THREADS, tid = e0 % WG_THREADS;
   const int t = slot / 32, i = (slot >> 4) & 1, r = slot & 15;
   const int lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
   const int co = (tile / tiles_ci) * WG_CO + wm * 64 + i * 32 + dx_acc_row(r, lane >> 5);
-  const int ci = (tile % tiles_ci) * WG_CI + wn * 32 + (lane & 31);
-  const float* src = ws + (size_t)tile * TILE_FLOATS + slot * WG_THREADS + tid;
-  float s0 = 0.f, s1 = 0.f;
+  const int ci = (tile % tiles_ci) * WG_CI + wn * 32 + (lane & 31);               // .. ci + 3 (lane % 4 == 0)
+  const float* src = ws + (size_t)tile * TILE_FLOATS + e0;
+  const size_t stride = (size_t)ntiles * TILE_FLOATS;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
   int k = 0;
-  for (; k + 1 < nsplit; k += 2) {
-    s0 += src[(size_t)k * ntiles * TILE_FLOATS];
-    s1 += src[(size_t)(k + 1) * ntiles * TILE_FLOATS];
+  for (; k + 3 < nsplit; k += 4) {
+    s0 += *reinterpret_cast<const f32x4*>(src + (size_t)k * stride);
+    s1 += *reinterpret_cast<const f32x4*>(src + (size_t)(k + 1) * stride);
+    s2 += *reinterpret_cast<const f32x4*>(src + (size_t)(k + 2) * stride);
+    s3 += *reinterpret_cast<const f32x4*>(src + (size_t)(k + 3) * stride);
   }
-  if (k < nsplit) s0 += src[(size_t)k * ntiles * TILE_FLOATS];
-  if (co < Cout && ci < Cin) dw[((size_t)co * Cin + ci) * TAPS + t] += s0 + s1;
+  for (; k < nsplit; ++k) s0 += *reinterpret_cast<const f32x4*>(src + (size_t)k * stride);
+  const f32x4 sum = (s0 + s1) + (s2 + s3);
+  if (co < Cout) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (ci + j < Cin) dw[((size_t)co * Cin + ci + j) * TAPS + t] += sum[j];
+  }
 }
 
 template <typename TA, typename TB, typename TC>
@@ -906,11 +919,11 @@ int launch_wgrad(const WgradArgs& a, int taps, hipStream_t s) {
   if (taps == 1) {
     hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 1>), grid, block, 0, s, a);
     if (a.ws && !(a.debug & 1))
-      hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(ntiles * 32), dim3(WG_THREADS), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
+      hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(ntiles * (1 * 2 * 16 * WG_THREADS / 4 / 256)), dim3(256), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
   } else {
     hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 3>), grid, block, 0, s, a);
     if (a.ws && !(a.debug & 1))
-      hipLaunchKernelGGL((wgrad_reduce_kernel<3>), dim3(ntiles * 96), dim3(WG_THREADS), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
+      hipLaunchKernelGGL((wgrad_reduce_kernel<3>), dim3(ntiles * (3 * 2 * 16 * WG_THREADS / 4 / 256)), dim3(256), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
   }
   DX_LAUNCH_CHECK();
   return DX_OK;
@@ -1027,7 +1040,7 @@ extern "C" int dx_pack_conv_weight(const float* w, void* out, int out_dtype, int
 }
 
 // number of workgroup splits of the position axis for a wgrad problem (shared by the launcher and the workspace query)
-static int wgrad_nsplit(int B, int N, int Cin, int Cout) {
+static int wgrad_nsplit(int B, int N, int Cin, int Cout, int taps) {
   // Workgroup target: the weight gradients run on a side stream UNDER the data-gradient chain, so the question is not
   // how fast they finish alone but how little they slow the main stream down.  Measured per training step with the
   // 128 x 128 tiles (B = 48, T <= 1000): 64 -> 10.73 ms, 128 -> 10.46, 160 -> 10.45, 192 -> 10.30, 224 -> 10.35,
@@ -1035,9 +1048,10 @@ static int wgrad_nsplit(int B, int N, int Cin, int Cout) {
   static int fixed = getenv("DX_WGRAD_BLOCKS") ? atoi(getenv("DX_WGRAD_BLOCKS")) : 0;
   const int target = fixed > 0 ? fixed : 192;
   const int tiles = dx_cdiv(Cout, WG_CO) * dx_cdiv(Cin, WG_CI);
-  // every split costs one more partial tile to write and re-read: keep >= ~8 items (64 positions each) per workgroup
+  // every split costs one more partial tile to write and re-read: keep >= ~8 items (64 positions each) per workgroup,
+  // 16 for the linear layers (a third of the MFMA work per item)
   int ns = target / tiles;
-  const long by_work = (long)B * dx_cdiv(N, WG_P) / 8;
+  const long by_work = (long)B * dx_cdiv(N, WG_P) / (taps == 1 ? 16 : 8);      // (B * N rows is an upper bound of the valid rows)
   if (ns > by_work) ns = (int)by_work;
   return ns < 1 ? 1 : ns;
 }
@@ -1045,7 +1059,7 @@ static int wgrad_nsplit(int B, int N, int Cin, int Cout) {
 extern "C" long dx_conv1d_wgrad_ws_floats(int B, int N, int Cin, int Cout, int taps) {
   if (B <= 0 || N <= 0 || Cin <= 0 || Cout <= 0 || (taps != 1 && taps != 3)) return 0;
   const long tiles = (long)dx_cdiv(Cout, WG_CO) * dx_cdiv(Cin, WG_CI);
-  return (long)wgrad_nsplit(B, N, Cin, Cout) * tiles * taps * 2 * 16 * WG_THREADS;
+  return (long)wgrad_nsplit(B, N, Cin, Cout, taps) * tiles * taps * 2 * 16 * WG_THREADS;
 }
 
 extern "C" int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const void* x, int x_dtype, long ldx,
@@ -1057,7 +1071,7 @@ extern "C" int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const vo
              "dx_conv1d_wgrad: Cin, Cout and the row strides must be multiples of 8");
   DX_REQUIRE(taps == 1 || taps == 3, DX_ERR_UNSUPPORTED, "dx_conv1d_wgrad: taps=%d (only 1 and 3)", taps);
   static int dbg = getenv("DX_WGRAD_DEBUG") ? atoi(getenv("DX_WGRAD_DEBUG")) : 0;
-  WgradArgs a{dy, lddy, x, ldx, dw, db, lengths, ws, B, N, Cin, Cout, wgrad_nsplit(B, N, Cin, Cout), dx_cdiv(Cin, WG_CI), dbg};
+  WgradArgs a{dy, lddy, x, ldx, dw, db, lengths, ws, B, N, Cin, Cout, wgrad_nsplit(B, N, Cin, Cout, taps), dx_cdiv(Cin, WG_CI), dbg};
   hipStream_t s = (hipStream_t)stream;
   if (compute_dtype == DX_BF16) {
     if (dy_dtype == DX_F32 && x_dtype == DX_F32) return launch_wgrad<float, float, bf16_t>(a, taps, s);
