@@ -655,10 +655,13 @@ class DaftExprt(nn.Module):
         # ---- prosody encoder trunk
         dx = ops.masked_mean_bwd(d_emb, pe.output_lengths, pe.T)
         dx = self._fft_stack_bwd(W, pe.blocks, dx, None)
-        dl3 = ops.scalar_embed_bwd(dx, [pe.frames_energy, pe.frames_pitch],
-                                   [G[f'{pre}.energy_embedding.conv.weight'], G[f'{pre}.pitch_embedding.conv.weight']],
-                                   [G[f'{pre}.energy_embedding.conv.bias'], G[f'{pre}.pitch_embedding.conv.bias']],
-                                   lengths=pe.output_lengths, need_dbase=True)
+        # rows >= length of dx are exactly zero (masked LayerNorm rows carry no gradient; pad queries / keys get zero
+        # attention gradients), so the gradient wrt the prenet output is dx itself: no masked copy
+        ops.scalar_embed_bwd(dx, [pe.frames_energy, pe.frames_pitch],
+                             [G[f'{pre}.energy_embedding.conv.weight'], G[f'{pre}.pitch_embedding.conv.weight']],
+                             [G[f'{pre}.energy_embedding.conv.bias'], G[f'{pre}.pitch_embedding.conv.bias']],
+                             lengths=pe.output_lengths, need_dbase=False)
+        dl3 = dx
         dl2 = self._conv_ln_bwd(W, pe.c3, dl3, lengths_hint=pe.output_lengths)
         dl1 = self._conv_ln_bwd(W, pe.c2, dl2, lengths_hint=pe.output_lengths)
         self._conv_ln_bwd(W, pe.c1, dl1, need_dx=False, lengths_hint=pe.output_lengths)
