@@ -60,9 +60,12 @@ struct ScalarEmbedBwdArgs {
   int N; int rows_per_block;
 };
 
-// grid (ceil(N / rows_per_block), B); 128 threads: thread = channel, loops over the slab's rows
-__global__ __launch_bounds__(128) void scalar_embed_bwd_kernel(ScalarEmbedBwdArgs a) {
-  const int c = threadIdx.x, b = blockIdx.y;
+// grid (ceil(N / rows_per_block), B); 512 threads = 4 row lanes x 128 channels: row lane q walks rows q, q + 4, ... of the
+// slab, the four partial sums meet in LDS, and the workgroup ends with ONE atomic per (feature, tap, channel) -- all
+// workgroups hit the same 1024 addresses, so few fat workgroups (the 2048-workgroup launch spent ~100 us queueing atomics)
+__global__ __launch_bounds__(512) void scalar_embed_bwd_kernel(ScalarEmbedBwdArgs a) {
+  __shared__ float red[4][3][4][C128];
+  const int c = threadIdx.x & 127, q = threadIdx.x >> 7, b = blockIdx.y;
   const int n0 = blockIdx.x * a.rows_per_block;
   const int len = a.lengths ? (int)a.lengths[b] : a.N;
   const int n1 = min(min(a.N, n0 + a.rows_per_block), a.dbase ? a.N : len);
@@ -70,21 +73,27 @@ __global__ __launch_bounds__(128) void scalar_embed_bwd_kernel(ScalarEmbedBwdArg
 #pragma unroll
   for (int f = 0; f < 3; ++f) { ab[f] = 0.f; aw[f][0] = aw[f][1] = aw[f][2] = 0.f; }
 #pragma unroll 4
-  for (int n = n0; n < n1; ++n) {
+  for (int n = n0 + q; n < n1; n += 4) {
     const long row = (long)b * a.N + n;
     const float g = n < len ? a.dout[row * C128 + c] : 0.f;
     if (a.dbase) a.dbase[row * C128 + c] = g;
-    for (int f = 0; f < a.nfeat; ++f) {
-      const float* ft = a.feat[f] + (long)b * a.N;
-      const float xm = n > 0 ? ft[n - 1] : 0.f, x0 = ft[n], xp = n + 1 < a.N ? ft[n + 1] : 0.f;
-      aw[f][0] += g * xm; aw[f][1] += g * x0; aw[f][2] += g * xp; ab[f] += g;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      if (f < a.nfeat) {
+        const float* ft = a.feat[f] + (long)b * a.N;
+        const float xm = n > 0 ? ft[n - 1] : 0.f, x0 = ft[n], xp = n + 1 < a.N ? ft[n + 1] : 0.f;
+        aw[f][0] += g * xm; aw[f][1] += g * x0; aw[f][2] += g * xp; ab[f] += g;
+      }
     }
   }
-  for (int f = 0; f < a.nfeat; ++f) {
-    atomicAdd(a.dw[f] + c * 3 + 0, aw[f][0]);
-    atomicAdd(a.dw[f] + c * 3 + 1, aw[f][1]);
-    atomicAdd(a.dw[f] + c * 3 + 2, aw[f][2]);
-    atomicAdd(a.dbias[f] + c, ab[f]);
+#pragma unroll
+  for (int f = 0; f < 3; ++f) { red[q][f][0][c] = aw[f][0]; red[q][f][1][c] = aw[f][1]; red[q][f][2][c] = aw[f][2]; red[q][f][3][c] = ab[f]; }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < a.nfeat * 4 * C128; idx += 512) {
+    const int f = idx / (4 * C128), k = (idx / C128) & 3, ch = idx & (C128 - 1);
+    const float t = red[0][f][k][ch] + red[1][f][k][ch] + red[2][f][k][ch] + red[3][f][k][ch];
+    if (k < 3) atomicAdd(a.dw[f] + ch * 3 + k, t);
+    else atomicAdd(a.dbias[f] + ch, t);
   }
 }
 
@@ -321,11 +330,11 @@ extern "C" int dx_scalar_embed_bwd(const float* dout, const float* const* feats,
   ScalarEmbedBwdArgs a{};
   a.dout = dout; a.nfeat = nfeat; a.lengths = lengths; a.dbase = dbase; a.N = N;
   // every workgroup ends with 512-1024 atomics on the same few addresses: few, fat workgroups
-  int rpb = 32;
-  while (rpb < 1024 && (long)dx_cdiv(N, rpb) * B > 2048) rpb *= 2;   // ~6 two-wave workgroups per CU: the row loop is latency bound
+  int rpb = 64;
+  while (rpb < 1024 && (long)dx_cdiv(N, rpb) * B > 512) rpb *= 2;
   a.rows_per_block = rpb;
   for (int f = 0; f < nfeat; ++f) { a.feat[f] = feats[f]; a.dw[f] = dws[f]; a.dbias[f] = dbiases[f]; }
-  hipLaunchKernelGGL(scalar_embed_bwd_kernel, dim3(dx_cdiv(N, rpb), B), dim3(128), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(scalar_embed_bwd_kernel, dim3(dx_cdiv(N, rpb), B), dim3(512), 0, (hipStream_t)stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
