@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DX_ABI_VERSION 2
+#define DX_ABI_VERSION 3
 
 enum { DX_F32 = 0, DX_BF16 = 1, DX_I64 = 2 };
 enum { DX_OK = 0, DX_ERR_ARG = -1, DX_ERR_SHAPE = -2, DX_ERR_DTYPE = -3, DX_ERR_LAUNCH = -4, DX_ERR_UNSUPPORTED = -5 };
