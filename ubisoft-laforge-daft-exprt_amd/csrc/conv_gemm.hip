@@ -455,19 +455,17 @@ constexpr int WR_THREADS = 512, WR_BN = 256, WR_BM = 128;
 #ifndef WR_ABL
 #define WR_ABL 0   // compile-time ablation (development): 1 no MFMA, 2 no epilogue, 4 no global stores
 #endif
-template <typename TO, typename TG, int TAPS, bool RELU>
+template <typename TO, typename TG, int TAPS, bool RELU, bool GATE>
 __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, int ngrp) {
   typedef bf16_t TC;
   constexpr int BM = WR_BM, HALO = TAPS / 2, AROWS = BM + TAPS - 1, CIN = 128, LDK = CIN + Pad<TC>::value, KCH = CIN / 8;
   constexpr int KSTEPS = CIN / 16;
   constexpr int A_CH = AROWS * KCH, A_PT = (A_CH + WR_THREADS - 1) / WR_THREADS;
-  constexpr int STG_LD = 32 + 4, STG_FLOATS = 64 * STG_LD;
   constexpr int A_BYTES = AROWS * LDK * (int)sizeof(TC);
   typedef typename Vec8<TC>::type frag_t;
-  __shared__ __attribute__((aligned(16))) char smem[2 * A_BYTES + 8 * STG_FLOATS * 4];
+  __shared__ __attribute__((aligned(16))) char smem[2 * A_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, g = lane >> 5;
-  float* stage = reinterpret_cast<float*>(smem + 2 * A_BYTES) + wave * STG_FLOATS;
   const int ztiles = p.Cout / WR_BN, ptiles = dx_cdiv(p.N, BM);
   const int grp = blockIdx.x / ztiles, co0 = (blockIdx.x % ztiles) * WR_BN + wave * 32;
   const int N = p.N, Cout = p.Cout;
@@ -482,7 +480,12 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks)
       wreg[tap][ks] = *reinterpret_cast<const frag_t*>(W + ((size_t)tap * Cout + co0 + l31) * CIN + ks * 16 + g * 8);
-  const float bv = p.bias ? p.bias[co0 + l31] : 0.f;
+  // The MFMAs run with the operands swapped (weights as A, activations as B), so the accumulator tile is D[co][position]:
+  // a lane holds ONE position (l31) and, per group of 4 registers, 4 CONSECUTIVE output channels (rows (r & 3) + 8 (r >> 2)
+  // + 4 g) -- row-major output leaves the registers without an LDS transpose.
+  float bvr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bvr[r] = p.bias ? p.bias[co0 + dx_acc_row(r, g)] : 0.f;
 
   // ---- this workgroup's share of the live position tiles (flat list over the batch)
   auto live_of = [&](int b) { return p.skip_len ? min(ptiles, dx_cdiv(min(N, (int)p.skip_len[b] + 2), BM)) : ptiles; };
@@ -497,15 +500,22 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
   }
   int left = i1 - i0;
 
+  // All global accesses of the tile loop are BUFFER loads / stores on a per-utterance resource: rows outside [0, N) are
+  // dropped / read as zero by the hardware bounds check, so the loop body has no divergent branches and hipcc can count
+  // the outstanding memory operations exactly (with `if (n < N)` around the stores it fell back to `s_waitcnt vmcnt(0)`
+  // in front of every epilogue block, which also drained the A-tile prefetch issued at the top of the tile).
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t xbytes = (uint32_t)((size_t)N * p.ldx * sizeof(TC)), ybytes = (uint32_t)((size_t)N * p.ldy * sizeof(TO));
   bf16x8 ra[A_PT];
   auto fetch = [&](int fb, int fpt) {
-    const TC* X = reinterpret_cast<const TC*>(p.x) + (size_t)fb * N * p.ldx;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<TC*>(reinterpret_cast<const TC*>(p.x)) + (size_t)fb * N * p.ldx, 0, xbytes, 0x00020000);
 #pragma unroll
     for (int t = 0; t < A_PT; ++t) {
       const int c = tid + t * WR_THREADS;
-      const int n = fpt * BM + (c >> 4) - HALO;
-      ra[t] = zero8<TC>();
-      if (c < A_CH && n >= 0 && n < N) ra[t] = *reinterpret_cast<const bf16x8*>(X + (size_t)n * p.ldx + (c & 15) * 8);
+      const int n = fpt * BM + (c >> 4) - HALO;                       // -1 (halo of the first tile) wraps to out-of-range
+      const uint32_t voff = c < A_CH ? (uint32_t)(n * (int)p.ldx + (c & 15) * 8) * (uint32_t)sizeof(TC) : 0xffffff00u;
+      ra[t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voff, 0, 0));
     }
   };
   auto commit = [&](int buf) {
@@ -522,48 +532,78 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
   //   phase A(t): MFMAs of rows 0..63 of tile t    ||  epilogue of rows 64..127 of tile t-1
   //   phase B(t): MFMAs of rows 64..127 of tile t  ||  epilogue of rows 0..63 of tile t
   // (measured before: MFMA loop 22 us + epilogue 15 us back to back; the two waves of a SIMD ran them in lockstep)
-  struct Epi { size_t base; int n0, len; };   // base = element offset of row n0 of the utterance in y / gate
-  // slice kk (0 .. TAPS*KSTEPS-1) of the epilogue of accumulator pair acc[2h], acc[2h+1] of the tile described by e
-  const int srow = lane >> 2, scl = (lane & 3) * 8;          // this lane's row / channel segment within a 16-row output pass
-  const size_t lane_off = (size_t)srow * p.ldy + co0 + scl;
+  struct Epi { int cb, n0, len; };   // utterance, first row of the tile, mask length
+  // Epilogue of one 32-position accumulator tile, straight from registers.  bf16 output: two v_permlane32_swap per
+  // 8-channel group gather a lane's 8 consecutive channels (16-byte stores; lanes g = 0 / 1 of a position write
+  // channels [0, 8) / [8, 16) and [16, 24) / [24, 32) of the wave's 32); fp32 output: one 16-byte store per register group.
+  auto epi_tile = [&](const f32x16& ac, const Epi& e, int row0) {
+    const int n = e.n0 + row0 + l31;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(Y + (size_t)e.cb * N * p.ldy, 0, ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<TG*>(GATE ? G : reinterpret_cast<const TG*>(Y)) + (size_t)e.cb * N * p.ldy, 0, (uint32_t)((size_t)N * p.ldy * sizeof(TG)), 0x00020000);
+    const uint32_t eoff = (uint32_t)n * (uint32_t)p.ldy + (uint32_t)co0;     // element offset inside the utterance
+    const bool zero_row = n >= e.len;              // mask_lengths
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      v[r] = ac[r] + bvr[r];
+      if (RELU) v[r] = fmaxf(v[r], 0.f);
+    }
+    if constexpr (sizeof(TO) == 4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t o = (eoff + 8 * q + 4 * g) * 4u;
+        f32x4 w = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        if (GATE) {
+          const f32x4 gv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (int)o, 0, 0));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = gv[j] > 0.f ? w[j] : 0.f;
+        }
+        if (zero_row) w = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(WR_ABL & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w), ry, (int)o, 0, 0);
+      }
+    } else {
+      typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      uint32_t P[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bf16x2 pr = {(bf16_t)v[2 * k], (bf16_t)v[2 * k + 1]};
+        P[k] = __builtin_bit_cast(uint32_t, pr);
+      }
+      // (P0,P1 | P2,P3) and (P4,P5 | P6,P7): hi half of the first pair <-> lo half of the second
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const u32x2 sw = __builtin_amdgcn_permlane32_swap(P[4 * h2 + k], P[4 * h2 + 2 + k], false, false);
+          P[4 * h2 + k] = sw[0];
+          P[4 * h2 + 2 + k] = sw[1];
+        }
+      // now (P0, P1, P2, P3) = channel pairs (0,1)(2,3)(4,5)(6,7) + 8 g and (P4 .. P7) the same + 16
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const uint32_t o = (eoff + 16 * h2 + 8 * g) * 2u;
+        u32x4 w = {P[4 * h2], P[4 * h2 + 1], P[4 * h2 + 2], P[4 * h2 + 3]};
+        if (GATE) {   // gate > 0 on the packed bf16 bits: sign clear and magnitude non-zero  <=>  bits - 1 < 0x7fff (unsigned)
+          const u32x4 gw = __builtin_amdgcn_raw_buffer_load_b128(rg, (int)o, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t m = (((gw[j] & 0xffffu) - 1u) < 0x7fffu ? 0x0000ffffu : 0u) | (((gw[j] >> 16) - 1u) < 0x7fffu ? 0xffff0000u : 0u);
+            w[j] &= m;
+          }
+        }
+        if (zero_row) w = u32x4{0u, 0u, 0u, 0u};
+        if (!(WR_ABL & 4)) __builtin_amdgcn_raw_buffer_store_b128(w, ry, (int)o, 0, 0);
+      }
+    }
+  };
+  // slice kk (0 .. TAPS*KSTEPS-1) of the epilogue of accumulator pair ac[0], ac[1] (rows [64 h, 64 h + 64) of tile e)
   auto epi_slice = [&](int kk, const f32x16* ac, const Epi& e, int h) {
-    constexpr int NS = TAPS * KSTEPS;            // slices available (24 or 8)
-    constexpr int WS = NS >= 24 ? 8 : 2;         // slices that carry the 32 stage writes
-    constexpr int PER = 32 / WS;
-    if (kk < WS) {
-#pragma unroll
-      for (int q = 0; q < PER; ++q) {
-        const int idx = kk * PER + q, i = idx >> 4, r = idx & 15;
-        float v = ac[i][r] + bv;
-        if (RELU) v = fmaxf(v, 0.f);
-        stage[(i * 32 + dx_acc_row(r, g)) * STG_LD + l31] = v;
-      }
-      if (kk == WS - 1) __builtin_amdgcn_wave_barrier();
-      return;
-    }
-    constexpr int GAP = (NS - WS) / 4;           // one output pass every GAP slices
-    if ((kk - WS) % GAP != 0 || (kk - WS) / GAP >= 4) return;
-    const int pass = (kk - WS) / GAP;
-    const int sr = srow + pass * 16;
-    const int n = e.n0 + h * 64 + sr;
-    if (n < N) {
-      float v[8];
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(&stage[sr * STG_LD + scl]);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(&stage[sr * STG_LD + scl + 4]);
-      v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-      const size_t off = e.base + (size_t)(h * 64 + pass * 16) * p.ldy + lane_off;
-      if (G) {
-        const typename VecN<TG, 8>::type gv = raw_load8<TG>(G + off);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = ((float)gv[q] > 0.f) ? v[q] : 0.f;
-      }
-      if (n >= e.len) {                          // rare (mask_lengths): whole row to zero
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = 0.f;
-      }
-      if (!(WR_ABL & 4)) store8<TO>(Y + off, v);
-    }
-    if (pass == 3) __builtin_amdgcn_wave_barrier();
+    constexpr int NS = TAPS * KSTEPS;
+    // early in the phase: the end-of-tile wait for the prefetched A tile (vmcnt) also covers these stores
+    if (kk == 1) epi_tile(ac[0], e, h * 64);
+    else if (kk == NS / 3) epi_tile(ac[1], e, h * 64 + 32);
   };
 
   int buf = 0;
@@ -577,9 +617,9 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  Epi prev{0, N, 0};   // n0 = N: nothing to store before the first tile
+  Epi prev{0, N, 0};   // n0 = N: every row out of range, nothing is stored before the first tile
   while (left > 0) {
-    const Epi cur{((size_t)b * N + (size_t)pt * BM) * p.ldy, pt * BM, p.mask_len ? (int)p.mask_len[b] : N};
+    const Epi cur{b, pt * BM, p.mask_len ? (int)p.mask_len[b] : N};
     const TC* As = reinterpret_cast<const TC*>(smem + buf * A_BYTES);
     --left;
     if (left > 0) {
@@ -602,7 +642,7 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
 #pragma unroll
           for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const frag_t*>(&As[(h * 64 + i * 32 + l31 + tap) * LDK + ks * 16 + g * 8]);
 #pragma unroll
-          for (int i = 0; i < 2; ++i) { if (!(WR_ABL & 1)) dx_mma(acc[h * 2 + i], a[i], wreg[tap][ks]); }
+          for (int i = 0; i < 2; ++i) { if (!(WR_ABL & 1)) dx_mma(acc[h * 2 + i], wreg[tap][ks], a[i]); }
           if (!(WR_ABL & 2)) epi_slice(tap * KSTEPS + ks, &acc[h == 0 ? 2 : 0], ep, h == 0 ? 1 : 0);
         }
       }
@@ -654,11 +694,17 @@ bool try_weight_stationary(const ConvArgs& a, int B, int taps, hipStream_t s) {
     if (ngrp > tiles) ngrp = (int)tiles;
     if (ngrp < 1) ngrp = 1;
     dim3 grid(ngrp * ztiles), block(WR_THREADS);
-    const bool relu = a.flags & DX_CONV_RELU;
-    if (taps == 3 && relu) hipLaunchKernelGGL((conv_wreg_kernel<TO, TG, 3, true>), grid, block, 0, s, a, ngrp);
-    else if (taps == 3) hipLaunchKernelGGL((conv_wreg_kernel<TO, TG, 3, false>), grid, block, 0, s, a, ngrp);
-    else if (relu) hipLaunchKernelGGL((conv_wreg_kernel<TO, TG, 1, true>), grid, block, 0, s, a, ngrp);
-    else hipLaunchKernelGGL((conv_wreg_kernel<TO, TG, 1, false>), grid, block, 0, s, a, ngrp);
+    const bool relu = a.flags & DX_CONV_RELU, gate = a.gate != nullptr;
+    if ((size_t)a.N * a.ldy * 4 >= (1ull << 32) || (size_t)a.N * a.ldx * 2 >= (1ull << 32)) return false;   // 32-bit buffer offsets
+#define DX_WREG_LAUNCH(T, R, GT) hipLaunchKernelGGL((conv_wreg_kernel<TO, TG, T, R, GT>), grid, block, 0, s, a, ngrp)
+    if (taps == 3) {
+      if (relu && gate) DX_WREG_LAUNCH(3, true, true); else if (relu) DX_WREG_LAUNCH(3, true, false);
+      else if (gate) DX_WREG_LAUNCH(3, false, true); else DX_WREG_LAUNCH(3, false, false);
+    } else {
+      if (relu && gate) DX_WREG_LAUNCH(1, true, true); else if (relu) DX_WREG_LAUNCH(1, true, false);
+      else if (gate) DX_WREG_LAUNCH(1, false, true); else DX_WREG_LAUNCH(1, false, false);
+    }
+#undef DX_WREG_LAUNCH
     return true;
   }
 }
