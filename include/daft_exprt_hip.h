@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DX_ABI_VERSION 3
+#define DX_ABI_VERSION 4
 
 enum { DX_F32 = 0, DX_BF16 = 1, DX_I64 = 2 };
 enum { DX_OK = 0, DX_ERR_ARG = -1, DX_ERR_SHAPE = -2, DX_ERR_DTYPE = -3, DX_ERR_LAUNCH = -4, DX_ERR_UNSUPPORTED = -5 };
@@ -258,6 +258,22 @@ int dx_int_durations(float* duration_preds, const float* dur_factors, int64_t* d
 int dx_prosody_control(float* energy, float* pitch, const float* energy_factors, const float* pitch_factors,
                        const int64_t* durations_int, const int64_t* speaker_ids, const float* spk_pitch_mean,
                        const float* spk_pitch_std, int mode, int B, int L, void* stream);
+
+/* ---- K17: mel / energy front-end of the synthesis path (extract_features.py:330-359 `mel_spectrogram_HiFi`,
+ * 299-304 `extract_energy` as applied at generate.py:457 and extract_features.py:465-466).
+ *   mel[b, m, f]   = log(max(sum_k fb[m, k] * sqrt(re^2 + im^2 + 1e-9), min_clip)),  X = STFT(wav[b], n_fft, hop, Hann,
+ *                    center / reflect padding as torch.stft)            frames past the utterance: zeros
+ *   energy[b, f]   = || exp(mel[b, :, f]) ||_2;      n_frames[b] = centered ? 1 + n / hop : 1 + (n - n_fft) / hop
+ * wav (B, ldw) fp32, n_samples (B) int64.  basis / window: device tables filled once by dx_mel_tables
+ * (dx_mel_basis_floats(n_fft) and n_fft floats).  fb (n_mel, n_fft/2 + 1) dense filterbank with the non-zero bin range
+ * [fb_lo[m], fb_hi[m]) of every filter.  mag_ws: scratch of B * T * roundup(n_fft/2 + 1, 4) floats.  mel (B, n_mel, T),
+ * energy (B, T).  T >= max n_frames.  The DFT runs on the exact-fp32 MFMA (fp32 products and accumulation). */
+long dx_mel_basis_floats(int n_fft);
+int dx_mel_tables(float* basis, float* window, int n_fft, void* stream);
+int dx_mel_spectrogram(const float* wav, long ldw, const int64_t* n_samples, const float* basis, const float* window,
+                       const float* fb, const int* fb_lo, const int* fb_hi, float* mag_ws, float* mel, float* energy,
+                       int64_t* n_frames, int B, int T, int n_fft, int hop, int n_mel, int centered, float min_clip,
+                       void* stream);
 
 #ifdef __cplusplus
 }

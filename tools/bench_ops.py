@@ -136,3 +136,27 @@ def bench_attn():
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'attn':
     bench_attn()
+
+
+def bench_mel():
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from daft_exprt import extract_features as fe
+    from daft_exprt.hparams import HyperParams
+    hp = HyperParams(verbose=False, training_files='none', validation_files='none', output_directory='/nonexistent', language='english',
+                     speakers=['a', 'b'])
+    dev = torch.device('cuda:0')
+    for B, secs in ((256, 10.), (48, 11.6), (1, 10.)):
+        S = int(secs * 22050)
+        wavs = (torch.rand(B, S, device=dev) * 2 - 1) * 0.3
+        n = torch.full((B,), S, dtype=torch.int64, device=dev)
+        mel, en, nfr = fe.mel_spectrogram_batch(wavs, n, hp)
+        ms = timeit(lambda: fe.mel_spectrogram_batch(wavs, n, hp), iters=10)
+        frames = float(nfr.sum())
+        fl = frames * (2. * 1024 * 1026 + 2. * 1026)
+        by = frames * (256 * 4 + 2 * 516 * 4 + 80 * 4 + 4)
+        print(f'mel front-end B={B} {secs:.1f}s: {ms:8.3f} ms  {frames / ms / 1e3:8.2f} M frames/s  {fl / ms / 1e9:6.1f} TFLOP/s fp32 '
+              f'({fl / ms / 1e9 / 157.3 * 100:.0f} % of the fp32 MFMA peak)  {by / ms / 1e6:6.1f} GB/s algorithmic  RTF {B * secs / (ms * 1e-3):.0f}x')
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'mel':
+    bench_mel()
