@@ -1,0 +1,66 @@
+"""BASELINE configs[1] full size (B = 48, T <= 1000, dropout ON): size-independent properties of the training step.
+The CPU oracle needs ~100 s for this batch, so the checks here are internal consistency ones:
+  * the fused fast paths (LayerNorm backward inside the data-gradient GEMMs, partial-tile weight gradients) against the
+    plain paths (separate LayerNorm-backward launches, fp32 atomics) on the SAME dropout masks: every one of the 193
+    gradients must agree to fp32-reordering / bf16-operand precision;
+  * a second run of the same step reproduces every prediction bit for bit (no atomics on the forward path) and the loss
+    terms / gradients to atomic-reordering precision;
+  * scaling the loss gradient scales every parameter gradient (linearity of the hand-written backward)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup():
+    import bench
+    from daft_exprt.data_loader import synthetic_batch
+    from daft_exprt.loss import DaftExprtLoss
+    from daft_exprt.model import DaftExprt
+    hp = bench.make_hparams(48, 'bf16')
+    dev = torch.device('cuda:0')
+    torch.manual_seed(hp.seed)
+    model = DaftExprt(hp).to(dev).train()
+    cb = synthetic_batch(hp, 48, seed=1234, t_max=1000, force_first_full=True)
+    inputs, targets, _ = model.parse_batch(dev, cb)
+    weights = DaftExprtLoss(dev, hp).weights(20000)
+    return model, inputs, targets, weights
+
+
+def _step(model, inputs, targets, weights, step_id, scale=1.):
+    model.zero_grad()
+    model._step_id = step_id            # same dropout counters for every call
+    terms = model.forward_backward(inputs, targets, weights, grad_scale=scale)
+    torch.cuda.synchronize()
+    return terms.clone(), model._gflat.clone(), [model.last_outputs[3].clone()] + [t.clone() for t in model.last_outputs[2]]
+
+
+def test_fast_paths_match_plain_paths_and_step_is_reproducible():
+    from daft_exprt import ops
+    model, inputs, targets, weights = _setup()
+    assert int(inputs[9].max()) == 1000 and inputs[0].shape[0] == 48
+    t0, g0, o0 = _step(model, inputs, targets, weights, 7)
+    t1, g1, o1 = _step(model, inputs, targets, weights, 7)
+    assert all(torch.equal(a, b) for a, b in zip(o0, o1))                # mel, durations, energy, pitch: bit-identical
+    assert torch.allclose(t0, t1, rtol=1e-6, atol=0.)                    # loss sums: block partials meet in fp32 atomics
+    gn = float(g0.norm())
+    assert float((g0 - g1).norm()) <= 1e-4 * gn     # per-channel / FiLM atomics reorder, then pass through bf16 GEMM operands
+    model.fuse_ln_backward = False
+    ops.WGRAD_WORKSPACE = False
+    try:
+        t2, g2, o2 = _step(model, inputs, targets, weights, 7)
+    finally:
+        model.fuse_ln_backward = True
+        ops.WGRAD_WORKSPACE = True
+    assert all(torch.equal(a, b) for a, b in zip(o0, o2)) and torch.allclose(t0, t2, rtol=1e-6, atol=0.)
+    assert float((g0 - g2).norm()) <= 1e-3 * gn, float((g0 - g2).norm()) / gn
+    # per-parameter: no tensor may hide behind the global norm
+    off = 0
+    for name, p in model.named_parameters():
+        n = p.numel()
+        a, b = g0[off:off + n], g2[off:off + n]
+        off += n
+        assert float((a - b).norm()) <= 1e-2 * float(a.norm()) + 1e-6 * gn, (name, float((a - b).norm()), float(a.norm()))
+    # linearity in the loss-gradient scale
+    t3, g3, _ = _step(model, inputs, targets, weights, 7, scale=0.5)
+    assert float((g3 * 2 - g0).norm()) <= 1e-4 * gn

@@ -135,16 +135,26 @@ __global__ void gather_add_bwd_kernel(const float* __restrict__ dz, const int64_
 }
 
 // ------------------------------------------------------------------ masked mean over time
-// grid (B, chunks); 128 threads = channels; partial sums combined with atomics into a zeroed output
-__global__ __launch_bounds__(128) void masked_mean_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ lengths,
-                                                              float* __restrict__ out, int N, int rows_per_chunk) {
-  const int c = threadIdx.x, b = blockIdx.x;
-  const int len = (int)lengths[b];
-  const int n0 = blockIdx.y * rows_per_chunk, n1 = min(min(N, len), n0 + rows_per_chunk);  // pads are zeros (masked upstream)
+// grid (B); 1024 threads = 8 row lanes x 128 channels; fixed summation order (lane-strided rows, then the 8 lanes in LDS):
+// the utterance embedding feeds every FiLM parameter, and with bf16 GEMM operands downstream a 1e-7 run-to-run wobble
+// here (fp32 atomics in the first version) flips operand roundings and moves individual mel values by 0.1+
+__global__ __launch_bounds__(1024) void masked_mean_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ lengths,
+                                                               float* __restrict__ out, int N) {
+  __shared__ float red[8][C128];
+  const int c = threadIdx.x & 127, q = threadIdx.x >> 7, b = blockIdx.x;
+  const int len = (int)lengths[b], n1 = min(N, len);             // pads are zeros (masked upstream)
   const float* p = x + (long)b * N * C128 + c;
   float acc = 0.f;
-  for (int n = n0; n < n1; ++n) acc += p[(long)n * C128];
-  if (n1 > n0) atomicAdd(out + b * C128 + c, acc / (float)len);
+#pragma unroll 4
+  for (int n = q; n < n1; n += 8) acc += p[(long)n * C128];
+  red[q][c] = acc;
+  __syncthreads();
+  if (q == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][c];
+    out[b * C128 + c] = len > 0 ? t / (float)len : 0.f;
+  }
 }
 __global__ __launch_bounds__(256) void masked_mean_bwd_kernel(const float* __restrict__ dy, const int64_t* __restrict__ lengths,
                                                               float* __restrict__ dx, int N, long rows) {
@@ -363,9 +373,7 @@ extern "C" int dx_embed_pos_bwd(const int64_t* ids, const float* dout, const int
 extern "C" int dx_masked_mean_fwd(const float* x, const int64_t* lengths, float* out, int B, int N, int C, void* stream) {
   DX_REQUIRE(x && lengths && out, DX_ERR_ARG, "dx_masked_mean_fwd: null pointer");
   DX_REQUIRE(C == C128, DX_ERR_UNSUPPORTED, "dx_masked_mean_fwd: C=%d (only 128)", C);
-  hipMemsetAsync(out, 0, (size_t)B * C128 * sizeof(float), (hipStream_t)stream);
-  const int rpc = 64;
-  hipLaunchKernelGGL(masked_mean_fwd_kernel, dim3(B, dx_cdiv(N, rpc)), dim3(128), 0, (hipStream_t)stream, x, lengths, out, N, rpc);
+  hipLaunchKernelGGL(masked_mean_fwd_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, lengths, out, N);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
