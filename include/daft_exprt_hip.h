@@ -264,14 +264,13 @@ int dx_prosody_control(float* energy, float* pitch, const float* energy_factors,
  *   mel[b, m, f]   = log(max(sum_k fb[m, k] * sqrt(re^2 + im^2 + 1e-9), min_clip)),  X = STFT(wav[b], n_fft, hop, Hann,
  *                    center / reflect padding as torch.stft)            frames past the utterance: zeros
  *   energy[b, f]   = || exp(mel[b, :, f]) ||_2;      n_frames[b] = centered ? 1 + n / hop : 1 + (n - n_fft) / hop
- * wav (B, ldw) fp32, n_samples (B) int64.  basis / window: device tables filled once by dx_mel_tables
- * (dx_mel_basis_floats(n_fft) and n_fft floats).  fb (n_mel, n_fft/2 + 1) dense filterbank with the non-zero bin range
- * [fb_lo[m], fb_hi[m]) of every filter.  mag_ws: scratch of B * T * roundup(n_fft/2 + 1, 4) floats.  mel (B, n_mel, T),
- * energy (B, T).  T >= max n_frames.  The DFT runs on the exact-fp32 MFMA (fp32 products and accumulation). */
-long dx_mel_basis_floats(int n_fft);
-int dx_mel_tables(float* basis, float* window, int n_fft, void* stream);
-int dx_mel_spectrogram(const float* wav, long ldw, const int64_t* n_samples, const float* basis, const float* window,
-                       const float* fb, const int* fb_lo, const int* fb_hi, float* mag_ws, float* mel, float* energy,
+ * wav (B, ldw) fp32, n_samples (B) int64.  twiddle (2 * n_fft floats) / window (n_fft floats): device tables filled
+ * once by dx_mel_tables.  fb (n_mel, n_fft/2 + 1) dense filterbank with the non-zero bin range [fb_lo[m], fb_hi[m]) of
+ * every filter.  mel (B, n_mel, T), energy (B, T).  T >= max n_frames.  n_fft in {256, 1024, 4096} (radix-4 FFT in LDS,
+ * one workgroup per frame). */
+int dx_mel_tables(float* twiddle, float* window, int n_fft, void* stream);
+int dx_mel_spectrogram(const float* wav, long ldw, const int64_t* n_samples, const float* twiddle, const float* window,
+                       const float* fb, const int* fb_lo, const int* fb_hi, float* mel, float* energy,
                        int64_t* n_frames, int B, int T, int n_fft, int hop, int n_mel, int centered, float min_clip,
                        void* stream);
 

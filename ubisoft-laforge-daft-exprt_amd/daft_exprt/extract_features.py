@@ -45,7 +45,7 @@ def _tables(hparams, device):
     key = (str(device), hparams.sampling_rate, hparams.filter_length, hparams.n_mel_channels, hparams.mel_fmin, hparams.mel_fmax)
     if key not in _TABLES:
         n_fft = int(hparams.filter_length)
-        basis = torch.empty(H.lib().dx_mel_basis_floats(n_fft), dtype=torch.float32, device=device)
+        basis = torch.empty(2 * n_fft, dtype=torch.float32, device=device)      # FFT twiddles exp(-2 pi i t / n_fft)
         window = torch.empty(n_fft, dtype=torch.float32, device=device)
         H.check(H.lib().dx_mel_tables(H.ptr(basis), H.ptr(window), n_fft, H.stream()))
         fb = mel_filter_bank(hparams.sampling_rate, n_fft, hparams.n_mel_channels, hparams.mel_fmin, hparams.mel_fmax)
@@ -76,13 +76,11 @@ def mel_spectrogram_batch(wavs, n_samples, hparams):
         raise ValueError('mel_spectrogram: reflect padding needs more than filter_length / 2 samples')
     T = max(1, nb_frames(S, hparams))
     basis, window, fb, lo, hi = _tables(hparams, dev)
-    nb_pad = (n_fft // 2 + 1 + 3) // 4 * 4
-    mag = torch.empty((B, T, nb_pad), dtype=torch.float32, device=dev)
     mel = torch.empty((B, n_mel, T), dtype=torch.float32, device=dev)
     energy = torch.empty((B, T), dtype=torch.float32, device=dev)
     n_frames = torch.empty((B,), dtype=torch.int64, device=dev)
     H.check(H.lib().dx_mel_spectrogram(H.ptr(wavs), wavs.stride(0), H.ptr(n_samples), H.ptr(basis), H.ptr(window), H.ptr(fb),
-                                       H.ptr(lo), H.ptr(hi), H.ptr(mag), H.ptr(mel), H.ptr(energy), H.ptr(n_frames), B, T, n_fft,
+                                       H.ptr(lo), H.ptr(hi), H.ptr(mel), H.ptr(energy), H.ptr(n_frames), B, T, n_fft,
                                        hop, n_mel, int(bool(hparams.centered)), float(hparams.min_clipping), H.stream()))
     return mel, energy, n_frames
 
