@@ -568,11 +568,21 @@ class DaftExprt(nn.Module):
             self._side = torch.cuda.Stream(device=S.enc_out.device)
         self._side_stream = self._side if use_side else None
 
-        def done(name):
-            if self._side_stream is not None:       # the section's weight gradients live on the side stream
-                torch.cuda.current_stream().wait_stream(self._side_stream)
+        def done(name, last=False):
+            ''' a top-level module's gradients are complete once BOTH streams have passed this point.  The compute stream
+                must not stall for that (measured: ~60 us of idle main stream per section): the data-parallel hook is issued
+                from the side stream after it has caught up with the main stream, so the collective orders itself behind
+                both; only the end of the backward pass joins the side stream into the main one (optimizer next). '''
+            side = self._side_stream
             if section_done is not None:
-                section_done(name)
+                if side is not None:
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        section_done(name)
+                else:
+                    section_done(name)
+            if last and side is not None:
+                torch.cuda.current_stream().wait_stream(side)
         hp, P, G = self.hp, self._P, self._G
         W = self._packed
         dev = S.enc_out.device
@@ -665,7 +675,7 @@ class DaftExprt(nn.Module):
         dl2 = self._conv_ln_bwd(W, pe.c3, dl3, lengths_hint=pe.output_lengths)
         dl1 = self._conv_ln_bwd(W, pe.c2, dl2, lengths_hint=pe.output_lengths)
         self._conv_ln_bwd(W, pe.c1, dl1, need_dx=False, lengths_hint=pe.output_lengths)
-        done('prosody_encoder')
+        done('prosody_encoder', last=True)
 
     # ------------------------------------------------------------------ fused training step (no autograd graph)
     SECTIONS = ('prosody_encoder', 'speaker_classifier', 'phoneme_encoder', 'prosody_predictor', 'gaussian_upsampling',
