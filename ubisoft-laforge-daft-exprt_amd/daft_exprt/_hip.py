@@ -71,7 +71,14 @@ def dt(t):
     return _DT[t.dtype]
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream():
+    ''' raw hipStream_t of torch's current stream (the C hook is ~10x cheaper than building a torch.cuda.Stream object;
+        ~340 calls per training step) '''
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -173,6 +173,7 @@ class DaftExprt(nn.Module):
         self.always_repack = True   # safe default for external optimizers; the fused trainer turns it off
         self._anchor = None
         self._side = self._side_stream = None
+        self._wgrad_keep = []
         self.fuse_ln_backward = bool(int(__import__('os').environ.get('DX_FUSE_LN_BWD', '1')))   # see _fft_block_bwd
         self._step_id, self._site = 0, 0
         self._pos = None
@@ -486,8 +487,9 @@ class DaftExprt(nn.Module):
         side.wait_stream(main)                      # dy / x were produced on the main stream
         with torch.cuda.stream(side):
             ops.conv1d_wgrad(dy, x, dw, db, self.cd, lengths)
-        dy.record_stream(side)                      # keep the allocator from recycling them under the side stream
-        x.record_stream(side)
+        # keep the operands alive until the side stream has joined the main one at the end of the backward pass (cheaper on
+        # the host than two record_stream calls per launch; the small-N encoder blocks are host-bound)
+        self._wgrad_keep.append((dy, x))
 
     def _fft_stack_bwd(self, W, blocks, du, dfilms):
         ''' backward through a stack of FFT blocks, top block first.  dfilms: (B, nb_blocks, 2C) gradient view or None '''
@@ -583,6 +585,7 @@ class DaftExprt(nn.Module):
                     section_done(name)
             if last and side is not None:
                 torch.cuda.current_stream().wait_stream(side)
+                self._wgrad_keep.clear()            # freed on the main stream, which is now behind every side-stream read
         hp, P, G = self.hp, self._P, self._G
         W = self._packed
         dev = S.enc_out.device
