@@ -136,19 +136,28 @@ def pack_weights_batched(table, n, total, dtype):
     H.check(H.lib().dx_pack_conv_weights_batched(H.ptr(table), n, total, H._DT[dtype], H.stream()))
 
 
-def conv1d_wgrad(dy, x, dw, db, compute_dtype, lengths=None):
-    ''' dw (Cout, Cin, taps) / (Cout, Cin) fp32 and db (Cout) are ACCUMULATED. dy (B,N,Cout), x (B,N,Cin). '''
+def conv1d_wgrad(dy, x, dw, db, compute_dtype, lengths=None, stream=None, ws=None):
+    ''' dw (Cout, Cin, taps) / (Cout, Cin) fp32 and db (Cout) are ACCUMULATED. dy (B,N,Cout), x (B,N,Cin).
+        stream: raw hipStream_t to launch on (default: torch's current stream); ws: caller-owned scratch of at least
+        `wgrad_ws_floats(...)` floats that stays valid until the launch has completed on that stream. '''
     B, N, Cout = dy.shape
     Cin = x.shape[2]
     taps = dw.shape[2] if dw.dim() == 3 else 1
     assert dw.shape[0] == Cout and dw.shape[1] == Cin and dy.stride(2) == 1 and x.stride(2) == 1
     # scratch for the per-workgroup partial tiles; allocated on the current stream (the caching allocator keeps it
     # stream-ordered), ~25 MB for the wide convolutions
-    ws = torch.empty(H.lib().dx_conv1d_wgrad_ws_floats(B, N, Cin, Cout, taps), dtype=torch.float32, device=dy.device) if WGRAD_WORKSPACE else None
+    if not WGRAD_WORKSPACE:
+        ws = None
+    elif ws is None:
+        ws = torch.empty(H.lib().dx_conv1d_wgrad_ws_floats(B, N, Cin, Cout, taps), dtype=torch.float32, device=dy.device)
     with _Probe('conv_wgrad', 2. * B * N * Cin * Cout * taps, N):
       H.check(H.lib().dx_conv1d_wgrad(H.ptr(dy), H.dt(dy), dy.stride(1), H.ptr(x), H.dt(x), x.stride(1),
                                     H._DT[compute_dtype], H.ptr(dw), H.ptr(db), H.ptr(lengths), H.ptr(ws), B, N, Cin, Cout, taps,
-                                    H.stream()))
+                                    H.stream() if stream is None else stream))
+
+
+def wgrad_ws_floats(B, N, Cin, Cout, taps):
+    return H.lib().dx_conv1d_wgrad_ws_floats(B, N, Cin, Cout, taps)
 
 
 # ----------------------------------------------------------------------------- LayerNorm (+ residual, dropout, FiLM, mask)
