@@ -567,9 +567,11 @@ class DaftExprt(nn.Module):
         dc, _ = ops.layernorm_bwd(dy, s.c, s.mean, s.rstd, P[f'{s.ln_name}.weight'], P[f'{s.ln_name}.bias'],
                                   G[f'{s.ln_name}.weight'], G[f'{s.ln_name}.bias'], film=s.film, dfilm=dfilm, lengths=s.lengths,
                                   d_dtype=s.c.dtype, p_post=s.p, seed_post=s.seed, relu_input=True, skip_lengths=s.skip)
-        self._wgrad(dc, s.x, G[f'{s.conv_name}.conv.weight'], G[f'{s.conv_name}.conv.bias'], lengths_hint)
-        if not need_dx:
+        if not need_dx:   # last op of the backward pass: nothing left on the main stream to overlap with, and the side stream
+            # still has the previous (large) weight gradient queued -- launch here
+            ops.conv1d_wgrad(dc, s.x, G[f'{s.conv_name}.conv.weight'], G[f'{s.conv_name}.conv.bias'], self.cd, lengths_hint)
             return None
+        self._wgrad(dc, s.x, G[f'{s.conv_name}.conv.weight'], G[f'{s.conv_name}.conv.bias'], lengths_hint)
         if dx_out is not None:
             return ops.conv1d(dc, W[f'T:{s.conv_name}.conv.weight'], None, out=dx_out, accumulate=True, skip_lengths=s.skip)
         return ops.conv1d(dc, W[f'T:{s.conv_name}.conv.weight'], None, out_dtype=s.x.dtype, skip_lengths=s.skip)
