@@ -63,4 +63,4 @@ def test_fast_paths_match_plain_paths_and_step_is_reproducible():
         assert float((a - b).norm()) <= 1e-2 * float(a.norm()) + 1e-6 * gn, (name, float((a - b).norm()), float(a.norm()))
     # linearity in the loss-gradient scale
     t3, g3, _ = _step(model, inputs, targets, weights, 7, scale=0.5)
-    assert float((g3 * 2 - g0).norm()) <= 1e-4 * gn
+    assert float((g3 * 2 - g0).norm()) <= 3e-4 * gn
