@@ -105,7 +105,14 @@ __global__ __launch_bounds__(NTHREADS, MI == 1 ? (LN == 2 ? 3 : DX_CONV_WPS_NARR
   constexpr int BM = 64 * MI, KC = BK / 8;   // KC = 8-element chunks per row of a K chunk
   constexpr int HALO = TAPS / 2;
   constexpr int AROWS = BM + TAPS - 1;
-  constexpr int LDS_K = BK + Pad<TC>::value;
+  // LDS image of the operand tiles.  bf16 (BK = 32: four 16-byte chunks per row): NO padding, chunk c of row r sits at
+  // chunk position c ^ ((r >> 2) & 3) -- the 16 rows of a ds_read_b128 lane group then cover all 64 banks, and the
+  // 8 lanes of a ds_write_b128 group (2 rows x 4 chunks) cover 32 distinct banks.  (The padded 80-byte rows read
+  // conflict-free but staged with 2-way write conflicts: SQ_LDS_BANK_CONFLICT was 30 % of the LDS cycles of a kernel
+  // whose LDS pipe -- ds_write_b128 of the weight tile above all -- is busier than its matrix pipe.)  fp32: padded rows.
+  constexpr bool SWZ = sizeof(TC) == 2 && BK == 32;
+  constexpr int LDS_K = SWZ ? BK : BK + Pad<TC>::value;
+  auto lds_at = [](int row, int chunk) { return SWZ ? row * LDS_K + ((chunk ^ ((row >> 2) & 3)) << 3) : row * LDS_K + (chunk << 3); };
   constexpr int A_CH = AROWS * (BK / 8), A_PT = (A_CH + NTHREADS - 1) / NTHREADS;
   constexpr int W_PT = TAPS * BN * (BK / 8) / NTHREADS;
   constexpr int STG_LD = BN + 4;
@@ -217,13 +224,13 @@ __global__ __launch_bounds__(NTHREADS, MI == 1 ? (LN == 2 ? 3 : DX_CONV_WPS_NARR
 #pragma unroll
     for (int t = 0; t < A_PT; ++t) {
       const int c = tid + t * NTHREADS;
-      if (c < A_CH) *reinterpret_cast<frag_t*>(&As[(c / KC) * LDS_K + (c % KC) * 8]) = cvt8<TA, TC>(ra[t]);
+      if (c < A_CH) *reinterpret_cast<frag_t*>(&As[lds_at(c / KC, c % KC)]) = cvt8<TA, TC>(ra[t]);
     }
 #pragma unroll
     for (int t = 0; t < W_PT; ++t) {
       const int c = tid + t * NTHREADS;
       const int tap = c / (BN * KC), rem = c - tap * (BN * KC);
-      *reinterpret_cast<frag_t*>(&Ws[(tap * BN + rem / KC) * LDS_K + (rem % KC) * 8]) = rw[t];
+      *reinterpret_cast<frag_t*>(&Ws[lds_at(tap * BN + rem / KC, rem % KC)]) = rw[t];
     }
   };
 
@@ -240,10 +247,10 @@ __global__ __launch_bounds__(NTHREADS, MI == 1 ? (LN == 2 ? 3 : DX_CONV_WPS_NARR
         frag_t a[MI], bf[2];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
-          a[i] = *reinterpret_cast<const frag_t*>(&As[(wm * 32 * MI + i * 32 + l31 + tap) * LDS_K + ks * 16 + g * 8]);
+          a[i] = *reinterpret_cast<const frag_t*>(&As[lds_at(wm * 32 * MI + i * 32 + l31 + tap, ks * 2 + g)]);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          bf[j] = *reinterpret_cast<const frag_t*>(&Ws[(tap * BN + wn * 64 + j * 32 + l31) * LDS_K + ks * 16 + g * 8]);
+          bf[j] = *reinterpret_cast<const frag_t*>(&Ws[lds_at(tap * BN + wn * 64 + j * 32 + l31, ks * 2 + g)]);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
