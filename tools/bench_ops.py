@@ -27,7 +27,7 @@ def timeit(fn, iters=20, warmup=3):
 
 def bench_conv():
     dev = torch.device('cuda:0')
-    B, N = 48, 1000
+    B, N = int(os.environ.get('BENCH_B', '48')), 1000
     for (cin, cout, taps) in [(80, 1024, 3), (1024, 1024, 3), (1024, 128, 3), (128, 1024, 3), (128, 384, 1), (128, 128, 1), (128, 80, 1)]:
         for cd, xd, yd in [(torch.bfloat16, torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32, torch.float32)]:
             x = torch.randn(B, N, cin, device=dev).to(xd)

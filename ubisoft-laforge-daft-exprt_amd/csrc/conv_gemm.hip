@@ -719,7 +719,18 @@ bool try_weight_stationary(const ConvArgs& a, int B, int taps, hipStream_t s) {
 template <typename TA, typename TC, typename TO, typename TG, int LN = 0>
 int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
   const int ztiles = dx_cdiv(a.Cout, BN);
-  if constexpr (LN != 0) {   // LayerNorm epilogues: one channel tile (Cout = 128), 64-row tiles
+  // Narrow-output GEMMs (Cout <= 128, k = 3): 128-row tiles stage the weight chunk once per 128 rows (the LDS write of the
+  // weight tile is the busiest part of the kernel: 818 vs 609 TFLOP/s on a dense B = 256 problem) but need enough tiles to
+  // fill the chip; 64-row tiles otherwise.  Measured in the training step: B = 48 equal, B = 128 +2 % for 128 rows.
+  static int forced_mi = getenv("DX_CONV_NARROW_MI") ? atoi(getenv("DX_CONV_NARROW_MI")) : 0;
+  const int narrow_mi = forced_mi ? forced_mi : ((long)B * a.N > 64000 ? 2 : 1);
+  if constexpr (LN != 0) {   // LayerNorm epilogues: one channel tile (Cout = 128)
+    if (narrow_mi == 2 && taps == 3) {
+      const long pt2 = (long)dx_cdiv(a.N, 128) * B;
+      hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 2, 32, LN>), dim3((unsigned)(((pt2 + 7) / 8) * 8)), dim3(NTHREADS), 0, s, a);
+      DX_LAUNCH_CHECK();
+      return DX_OK;
+    }
     const long ptiles = (long)dx_cdiv(a.N, 64) * B;
     dim3 grid((unsigned)(((ptiles + 7) / 8) * 8)), block(NTHREADS);
     if (taps == 1) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 1, 32, LN>), grid, block, 0, s, a);
@@ -728,7 +739,7 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
     return DX_OK;
   } else {
     if (try_weight_stationary<TA, TC, TO, TG>(a, B, taps, s)) { DX_LAUNCH_CHECK(); return DX_OK; }
-    const int mi = ztiles == 1 ? 1 : 2;                       // 64-row tiles for the narrow-output GEMMs
+    const int mi = ztiles == 1 ? (taps == 3 ? narrow_mi : 1) : 2;                       // 64-row tiles for the narrow-output GEMMs
     const long ptiles = (long)dx_cdiv(a.N, 64 * mi) * B;
     dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * ztiles)), block(NTHREADS);
     if (taps == 1 && mi == 1) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 1, 32>), grid, block, 0, s, a);
