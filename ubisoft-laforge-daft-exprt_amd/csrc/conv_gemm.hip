@@ -100,8 +100,11 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
 #ifndef DX_CONV_WPS_NARROW
 #define DX_CONV_WPS_NARROW 4
 #endif
-template <typename TA, typename TC, typename TO, typename TG, int TAPS, int MI, int BK, int LN = 0>
-__global__ __launch_bounds__(NTHREADS, MI == 1 ? (LN == 2 ? 3 : DX_CONV_WPS_NARROW) : DX_CONV_WPS) void conv_gemm_kernel(ConvArgs p) {
+// LNM: 0 none, 1 forward LayerNorm, 2 backward LayerNorm with FiLM gradients, 3 backward LayerNorm without FiLM
+template <typename TA, typename TC, typename TO, typename TG, int TAPS, int MI, int BK, int LNM = 0>
+__global__ __launch_bounds__(NTHREADS, MI == 1 ? DX_CONV_WPS_NARROW : DX_CONV_WPS) void conv_gemm_kernel(ConvArgs p) {
+  constexpr int LN = LNM == 3 ? 2 : LNM;
+  constexpr bool LNFILM = LNM == 2;
   constexpr int BM = 64 * MI, KC = BK / 8;   // KC = 8-element chunks per row of a K chunk
   constexpr int HALO = TAPS / 2;
   constexpr int AROWS = BM + TAPS - 1;
@@ -265,9 +268,10 @@ __global__ __launch_bounds__(NTHREADS, MI == 1 ? (LN == 2 ? 3 : DX_CONV_WPS_NARR
   }
 
   // ---- epilogue
-  float csum[LN == 2 ? 4 : 1][8];   // LN backward: this thread's column sums (dgamma, dbeta, dfilm_g, dfilm_b) over its rows
+  constexpr int NCS = LNM == 2 ? 4 : (LNM == 3 ? 2 : 1);
+  float csum[NCS][8];   // LN backward: this thread's column sums (dgamma, dbeta [, dfilm_g, dfilm_b]) over its rows
 #pragma unroll
-  for (int q = 0; q < (LN == 2 ? 4 : 1); ++q)
+  for (int q = 0; q < NCS; ++q)
 #pragma unroll
     for (int e = 0; e < 8; ++e) csum[q][e] = 0.f;
   if (vec_out) {
@@ -309,12 +313,12 @@ __global__ __launch_bounds__(NTHREADS, MI == 1 ? (LN == 2 ? 3 : DX_CONV_WPS_NARR
             float xh[8], s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) xh[e] = (sv[e] - mean) * rstd;
-            if (p.ln.film) {                                      // y = fg * LN + fb
+            if (LNFILM) {                                         // y = fg * LN + fb
               const f32x8 fg = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + cl), bt = raw_load8<float>(p.ln.beta + cl);
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
-                csum[2][e] += v[e] * (xh[e] * gm[e] + bt[e]);
-                csum[3][e] += v[e];
+                csum[LNFILM ? 2 : 0][e] += v[e] * (xh[e] * gm[e] + bt[e]);
+                csum[LNFILM ? 3 : 0][e] += v[e];
                 v[e] *= fg[e];
               }
             }
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(NTHREADS, MI == 1 ? (LN == 2 ? 3 : DX_CONV_WPS_NARR
       __syncthreads();
     }
     if (LN == 2) {   // column sums: 16 row-threads per channel segment -> LDS -> one atomic per channel per workgroup
-      const int nq = p.ln.film ? 4 : 2;
+      constexpr int nq = NCS;
       for (int q = 0; q < nq; ++q)
 #pragma unroll
         for (int e = 0; e < 8; ++e) stage[(q * 16 + (tid >> 4)) * BN + (tid & 15) * 8 + e] = csum[q][e];
@@ -725,16 +729,25 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
   static int forced_mi = getenv("DX_CONV_NARROW_MI") ? atoi(getenv("DX_CONV_NARROW_MI")) : 0;
   const int narrow_mi = forced_mi ? forced_mi : ((long)B * a.N > 64000 ? 2 : 1);
   if constexpr (LN != 0) {   // LayerNorm epilogues: one channel tile (Cout = 128)
+    constexpr int LNB = LN == 2 ? 3 : LN;             // backward without FiLM gradients: fewer registers
+    const bool film = LN == 2 && a.ln.film != nullptr;
     if (narrow_mi == 2 && taps == 3) {
       const long pt2 = (long)dx_cdiv(a.N, 128) * B;
-      hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 2, 32, LN>), dim3((unsigned)(((pt2 + 7) / 8) * 8)), dim3(NTHREADS), 0, s, a);
+      dim3 grid2((unsigned)(((pt2 + 7) / 8) * 8));
+      if (film) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 2, 32, LN>), grid2, dim3(NTHREADS), 0, s, a);
+      else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 2, 32, LNB>), grid2, dim3(NTHREADS), 0, s, a);
       DX_LAUNCH_CHECK();
       return DX_OK;
     }
     const long ptiles = (long)dx_cdiv(a.N, 64) * B;
     dim3 grid((unsigned)(((ptiles + 7) / 8) * 8)), block(NTHREADS);
-    if (taps == 1) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 1, 32, LN>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 1, 32, LN>), grid, block, 0, s, a);
+    if (taps == 1) {
+      if (film) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 1, 32, LN>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 1, 32, LNB>), grid, block, 0, s, a);
+    } else {
+      if (film) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 1, 32, LN>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 1, 32, LNB>), grid, block, 0, s, a);
+    }
     DX_LAUNCH_CHECK();
     return DX_OK;
   } else {
