@@ -60,6 +60,20 @@ def test_conv_bf16(shape, taps):
     _run(B, N, Cin, Cout, taps, torch.bfloat16, torch.bfloat16, torch.float32)
 
 
+def test_conv_tall_tiles():
+    ''' 256-row tiles (MI = 4) of the wide k = 3 GEMMs: forced on a small problem -- ragged N, one utterance shorter than a tile '''
+    import os
+    import subprocess
+    import sys
+    code = ("import torch, sys; sys.path.insert(0, 'tests'); import test_gpu_conv as t; "
+            "t._run(3, 300, 1024, 256, 3, torch.bfloat16, torch.bfloat16, torch.bfloat16, relu=True, mask=True); "
+            "t._run(2, 77, 512, 384, 3, torch.bfloat16, torch.bfloat16, torch.float32, gate=True); print('ok')")
+    env = dict(os.environ, DX_CONV_WIDE_MI='4')
+    env['PYTHONPATH'] = os.pathsep.join([os.getcwd(), os.path.join(os.getcwd(), 'ubisoft-laforge-daft-exprt_amd'), env.get('PYTHONPATH', '')])
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, cwd=os.getcwd())
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stdout + r.stderr
+
+
 def test_conv_epilogues():
     _run(2, 70, 128, 1024, 3, torch.float32, torch.float32, torch.float32, relu=True)
     _run(2, 70, 128, 80, 1, torch.float32, torch.float32, torch.float32, mask=True, trans=True)

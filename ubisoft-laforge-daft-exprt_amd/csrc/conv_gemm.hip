@@ -11,11 +11,17 @@
 // Operand type TC: bf16 (v_mfma_f32_32x32x16_bf16) or fp32 (v_mfma_f32_32x32x2_f32, exact fp32 mode).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "dx_common.h"
 
 namespace {
 
 constexpr int BN = 128, NTHREADS = 256;
+
+// zeros for the LDS-DMA lanes whose row lies outside the utterance / the weight matrix (read at offsets < 2 * Cin bytes)
+constexpr int DX_ZERO_PAGE_EL = 4096;
+__device__ __attribute__((aligned(16))) unsigned short dx_zero_page[DX_ZERO_PAGE_EL + 32];
 
 template <typename TC> struct Pad;
 template <> struct Pad<bf16_t> { static constexpr int value = 8; };
@@ -101,8 +107,23 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
 #define DX_CONV_WPS_NARROW 4
 #endif
 // LNM: 0 none, 1 forward LayerNorm, 2 backward LayerNorm with FiLM gradients, 3 backward LayerNorm without FiLM
-template <typename TA, typename TC, typename TO, typename TG, int TAPS, int MI, int BK, int LNM = 0>
-__global__ __launch_bounds__(NTHREADS, MI == 1 ? DX_CONV_WPS_NARROW : DX_CONV_WPS) void conv_gemm_kernel(ConvArgs p) {
+// LDS-DMA ring pipeline (conv_gemm_kernel<..., RING>): bf16 operands, long contractions.  OPT-IN (DX_CONV_RING=1):
+// measured on MI355X it ties with the register-staged pipeline (1024 -> 1024 k3: 814 vs 818 TFLOP/s; 1024 -> 128 k3
+// 55 vs 61 us plain, 78 vs 72 us with the LayerNorm epilogue; training step 9.35 vs 9.36 ms) because neither is bound by
+// its pipeline: a CU fetches at most ~30 B/clk from L2 (tools/probes/lds_dma_rate_probe.hip: 16-17 TB/s chip-wide for
+// global_load_lds_dwordx4, 14 TB/s for loads to registers, independent of row width and of the number of pieces in
+// flight), a 128 x 128 x (3 x 32) chunk needs 36 KB for 768 MFMA cycles = 47 B/clk, and the ablations of this kernel
+// give 306 us with the MFMA waves idle, 237 us with the loaders idle, 367 us together.  Past ~800 TFLOP/s the lever
+// is bytes per FLOP per CU (taller position tiles when the batch has enough of them), not the pipeline.
+#ifndef DX_RING
+#define DX_RING 4
+#endif
+#ifndef DX_RING_ABL
+#define DX_RING_ABL 0   // compile-time ablation (development): 1 no fragment reads / MFMAs, 2 no loads
+#endif
+// RING: 0 = register-staged single-buffer pipeline; S >= 2 = S-stage LDS ring filled by four loader waves (512 threads, bf16)
+template <typename TA, typename TC, typename TO, typename TG, int TAPS, int MI, int BK, int LNM = 0, int RING = 0>
+__global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1 ? DX_CONV_WPS_NARROW : DX_CONV_WPS)) void conv_gemm_kernel(ConvArgs p) {
   constexpr int LN = LNM == 3 ? 2 : LNM;
   constexpr bool LNFILM = LNM == 2;
   constexpr int BM = 64 * MI, KC = BK / 8;   // KC = 8-element chunks per row of a K chunk
@@ -119,7 +140,10 @@ __global__ __launch_bounds__(NTHREADS, MI == 1 ? DX_CONV_WPS_NARROW : DX_CONV_WP
   constexpr int A_CH = AROWS * (BK / 8), A_PT = (A_CH + NTHREADS - 1) / NTHREADS;
   constexpr int W_PT = TAPS * BN * (BK / 8) / NTHREADS;
   constexpr int STG_LD = BN + 4;
-  constexpr int OPER_BYTES = (AROWS + TAPS * BN) * LDS_K * (int)sizeof(TC), STG_BYTES = 64 * STG_LD * 4;
+  // ring image of one K chunk: activation rows rounded up to whole 16-row DMA pieces, then the taps x 128 weight rows
+  // (and padded to a multiple of 4 pieces: every wave issues the same number of DMA instructions per chunk)
+  constexpr int AR16 = (AROWS + 15) & ~15, STAGE_EL = ((AR16 + TAPS * BN) / 16 + 3) / 4 * 4 * 512;
+  constexpr int OPER_BYTES = RING ? RING * STAGE_EL * 2 : (AROWS + TAPS * BN) * LDS_K * (int)sizeof(TC), STG_BYTES = 64 * STG_LD * 4;
   typedef typename Vec8<TC>::type frag_t;
   typedef typename VecN<TA, 8>::type raw_t;
   __shared__ __attribute__((aligned(16))) char smem[OPER_BYTES > STG_BYTES ? OPER_BYTES : STG_BYTES];
@@ -153,6 +177,7 @@ __global__ __launch_bounds__(NTHREADS, MI == 1 ? DX_CONV_WPS_NARROW : DX_CONV_WP
 
   // padding early-out: a tile that starts past length + conv halo cannot reach a valid output -> zeros, no MFMA
   if (p.skip_len && n0 >= (int)p.skip_len[b] + 2) {
+    if (RING && tid >= NTHREADS) return;             // loader waves
     if (LN == 2) {   // incoming residual gradient rows are zero there and stay; the bf16 dx_pre rows must exist as zeros
       float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       for (int c = tid; c < BM * (BN / 8); c += NTHREADS) {
@@ -201,69 +226,156 @@ __global__ __launch_bounds__(NTHREADS, MI == 1 ? DX_CONV_WPS_NARROW : DX_CONV_WP
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  raw_t ra[A_PT];
-  frag_t rw[W_PT];
-  auto fetch = [&](int k0) {
+  if constexpr (RING > 0) {
+    // ---- LDS-DMA ring with dedicated loader waves (bf16 operands, Cin % 32 == 0; 512-thread workgroup).
+    // Waves 0-3 run the MFMAs exactly as in the register-staged pipeline; waves 4-7 (one per SIMD, next to an MFMA
+    // wave) only move data: measured with the MFMA waves issuing their own loads, a 1-wave-per-SIMD workgroup spends
+    // more time ISSUING global -> LDS pieces (~100 cycles each, in order with its MFMAs) than the MFMAs take.
+    // A K chunk's image is (AR16 + TAPS * 128) rows of 64 bytes in the swizzled layout of lds_at, written by
+    // global_load_lds_dwordx4 pieces of 16 rows (1 KiB per wave instruction; LDS destination = piece base + 16 * lane,
+    // so the swizzle is applied to each lane's SOURCE chunk).  Piece q belongs to loader q % 4; rows outside the
+    // utterance / beyond Cout read a zero page.
+    // Per chunk k, ONE workgroup barrier: a loader arrives after its pieces of chunk k have landed (counted vmcnt: the
+    // RING - 2 younger chunks stay in flight), an MFMA wave after it has finished reading chunk k - 1.  Past the
+    // barrier the MFMA waves read chunk k and the loaders refill the buffer chunk k - 1 just left with chunk k + RING - 1.
+    static_assert(sizeof(TA) == 2 && sizeof(TC) == 2 && BK == 32, "ring pipeline: bf16 operands, 32-channel chunks");
+    constexpr int A_INS = AR16 / 16, W_INS = TAPS * BN / 16, T_INS = A_INS + W_INS;
+    constexpr int CNT = (T_INS + 3) / 4, NSTEP = TAPS * 2;     // pieces per loader per chunk; pieces >= T_INS are padding
+    TC* ring = reinterpret_cast<TC*>(smem);
+    const int nk = Cin >> 5;
+    if (wave >= 4) {
+      const int lw = __builtin_amdgcn_readfirstlane(wave) - 4;
+      const TC* src[CNT];
 #pragma unroll
-    for (int t = 0; t < A_PT; ++t) {
-      const int c = tid + t * NTHREADS;
-      const int r = c / KC, kc = (c % KC) * 8;
-      const int n = n0 + r - HALO, ci = k0 + kc;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) ra[t][e] = (TA)0.f;
-      if (c < A_CH && n >= 0 && n < N && ci < Cin) ra[t] = raw_load8<TA>(X + (size_t)n * p.ldx + ci);
-    }
-#pragma unroll
-    for (int t = 0; t < W_PT; ++t) {
-      const int c = tid + t * NTHREADS;
-      const int tap = c / (BN * KC), rem = c - tap * (BN * KC);
-      const int row = rem / KC, kc = (rem % KC) * 8;
-      const int co = co0 + row, ci = k0 + kc;
-      rw[t] = zero8<TC>();
-      if (co < Cout && ci < Cin) rw[t] = *reinterpret_cast<const frag_t*>(W + ((size_t)tap * Cout + co) * Cin + ci);
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int t = 0; t < A_PT; ++t) {
-      const int c = tid + t * NTHREADS;
-      if (c < A_CH) *reinterpret_cast<frag_t*>(&As[lds_at(c / KC, c % KC)]) = cvt8<TA, TC>(ra[t]);
-    }
-#pragma unroll
-    for (int t = 0; t < W_PT; ++t) {
-      const int c = tid + t * NTHREADS;
-      const int tap = c / (BN * KC), rem = c - tap * (BN * KC);
-      *reinterpret_cast<frag_t*>(&Ws[lds_at(tap * BN + rem / KC, rem % KC)]) = rw[t];
-    }
-  };
-
-  fetch(0);
-  commit();
-  __syncthreads();
-  for (int k0 = 0; k0 < Cin; k0 += BK) {
-    const bool more = k0 + BK < Cin;
-    if (more) fetch(k0 + BK);
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-#pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        frag_t a[MI], bf[2];
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-          a[i] = *reinterpret_cast<const frag_t*>(&As[lds_at(wm * 32 * MI + i * 32 + l31 + tap, ks * 2 + g)]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          bf[j] = *reinterpret_cast<const frag_t*>(&Ws[lds_at(tap * BN + wn * 64 + j * 32 + l31, ks * 2 + g)]);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) dx_mma(acc[i][j], a[i], bf[j]);
+      for (int t = 0; t < CNT; ++t) {
+        const int q = lw + 4 * t, r = q * 16 + (lane >> 2);     // row of the chunk image this lane fills
+        const int c = (lane & 3) ^ ((r >> 2) & 3);                // source chunk that belongs at position lane & 3
+        const TC* sp = reinterpret_cast<const TC*>(dx_zero_page) + c * 8;
+        const int n = n0 + r - HALO, wr = r - AR16, co = co0 + (wr & (BN - 1));
+        const TC* xa = reinterpret_cast<const TC*>(X) + (long)n * p.ldx + c * 8;
+        const TC* wa = W + ((size_t)(wr / BN) * Cout + co) * Cin + c * 8;
+        sp = (r < AROWS && n >= 0 && n < N) ? xa : sp;
+        sp = (q >= A_INS && q < T_INS && co < Cout) ? wa : sp;
+        src[t] = sp;
       }
+      auto issue_chunk = [&](int kc, int buf) {
+        if (DX_RING_ABL & 2) return;
+#pragma unroll
+        for (int t = 0; t < CNT; ++t)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + kc * 32),
+                                           (__attribute__((address_space(3))) void*)(ring + buf * STAGE_EL + (lw + 4 * t) * 512), 16, 0, 0);
+      };
+#pragma unroll
+      for (int st = 0; st < RING - 1; ++st)
+        if (st < nk) issue_chunk(st, st);
+      int nbuf = RING - 1, k = 0;                                // buffer that chunk k + RING - 1 goes to
+      for (; k + RING - 1 < nk; ++k) {
+        if (RING > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT * (RING - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_chunk(k + RING - 1, nbuf);
+        nbuf = nbuf + 1 == RING ? 0 : nbuf + 1;
+      }
+      for (; k < nk; ++k) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      return;                                                     // the epilogue belongs to the MFMA waves
     }
+    auto load_frags = [&](const TC* Ar, const TC* Wr, int step, frag_t* a, frag_t* bf) {
+      const int tap = step >> 1, ks = step & 1;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const frag_t*>(&Ar[lds_at(wm * 32 * MI + i * 32 + l31 + tap, ks * 2 + g)]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const frag_t*>(&Wr[lds_at(tap * BN + wn * 64 + j * 32 + l31, ks * 2 + g)]);
+    };
+    int buf = 0;
+    for (int k = 0; k < nk; ++k) {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const TC* Ar = ring + buf * STAGE_EL;
+      const TC* Wr = Ar + AR16 * 32;
+      frag_t a[2][MI], bf[2][2];
+      if (DX_RING_ABL & 1) { buf = buf + 1 == RING ? 0 : buf + 1; continue; }
+      load_frags(Ar, Wr, 0, a[0], bf[0]);
+#pragma unroll
+      for (int step = 0; step < NSTEP; ++step) {     // fragments of k-step s + 1 are read before the MFMAs of k-step s
+        if (step + 1 < NSTEP) load_frags(Ar, Wr, step + 1, a[(step + 1) & 1], bf[(step + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) dx_mma(acc[i][j], a[step & 1][i], bf[step & 1][j]);
+      }
+      buf = buf + 1 == RING ? 0 : buf + 1;
+    }
+    __syncthreads();                                 // every MFMA wave is done with the ring: the epilogue stages through it
+  } else {
+  raw_t ra[A_PT];
+    frag_t rw[W_PT];
+    auto fetch = [&](int k0) {
+#pragma unroll
+      for (int t = 0; t < A_PT; ++t) {
+        const int c = tid + t * NTHREADS;
+        const int r = c / KC, kc = (c % KC) * 8;
+        const int n = n0 + r - HALO, ci = k0 + kc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ra[t][e] = (TA)0.f;
+        if (c < A_CH && n >= 0 && n < N && ci < Cin) ra[t] = raw_load8<TA>(X + (size_t)n * p.ldx + ci);
+      }
+#pragma unroll
+      for (int t = 0; t < W_PT; ++t) {
+        const int c = tid + t * NTHREADS;
+        const int tap = c / (BN * KC), rem = c - tap * (BN * KC);
+        const int row = rem / KC, kc = (rem % KC) * 8;
+        const int co = co0 + row, ci = k0 + kc;
+        rw[t] = zero8<TC>();
+        if (co < Cout && ci < Cin) rw[t] = *reinterpret_cast<const frag_t*>(W + ((size_t)tap * Cout + co) * Cin + ci);
+      }
+    };
+    auto commit = [&]() {
+#pragma unroll
+      for (int t = 0; t < A_PT; ++t) {
+        const int c = tid + t * NTHREADS;
+        if (c < A_CH) *reinterpret_cast<frag_t*>(&As[lds_at(c / KC, c % KC)]) = cvt8<TA, TC>(ra[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < W_PT; ++t) {
+        const int c = tid + t * NTHREADS;
+        const int tap = c / (BN * KC), rem = c - tap * (BN * KC);
+        *reinterpret_cast<frag_t*>(&Ws[lds_at(tap * BN + rem / KC, rem % KC)]) = rw[t];
+      }
+    };
+  
+    fetch(0);
+    commit();
     __syncthreads();
-    if (more) {
-      commit();
+    for (int k0 = 0; k0 < Cin; k0 += BK) {
+      const bool more = k0 + BK < Cin;
+      if (more) fetch(k0 + BK);
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+          frag_t a[MI], bf[2];
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+            a[i] = *reinterpret_cast<const frag_t*>(&As[lds_at(wm * 32 * MI + i * 32 + l31 + tap, ks * 2 + g)]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            bf[j] = *reinterpret_cast<const frag_t*>(&Ws[lds_at(tap * BN + wn * 64 + j * 32 + l31, ks * 2 + g)]);
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dx_mma(acc[i][j], a[i], bf[j]);
+        }
+      }
       __syncthreads();
+      if (more) {
+        commit();
+        __syncthreads();
+      }
     }
   }
 
@@ -720,6 +832,12 @@ bool try_weight_stationary(const ConvArgs& a, int B, int taps, hipStream_t s) {
   }
 }
 
+static bool ring_ok(const ConvArgs& a) {
+  static int enabled = getenv("DX_CONV_RING") ? atoi(getenv("DX_CONV_RING")) : 0;
+  static int min_cin = getenv("DX_CONV_RING_MIN_CIN") ? atoi(getenv("DX_CONV_RING_MIN_CIN")) : 256;
+  return enabled && a.Cin % 32 == 0 && a.Cin >= min_cin && a.Cin <= DX_ZERO_PAGE_EL && a.ldx % 8 == 0;
+}
+
 template <typename TA, typename TC, typename TO, typename TG, int LN = 0>
 int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
   const int ztiles = dx_cdiv(a.Cout, BN);
@@ -731,6 +849,16 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
   if constexpr (LN != 0) {   // LayerNorm epilogues: one channel tile (Cout = 128)
     constexpr int LNB = LN == 2 ? 3 : LN;             // backward without FiLM gradients: fewer registers
     const bool film = LN == 2 && a.ln.film != nullptr;
+    if constexpr (sizeof(TA) == 2 && sizeof(TC) == 2) {
+      if (ring_ok(a) && taps == 3) {
+        const long pt2 = (long)dx_cdiv(a.N, 128) * B;
+        dim3 grid2((unsigned)(((pt2 + 7) / 8) * 8));
+        if (film) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 2, 32, LN, DX_RING>), grid2, dim3(2 * NTHREADS), 0, s, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 2, 32, LNB, DX_RING>), grid2, dim3(2 * NTHREADS), 0, s, a);
+        DX_LAUNCH_CHECK();
+        return DX_OK;
+      }
+    }
     if (narrow_mi == 2 && taps == 3) {
       const long pt2 = (long)dx_cdiv(a.N, 128) * B;
       dim3 grid2((unsigned)(((pt2 + 7) / 8) * 8));
@@ -752,9 +880,30 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
     return DX_OK;
   } else {
     if (try_weight_stationary<TA, TC, TO, TG>(a, B, taps, s)) { DX_LAUNCH_CHECK(); return DX_OK; }
-    const int mi = ztiles == 1 ? (taps == 3 ? narrow_mi : 1) : 2;                       // 64-row tiles for the narrow-output GEMMs
+    if constexpr (sizeof(TA) == 2 && sizeof(TC) == 2) {
+      if (ring_ok(a) && taps == 3 && !(a.flags & DX_CONV_TRANSPOSED_OUT)) {
+        const long pt2 = (long)dx_cdiv(a.N, 128) * B;
+        dim3 grid2((unsigned)(((pt2 + 7) / 8) * 8 * ztiles));
+        hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 2, 32, 0, DX_RING>), grid2, dim3(2 * NTHREADS), 0, s, a);
+        DX_LAUNCH_CHECK();
+        return DX_OK;
+      }
+    }
+    // Wide k = 3 GEMMs with a long contraction (prenet 1024 -> 1024): 256-row tiles (MI = 4, a wave owns 128 x 64) when
+    // that still leaves >= 4 workgroups per CU.  The kernel is bound by what a CU can fetch from L2 (~30 B/clk, see
+    // ring_ok), and a taller tile re-uses the taps x 128-channel weight chunk for twice the positions: 930 vs 810 TFLOP/s.
+    static int forced_wide = getenv("DX_CONV_WIDE_MI") ? atoi(getenv("DX_CONV_WIDE_MI")) : 0;
+    const int wide_mi = forced_wide ? forced_wide : ((long)dx_cdiv(a.N, 256) * B * ztiles >= 1024 ? 4 : 2);
+    const int mi = ztiles == 1 ? (taps == 3 ? narrow_mi : 1) : ((taps == 3 && a.Cin >= 512 && sizeof(TC) == 2) ? wide_mi : 2);
     const long ptiles = (long)dx_cdiv(a.N, 64 * mi) * B;
     dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * ztiles)), block(NTHREADS);
+    if constexpr (sizeof(TC) == 2) {
+      if (mi == 4) {
+        hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 4, 32>), grid, block, 0, s, a);
+        DX_LAUNCH_CHECK();
+        return DX_OK;
+      }
+    }
     if (taps == 1 && mi == 1) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 1, 32>), grid, block, 0, s, a);
     else if (taps == 1) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 2, 32>), grid, block, 0, s, a);
     else if (mi == 1) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 1, 32>), grid, block, 0, s, a);
