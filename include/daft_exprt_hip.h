@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DX_ABI_VERSION 4
+#define DX_ABI_VERSION 5
 
 enum { DX_F32 = 0, DX_BF16 = 1, DX_I64 = 2 };
 enum { DX_OK = 0, DX_ERR_ARG = -1, DX_ERR_SHAPE = -2, DX_ERR_DTYPE = -3, DX_ERR_LAUNCH = -4, DX_ERR_UNSUPPORTED = -5 };
@@ -66,7 +66,7 @@ int dx_conv1d(const void* x, int x_dtype, long ldx, const void* w_packed, int w_
 int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const float* bias,
                  const float* residual, const float* gamma, const float* beta, const float* film, long ldf,
                  const int64_t* lengths, float* y, void* y_lp, float* s_out, float* mean, float* rstd, int B, int N,
-                 int Cin, int taps, float p_pre, uint64_t seed_pre, void* stream);
+                 int Cin, int taps, float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, void* stream);
 
 /* Data gradient of a conv / linear INTO a 128-channel residual stream, fused with the BACKWARD of the LayerNorm that
  * consumed that stream in the forward pass (autograd of model.py:189-191 resp. 226-235 + 259/262, i.e. what
@@ -81,7 +81,18 @@ int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void* w_packed, 
                     const float* s_in, const float* mean, const float* rstd, const float* gamma, const float* beta,
                     const float* film, long ldf, const int64_t* lengths, void* dx_pre_lp, float* dgamma, float* dbeta,
                     float* dfilm, long lddf, int B, int N, int Cin, int taps, float p_pre, uint64_t seed_pre,
-                    void* stream);
+                    const int* plan, int plan_tiles, void* stream);
+
+/* Balanced position tiles for dx_conv1d_ln / dx_conv1d_lnbwd (optional `plan`; bf16 operands, taps = 3, Cin % 32 == 0).
+ * The k = 3 GEMMs into the 128-channel stream are bound by what a compute unit fetches from L2, and every workgroup
+ * fetches the whole weight slice whatever the height of its tile; a ragged batch (model.py:21-23 masks, lengths differ
+ * 10x inside a batch) cut into fixed 128-row tiles ends a few tiles above a multiple of the 256 CUs.  The plan cuts
+ * each utterance into equal pieces of <= 256 rows so that the batch is exactly n_tiles = dx_conv_tile_plan_size(B, N)
+ * pieces (a multiple of 256) with the smallest possible maximum height.  table: n_tiles x 4 int32 {b, n0, rows, 0},
+ * device memory, valid for every GEMM over the same lengths (one plan per batch).  Results are identical to the
+ * unplanned call: same rows, same summation order per output; rows >= lengths[b] are written as zeros. */
+int dx_conv_tile_plan_size(int B, int N);
+int dx_conv_tile_plan(const int64_t* lengths, int B, int N, int n_tiles, int* table, void* stream);
 
 /* Pack an fp32 (Cout, Cin, taps) PyTorch conv / (Cout, Cin) linear weight for dx_conv1d.
  *   transpose_flip = 0: out[tap][co][ci] = w[co][ci][tap]                (forward operand)

@@ -180,3 +180,78 @@ def test_conv_lnbwd_fusion_matches_two_launches(taps, cin, film, p):
         assert float((dx1.float() - dx0.float()).abs().max()) <= max(tol, 1e-2) * sc   # bf16 output rounding
         for a, b_ in ((dg1, dg0), (db1, db0)) + (((df1, df0),) if film else ()):
             assert float((a - b_).abs().max()) <= max(tol, 1e-4) * float(b_.abs().max()) + 1e-4
+
+
+def _plan_rows(table):
+    ''' {b: sorted [(n0, rows)]} of a tile plan '''
+    out = {}
+    for b, n0, rows, _ in table.cpu().tolist():
+        if rows > 0:
+            out.setdefault(b, []).append((n0, rows))
+    return {b: sorted(v) for b, v in out.items()}
+
+
+@pytest.mark.parametrize('lens_list,N', [([1000, 517, 300, 129, 64, 1, 999, 730], 1000), ([257, 256, 255, 3], 257), ([40, 33], 40)])
+def test_conv_tile_plan_covers_every_row_once(lens_list, N):
+    ''' dx_conv_tile_plan: a multiple of 256 tiles, every valid row of every utterance in exactly one tile, tiles <= 256 rows and
+        equal (+-1 row per piece) inside an utterance '''
+    from daft_exprt import ops
+    lens = torch.tensor(lens_list, device=DEV)
+    table, B, n = ops.conv_tile_plan(lens, N)
+    torch.cuda.synchronize()
+    assert table.shape[0] % 256 == 0 and table.shape[0] >= len(lens_list) * ((N + 255) // 256)
+    rows = _plan_rows(table)
+    for b, ln in enumerate(lens_list):
+        pos = 0
+        for n0, r in rows[b]:
+            assert n0 == pos and 0 < r <= 256
+            pos += r
+        assert pos == ln
+        hs = [r for _, r in rows[b]]
+        assert max(hs) - min(hs) <= len(hs)       # equal pieces (the last one takes the remainder)
+    tall = max(r for v in rows.values() for _, r in v)
+    # no shorter maximum height fits the tile budget
+    assert tall == 1 or sum(-(-ln // (tall - 1)) for ln in lens_list) > table.shape[0]
+
+
+@pytest.mark.parametrize('film', [False, True])
+def test_planned_conv_ln_and_lnbwd_match_unplanned(film):
+    ''' the balanced-tile launches (256-row tiles from dx_conv_tile_plan, LDS-DMA ring, padding-fill workgroups) give the
+        results of the fixed-tile launches: outputs bit-identical on valid rows (same summation order), zeros on padding
+        rows, per-channel reductions equal up to the order of the atomics '''
+    from daft_exprt import ops
+    g = torch.Generator().manual_seed(11)
+    B, N, cin = 6, 700, 1024
+    lens = torch.tensor([700, 433, 257, 256, 130, 5]).to(DEV)
+    n_idx = torch.arange(N, device=DEV)[None, :, None]
+    valid = n_idx < lens[:, None, None]
+    x = (torch.randn(B, N, cin, generator=g).to(DEV) * (n_idx < lens[:, None, None] + 2)).to(torch.bfloat16)
+    w = (torch.randn(128, cin, 3, generator=g) / (cin * 3) ** 0.5).to(DEV)
+    wp = ops.pack_conv_weight(w, torch.bfloat16)
+    bias, gamma, beta = (torch.randn(128, generator=g).to(DEV) for _ in range(3))
+    res = torch.randn(B, N, 128, generator=g).to(DEV) * valid
+    fl = torch.randn(B, 256, generator=g).to(DEV) if film else None
+    plan = ops.conv_tile_plan(lens, N)
+    outs = []
+    for pl in (None, plan):
+        outs.append(ops.conv1d_ln(x, wp, bias, res, gamma, beta, lens, film=fl, save=True, p_pre=0.1, seed_pre=9, lp_copy=True, plan=pl))
+    for a, b_, name in zip(outs[0], outs[1], ('y', 'y_lp', 's', 'mean', 'rstd')):
+        m = valid if a.dim() == 3 else valid.reshape(-1)
+        a, b_ = a.float(), b_.float()
+        assert torch.equal(a * m, b_ * m), (name, float(((a - b_) * m).abs().max()))
+        assert float((b_ * ~m).abs().max()) == 0., name           # padding rows of the planned launch are zeros
+    # backward
+    y_ln, _, s_in, mean, rstd = outs[0]
+    wpt = ops.pack_conv_weight((torch.randn(cin, 128, 3, generator=g) / (cin * 3) ** 0.5).to(DEV), torch.bfloat16, transpose_flip=True)
+    gin = torch.randn(B, N, 128, generator=g).to(DEV) * (n_idx < lens[:, None, None] + 2)
+    r = []
+    for pl in (None, plan):
+        y = gin.clone()
+        dg, db = torch.zeros(128, device=DEV), torch.zeros(128, device=DEV)
+        df = torch.zeros(B, 256, device=DEV) if film else None
+        dx = ops.conv1d_lnbwd(x, wpt, y, s_in, mean, rstd, gamma, beta, lens, dg, db, film=fl, dfilm=df, p_pre=0.1, seed_pre=4, plan=pl)
+        r.append((y, dx.float(), dg, db, df))
+    assert torch.equal(r[0][0] * valid, r[1][0] * valid) and torch.equal(r[0][1] * valid, r[1][1] * valid)
+    assert float((r[1][0] * ~valid).abs().max()) == 0. and float((r[1][1] * ~valid).abs().max()) == 0.
+    for k in (2, 3) + ((4,) if film else ()):
+        assert float((r[0][k] - r[1][k]).abs().max()) <= 1e-4 * float(r[0][k].abs().max()) + 1e-5, k

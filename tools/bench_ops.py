@@ -93,8 +93,8 @@ if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'ln':
 
 def bench_convln():
     dev = torch.device('cuda:0')
-    B, N = 48, 1000
-    lens = torch.randint(250, 1001, (B,), device=dev)
+    B, N = int(os.environ.get('BENCH_B', '48')), int(os.environ.get('BENCH_N', '1000'))
+    lens = torch.randint(250, 1001, (B,), device=dev) if N == 1000 else torch.full((B,), N, device=dev)
     lens[0] = N
     for cin, taps in [(1024, 3), (128, 1)]:
         x = torch.randn(B, N, cin, device=dev).to(torch.bfloat16)
@@ -103,7 +103,8 @@ def bench_convln():
         bias, g, bt = torch.zeros(128, device=dev), torch.ones(128, device=dev), torch.zeros(128, device=dev)
         res = torch.randn(B, N, 128, device=dev)
         film = torch.randn(B, 256, device=dev)
-        t_fused = timeit(lambda: ops.conv1d_ln(x, wp, bias, res, g, bt, lens, film=film, save=True, p_pre=0.1, seed_pre=5, lp_copy=True))
+        plan = ops.conv_tile_plan(lens, N) if os.environ.get('BENCH_PLAN') and taps == 3 else None
+        t_fused = timeit(lambda: ops.conv1d_ln(x, wp, bias, res, g, bt, lens, film=film, save=True, p_pre=0.1, seed_pre=5, lp_copy=True, plan=plan))
         t_conv = timeit(lambda: ops.conv1d(x, wp, bias, out_dtype=torch.float32, skip_lengths=lens))
         z = ops.conv1d(x, wp, bias, out_dtype=torch.float32, skip_lengths=lens)
         t_ln = timeit(lambda: ops.layernorm_fwd(z, g, bt, residual=res, film=film, lengths=lens, save=True, save_s=True, p_pre=0.1, seed_pre=5,
@@ -159,3 +160,28 @@ def bench_mel():
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'mel':
     bench_mel()
+
+
+def bench_lnbwd():
+    dev = torch.device('cuda:0')
+    B, N = int(os.environ.get('BENCH_B', '48')), int(os.environ.get('BENCH_N', '1000'))
+    lens = torch.randint(250, 1001, (B,), device=dev) if N == 1000 else torch.full((B,), N, device=dev)
+    lens[0] = N
+    cin, taps = 1024, 3
+    x = torch.randn(B, N, cin, device=dev).to(torch.bfloat16)
+    w = torch.randn(128, cin, taps, device=dev) / (cin * taps) ** 0.5
+    wp = ops.pack_conv_weight(w, torch.bfloat16)
+    g, bt = torch.ones(128, device=dev), torch.zeros(128, device=dev)
+    y = torch.randn(B, N, 128, device=dev)
+    s_in = torch.randn(B, N, 128, device=dev)
+    mean, rstd = torch.zeros(B, N, device=dev), torch.ones(B, N, device=dev)
+    dg, db = torch.zeros(128, device=dev), torch.zeros(128, device=dev)
+    film, dfilm = torch.randn(B, 256, device=dev), torch.zeros(B, 256, device=dev)
+    plan = ops.conv_tile_plan(lens, N) if os.environ.get('BENCH_PLAN') else None
+    t0 = timeit(lambda: ops.conv1d_lnbwd(x, wp, y, s_in, mean, rstd, g, bt, lens, dg, db, p_pre=0.1, seed_pre=3, plan=plan))
+    t1 = timeit(lambda: ops.conv1d_lnbwd(x, wp, y, s_in, mean, rstd, g, bt, lens, dg, db, film=film, dfilm=dfilm, p_pre=0.1, seed_pre=3, plan=plan))
+    print(f'lnbwd-fused data gradient 1024->128 k3, {int(lens.sum())} valid rows: {t0 * 1e3:6.1f} us | with FiLM gradients {t1 * 1e3:6.1f} us')
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'lnbwd':
+    bench_lnbwd()

@@ -49,6 +49,7 @@ struct ConvArgs {
   const int64_t* skip_len;
   int N, Cin, Cout, flags, B;
   LNEpi ln;
+  const int* plan; int plan_tiles;     // balanced position tiles {b, n0, rows, 0} (dx_conv_tile_plan), ring kernels only
 };
 
 template <typename T, int V> struct VecN;
@@ -141,8 +142,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
   constexpr int W_PT = TAPS * BN * (BK / 8) / NTHREADS;
   constexpr int STG_LD = BN + 4;
   // ring image of one K chunk: activation rows rounded up to whole 16-row DMA pieces, then the taps x 128 weight rows
-  // (and padded to a multiple of 4 pieces: every wave issues the same number of DMA instructions per chunk)
-  constexpr int AR16 = (AROWS + 15) & ~15, STAGE_EL = ((AR16 + TAPS * BN) / 16 + 3) / 4 * 4 * 512;
+  constexpr int AR16 = (AROWS + 15) & ~15, STAGE_EL = (AR16 + TAPS * BN) * 32;
   constexpr int OPER_BYTES = RING ? RING * STAGE_EL * 2 : (AROWS + TAPS * BN) * LDS_K * (int)sizeof(TC), STG_BYTES = 64 * STG_LD * 4;
   typedef typename Vec8<TC>::type frag_t;
   typedef typename VecN<TA, 8>::type raw_t;
@@ -160,12 +160,35 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
   // for channel tile 1, ...  (Measured: no difference vs the channel-tile-fastest order on MI355X -- the kernel is bound
   // by its LDS->MFMA issue pattern at ~800 TFLOP/s, the known ceiling of a 128x128-tile two-barrier structure -- but this
   // order keeps the weight working set of an XCD at one slice, which matters once the inner loop gets faster.)
-  const int ztiles = dx_cdiv(p.Cout, BN), ptiles = dx_cdiv(p.N, BM);
-  const int Lid = blockIdx.x, jj = Lid >> 3;
-  const int per_xcd = (ptiles * p.B + 7) >> 3;         // position tiles owned by one XCD
-  const int pt = (Lid & 7) + 8 * (jj % per_xcd);
-  if (pt >= ptiles * p.B) return;
-  const int n0 = (pt % ptiles) * BM, b = pt / ptiles, co0 = (jj / per_xcd) * BN;
+  // PLAN (ring kernels with 256-row tiles, one channel tile): the position tiles come from a table that cuts every
+  // utterance into equal pieces of <= 256 rows such that the whole batch is a multiple of 256 workgroups of (nearly) the
+  // same height -- a workgroup costs one pass over the weights whatever its height.  Workgroups past the table zero-fill
+  // the padding rows [length, N) of one utterance, 256 rows each.
+  constexpr bool PLAN = RING > 0 && MI == 4;
+  int n0, b, co0, h = BM;              // h = rows of this tile
+  bool fill_only = false;
+  if constexpr (PLAN) {
+    co0 = 0;
+    if ((int)blockIdx.x < p.plan_tiles) {
+      const int4 e = reinterpret_cast<const int4*>(p.plan)[blockIdx.x];
+      b = e.x; n0 = e.y; h = e.z;
+      if (h <= 0) return;
+    } else {
+      const int j = blockIdx.x - p.plan_tiles, per_b = dx_cdiv(p.N, BM);
+      b = j / per_b;
+      n0 = (int)p.skip_len[b] + (j - b * per_b) * BM;
+      if (n0 >= p.N) return;
+      fill_only = true;
+    }
+  } else {
+    const int ztiles = dx_cdiv(p.Cout, BN), ptiles = dx_cdiv(p.N, BM);
+    const int Lid = blockIdx.x, jj = Lid >> 3;
+    const int per_xcd = (ptiles * p.B + 7) >> 3;         // position tiles owned by one XCD
+    const int pt = (Lid & 7) + 8 * (jj % per_xcd);
+    if (pt >= ptiles * p.B) return;
+    n0 = (pt % ptiles) * BM; b = pt / ptiles; co0 = (jj / per_xcd) * BN;
+    (void)ztiles;
+  }
   const int N = p.N, Cin = p.Cin, Cout = p.Cout;
   const TA* X = reinterpret_cast<const TA*>(p.x) + (size_t)b * N * p.ldx;
   const TC* W = reinterpret_cast<const TC*>(p.w);
@@ -176,7 +199,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
   const bool vec_out = !trans && (Cout % 8 == 0) && (p.ldy % 8 == 0);
 
   // padding early-out: a tile that starts past length + conv halo cannot reach a valid output -> zeros, no MFMA
-  if (p.skip_len && n0 >= (int)p.skip_len[b] + 2) {
+  if (PLAN ? fill_only : (p.skip_len && n0 >= (int)p.skip_len[b] + 2)) {
     if (RING && tid >= NTHREADS) return;             // loader waves
     if (LN == 2) {   // incoming residual gradient rows are zero there and stay; the bf16 dx_pre rows must exist as zeros
       float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -239,39 +262,56 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
     // RING - 2 younger chunks stay in flight), an MFMA wave after it has finished reading chunk k - 1.  Past the
     // barrier the MFMA waves read chunk k and the loaders refill the buffer chunk k - 1 just left with chunk k + RING - 1.
     static_assert(sizeof(TA) == 2 && sizeof(TC) == 2 && BK == 32, "ring pipeline: bf16 operands, 32-channel chunks");
-    constexpr int A_INS = AR16 / 16, W_INS = TAPS * BN / 16, T_INS = A_INS + W_INS;
-    constexpr int CNT = (T_INS + 3) / 4, NSTEP = TAPS * 2;     // pieces per loader per chunk; pieces >= T_INS are padding
+    // pieces of a chunk: the first nA cover the h + TAPS - 1 activation rows of this tile, then TAPS * 8 weight pieces
+    constexpr int W_INS = TAPS * BN / 16, MAXP = (AR16 / 16 + W_INS + 3) / 4, NSTEP = TAPS * 2;
+    const int nA = (h + TAPS - 1 + 15) >> 4, nP = nA + W_INS;
     TC* ring = reinterpret_cast<TC*>(smem);
     const int nk = Cin >> 5;
     if (wave >= 4) {
       const int lw = __builtin_amdgcn_readfirstlane(wave) - 4;
-      const TC* src[CNT];
+      const int mine = (nP - lw + 3) >> 2;                       // pieces lw, lw + 4, ... of every chunk are this loader's
+      const TC* src[MAXP];
+      int dst[MAXP];
 #pragma unroll
-      for (int t = 0; t < CNT; ++t) {
-        const int q = lw + 4 * t, r = q * 16 + (lane >> 2);     // row of the chunk image this lane fills
+      for (int t = 0; t < MAXP; ++t) {
+        const int q = lw + 4 * t;
+        const bool isw = q >= nA;
+        const int r = (isw ? q - nA : q) * 16 + (lane >> 2);     // row of the activation / weight image this lane fills
         const int c = (lane & 3) ^ ((r >> 2) & 3);                // source chunk that belongs at position lane & 3
         const TC* sp = reinterpret_cast<const TC*>(dx_zero_page) + c * 8;
-        const int n = n0 + r - HALO, wr = r - AR16, co = co0 + (wr & (BN - 1));
+        const int n = n0 + r - HALO, co = co0 + (r & (BN - 1));
         const TC* xa = reinterpret_cast<const TC*>(X) + (long)n * p.ldx + c * 8;
-        const TC* wa = W + ((size_t)(wr / BN) * Cout + co) * Cin + c * 8;
-        sp = (r < AROWS && n >= 0 && n < N) ? xa : sp;
-        sp = (q >= A_INS && q < T_INS && co < Cout) ? wa : sp;
+        const TC* wa = W + ((size_t)(r / BN) * Cout + co) * Cin + c * 8;
+        sp = (!isw && r < h + TAPS - 1 && n >= 0 && n < N) ? xa : sp;
+        sp = (isw && q < nP && co < Cout) ? wa : sp;
         src[t] = sp;
+        dst[t] = __builtin_amdgcn_readfirstlane((isw ? AR16 / 16 + q - nA : q) * 512);
       }
       auto issue_chunk = [&](int kc, int buf) {
         if (DX_RING_ABL & 2) return;
 #pragma unroll
-        for (int t = 0; t < CNT; ++t)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + kc * 32),
-                                           (__attribute__((address_space(3))) void*)(ring + buf * STAGE_EL + (lw + 4 * t) * 512), 16, 0, 0);
+        for (int t = 0; t < MAXP; ++t)
+          if (t < mine)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + kc * 32),
+                                             (__attribute__((address_space(3))) void*)(ring + buf * STAGE_EL + dst[t]), 16, 0, 0);
       };
+      auto wait_landed = [&](int keep) {                         // s_waitcnt vmcnt(keep), keep wave-uniform
+        switch (keep) {
+#define DX_VMW(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+          DX_VMW(1) DX_VMW(2) DX_VMW(3) DX_VMW(4) DX_VMW(5) DX_VMW(6) DX_VMW(7) DX_VMW(8) DX_VMW(9) DX_VMW(10) DX_VMW(11) DX_VMW(12)
+          DX_VMW(13) DX_VMW(14) DX_VMW(15) DX_VMW(16) DX_VMW(17) DX_VMW(18) DX_VMW(19) DX_VMW(20) DX_VMW(21) DX_VMW(22) DX_VMW(23) DX_VMW(24)
+          DX_VMW(25) DX_VMW(26) DX_VMW(27) DX_VMW(28) DX_VMW(29) DX_VMW(30) DX_VMW(31) DX_VMW(32) DX_VMW(33) DX_VMW(34) DX_VMW(35) DX_VMW(36)
+#undef DX_VMW
+          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      };
+      static_assert(MAXP * (RING - 2) <= 36, "vmcnt switch too short");
 #pragma unroll
       for (int st = 0; st < RING - 1; ++st)
         if (st < nk) issue_chunk(st, st);
       int nbuf = RING - 1, k = 0;                                // buffer that chunk k + RING - 1 goes to
       for (; k + RING - 1 < nk; ++k) {
-        if (RING > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT * (RING - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_landed(mine * (RING - 2));
         __builtin_amdgcn_s_barrier();
         issue_chunk(k + RING - 1, nbuf);
         nbuf = nbuf + 1 == RING ? 0 : nbuf + 1;
@@ -282,34 +322,49 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
       }
       return;                                                     // the epilogue belongs to the MFMA waves
     }
-    auto load_frags = [&](const TC* Ar, const TC* Wr, int step, frag_t* a, frag_t* bf) {
-      const int tap = step >> 1, ks = step & 1;
+    // MFMA waves.  PLAN: wave (wm, wn) owns the 32-row blocks wm, wm + 2, ... (interleaved, so a short tile still
+    // spreads over both wave rows) and skips the blocks past the tile's height.
+    auto row_of = [&](int i) { return PLAN ? (2 * i + wm) * 32 : wm * 32 * MI + i * 32; };
+    const int nact = PLAN ? __builtin_amdgcn_readfirstlane((((h + 31) >> 5) - wm + 1) >> 1) : MI;
+    auto mainloop = [&](auto na_tag) {
+      constexpr int NA = decltype(na_tag)::value;
+      int buf = 0;
+      for (int k = 0; k < nk; ++k) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (NA > 0) {
+          const TC* Ar = ring + buf * STAGE_EL;
+          const TC* Wr = Ar + AR16 * 32;
+          frag_t a[2][NA], bf[2][2];
+          auto load_frags = [&](int step, frag_t* af, frag_t* bfr) {
+            const int tap = step >> 1, ks = step & 1;
 #pragma unroll
-      for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const frag_t*>(&Ar[lds_at(wm * 32 * MI + i * 32 + l31 + tap, ks * 2 + g)]);
+            for (int i = 0; i < NA; ++i) af[i] = *reinterpret_cast<const frag_t*>(&Ar[lds_at(row_of(i) + l31 + tap, ks * 2 + g)]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const frag_t*>(&Wr[lds_at(tap * BN + wn * 64 + j * 32 + l31, ks * 2 + g)]);
-    };
-    int buf = 0;
-    for (int k = 0; k < nk; ++k) {
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const TC* Ar = ring + buf * STAGE_EL;
-      const TC* Wr = Ar + AR16 * 32;
-      frag_t a[2][MI], bf[2][2];
-      if (DX_RING_ABL & 1) { buf = buf + 1 == RING ? 0 : buf + 1; continue; }
-      load_frags(Ar, Wr, 0, a[0], bf[0]);
+            for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const frag_t*>(&Wr[lds_at(tap * BN + wn * 64 + j * 32 + l31, ks * 2 + g)]);
+          };
+          if (!(DX_RING_ABL & 1)) {
+            load_frags(0, a[0], bf[0]);
 #pragma unroll
-      for (int step = 0; step < NSTEP; ++step) {     // fragments of k-step s + 1 are read before the MFMAs of k-step s
-        if (step + 1 < NSTEP) load_frags(Ar, Wr, step + 1, a[(step + 1) & 1], bf[(step + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int step = 0; step < NSTEP; ++step) {   // fragments of k-step s + 1 are read before the MFMAs of k-step s
+              if (step + 1 < NSTEP) load_frags(step + 1, a[(step + 1) & 1], bf[(step + 1) & 1]);
+              __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+              for (int i = 0; i < NA; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) dx_mma(acc[i][j], a[step & 1][i], bf[step & 1][j]);
+                for (int j = 0; j < 2; ++j) dx_mma(acc[i][j], a[step & 1][i], bf[step & 1][j]);
+            }
+          }
+        }
+        buf = buf + 1 == RING ? 0 : buf + 1;
       }
-      buf = buf + 1 == RING ? 0 : buf + 1;
-    }
+    };
+    if (nact >= MI) mainloop(std::integral_constant<int, MI>{});
+    else if (MI > 3 && nact == 3) mainloop(std::integral_constant<int, (MI > 3 ? 3 : MI)>{});
+    else if (MI > 2 && nact == 2) mainloop(std::integral_constant<int, (MI > 2 ? 2 : MI)>{});
+    else if (MI > 1 && nact == 1) mainloop(std::integral_constant<int, 1>{});
+    else mainloop(std::integral_constant<int, 0>{});
     __syncthreads();                                 // every MFMA wave is done with the ring: the epilogue stages through it
   } else {
   raw_t ra[A_PT];
@@ -389,6 +444,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
   if (vec_out) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+      if (PLAN && i * 64 >= h) break;                             // workgroup-uniform: the barriers below stay matched
       // phase 1: bias + ReLU in the MFMA layout, accumulators -> LDS stage (64 rows x 128 channels, fp32)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -406,8 +462,9 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
         const int sr = (tid >> 4) + pass * 16;                     // stage row 0..63
-        const int n = n0 + (sr >> 5) * 32 * MI + i * 32 + (sr & 31), cl = (tid & 15) * 8, co = co0 + cl;
-        if (n < N && co < Cout) {
+        const int trow = PLAN ? i * 64 + sr : (sr >> 5) * 32 * MI + i * 32 + (sr & 31);   // row inside the tile
+        const int n = n0 + trow, cl = (tid & 15) * 8, co = co0 + cl;
+        if (n < N && co < Cout && trow < h) {
           float v[8];
           const f32x4 lo = *reinterpret_cast<const f32x4*>(&stage[sr * STG_LD + cl]);
           const f32x4 hi = *reinterpret_cast<const f32x4*>(&stage[sr * STG_LD + cl + 4]);
@@ -850,6 +907,13 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
     constexpr int LNB = LN == 2 ? 3 : LN;             // backward without FiLM gradients: fewer registers
     const bool film = LN == 2 && a.ln.film != nullptr;
     if constexpr (sizeof(TA) == 2 && sizeof(TC) == 2) {
+      if (a.plan && taps == 3) {   // balanced 256-row tiles + padding-fill workgroups (dx_conv_tile_plan)
+        dim3 gridp((unsigned)(a.plan_tiles + B * dx_cdiv(a.N, 256)));
+        if (film) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 4, 32, LN, 3>), gridp, dim3(2 * NTHREADS), 0, s, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 4, 32, LNB, 3>), gridp, dim3(2 * NTHREADS), 0, s, a);
+        DX_LAUNCH_CHECK();
+        return DX_OK;
+      }
       if (ring_ok(a) && taps == 3) {
         const long pt2 = (long)dx_cdiv(a.N, 128) * B;
         dim3 grid2((unsigned)(((pt2 + 7) / 8) * 8));
@@ -1311,11 +1375,82 @@ extern "C" int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const vo
   return DX_ERR_DTYPE;
 }
 
+// ---- balanced position tiles (dx_conv_tile_plan) ----------------------------------------------------------------
+// The k = 3, 1024 -> 128 GEMMs are bound by what a CU can fetch from L2, and a workgroup fetches the whole 786 KB weight
+// slice whatever the height of its tile: the cost of a launch is (weight passes per CU) x 12 us.  Fixed 128-row tiles
+// give a ragged batch a few tiles more than 256 (a second pass on a handful of CUs doubles the kernel); the plan cuts
+// every utterance into equal pieces of at most DX_PLAN_ROWS rows such that the batch is exactly n_tiles (a multiple of
+// the 256 CUs) pieces and the tallest piece is as short as possible.
+constexpr int DX_PLAN_ROWS = 256, DX_NUM_CU = 256;
+__global__ __launch_bounds__(64) void conv_plan_kernel(const int64_t* __restrict__ lens, int B, int N, int T, int4* __restrict__ table) {
+  __shared__ int first[4096 + 1];
+  const int lane = threadIdx.x;
+  auto len_of = [&](int b) { const int l = (int)lens[b]; return l < 0 ? 0 : (l > N ? N : l); };
+  auto tiles_at = [&](int H) {
+    int c = 0;
+    for (int b = lane; b < B; b += 64) c += (len_of(b) + H - 1) / H;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    return c;
+  };
+  int lo = 1, hi = DX_PLAN_ROWS;                       // smallest height whose tile count fits (T >= B * ceil(N / 256) by contract)
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (tiles_at(mid) <= T) hi = mid; else lo = mid + 1;
+  }
+  const int H = lo;
+  if (lane == 0) {
+    int acc = 0;
+    for (int b = 0; b < B; ++b) { first[b] = acc; acc += (len_of(b) + H - 1) / H; }
+    first[B] = acc;
+  }
+  __syncthreads();
+  for (int b = lane; b < B; b += 64) {
+    const int l = len_of(b), t = first[b + 1] - first[b];
+    if (t == 0) continue;
+    const int hb = (l + t - 1) / t;                    // equal pieces inside the utterance
+    for (int j = 0; j < t; ++j) {
+      const int n0 = j * hb, rows = l - n0 < hb ? l - n0 : hb;
+      if (first[b] + j < T) table[first[b] + j] = make_int4(b, n0, rows > 0 ? rows : 0, 0);
+    }
+  }
+  for (int i = first[B] + lane; i < T; i += 64) table[i] = make_int4(0, 0, 0, 0);
+}
+
+extern "C" int dx_conv_tile_plan_size(int B, int N) {
+  if (B <= 0 || N <= 0) return 0;
+  const long worst = (long)B * dx_cdiv(N, DX_PLAN_ROWS);
+  return (int)((worst + DX_NUM_CU - 1) / DX_NUM_CU * DX_NUM_CU);
+}
+
+extern "C" int dx_conv_tile_plan(const int64_t* lengths, int B, int N, int n_tiles, int* table, void* stream) {
+  DX_REQUIRE(lengths && table, DX_ERR_ARG, "dx_conv_tile_plan: null pointer");
+  DX_REQUIRE(B > 0 && B <= 4096 && N > 0, DX_ERR_SHAPE, "dx_conv_tile_plan: B=%d (1..4096), N=%d", B, N);
+  DX_REQUIRE(n_tiles >= dx_conv_tile_plan_size(B, N), DX_ERR_ARG, "dx_conv_tile_plan: n_tiles=%d < dx_conv_tile_plan_size=%d", n_tiles,
+             dx_conv_tile_plan_size(B, N));
+  hipLaunchKernelGGL(conv_plan_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lengths, B, N, n_tiles, reinterpret_cast<int4*>(table));
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+// plan validity for the LayerNorm-fused GEMMs: bf16 operands, k = 3, whole 32-channel chunks
+static int plan_check(const char* who, const int* plan, int plan_tiles, const int64_t* lengths, int x_dtype, int w_dtype, long ldx, int Cin,
+                      int taps, int B, int N) {
+  if (!plan) return DX_OK;
+  DX_REQUIRE(lengths, DX_ERR_ARG, "%s: a tile plan needs lengths", who);
+  DX_REQUIRE(x_dtype == DX_BF16 && w_dtype == DX_BF16 && taps == 3 && Cin % 32 == 0 && Cin <= DX_ZERO_PAGE_EL && ldx % 8 == 0, DX_ERR_UNSUPPORTED,
+             "%s: tile plans are for bf16 operands, taps = 3, Cin %% 32 == 0 (got x=%d w=%d taps=%d Cin=%d)", who, x_dtype, w_dtype, taps, Cin);
+  DX_REQUIRE(plan_tiles >= dx_conv_tile_plan_size(B, N), DX_ERR_ARG, "%s: plan_tiles=%d < dx_conv_tile_plan_size(B, N)=%d", who, plan_tiles,
+             dx_conv_tile_plan_size(B, N));
+  return DX_OK;
+}
+
 extern "C" int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const float* bias,
                             const float* residual, const float* gamma, const float* beta, const float* film, long ldf,
                             const int64_t* lengths, float* y, void* y_lp, float* s_out, float* mean, float* rstd, int B, int N,
-                            int Cin, int taps, float p_pre, uint64_t seed_pre, void* stream) {
+                            int Cin, int taps, float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, void* stream) {
   DX_REQUIRE(x && w_packed && residual && gamma && beta && y, DX_ERR_ARG, "dx_conv1d_ln: null pointer");
+  if (int rc = plan_check("dx_conv1d_ln", plan, plan_tiles, lengths, x_dtype, w_dtype, ldx, Cin, taps, B, N)) return rc;
   DX_REQUIRE(B > 0 && N > 0 && Cin > 0, DX_ERR_SHAPE, "dx_conv1d_ln: empty shape");
   DX_REQUIRE(Cin % 8 == 0 && ldx % 8 == 0, DX_ERR_SHAPE, "dx_conv1d_ln: Cin (%d) and ldx (%ld) must be multiples of 8", Cin, ldx);
   DX_REQUIRE(taps == 1 || taps == 3, DX_ERR_UNSUPPORTED, "dx_conv1d_ln: taps=%d (only 1 and 3)", taps);
@@ -1323,6 +1458,7 @@ extern "C" int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_
   DX_REQUIRE(p_pre >= 0.f && p_pre < 1.f, DX_ERR_ARG, "dx_conv1d_ln: dropout p out of [0,1)");
   ConvArgs a{x, ldx, w_packed, bias, nullptr, BN, nullptr, lengths, lengths, N, Cin, BN, 0, B,
              LNEpi{gamma, beta, residual, film, ldf, y, y_lp, s_out, mean, rstd, p_pre, seed_pre, 1}};
+  a.plan = plan; a.plan_tiles = plan_tiles;
   hipStream_t s = (hipStream_t)stream;
   if (w_dtype == DX_BF16 && x_dtype == DX_BF16) return launch_taps<bf16_t, bf16_t, float, float, 1>(a, B, taps, s);
   if (w_dtype == DX_BF16 && x_dtype == DX_F32) return launch_taps<float, bf16_t, float, float, 1>(a, B, taps, s);
@@ -1335,7 +1471,8 @@ extern "C" int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void*
                                const float* s_in, const float* mean, const float* rstd, const float* gamma,
                                const float* beta, const float* film, long ldf, const int64_t* lengths, void* dx_pre_lp,
                                float* dgamma, float* dbeta, float* dfilm, long lddf, int B, int N, int Cin, int taps,
-                               float p_pre, uint64_t seed_pre, void* stream) {
+                               float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, void* stream) {
+  if (int rc = plan_check("dx_conv1d_lnbwd", plan, plan_tiles, lengths, x_dtype, w_dtype, ldx, Cin, taps, B, N)) return rc;
   DX_REQUIRE(x && w_packed && y_inout && s_in && mean && rstd && gamma && beta && lengths && dx_pre_lp && dgamma && dbeta,
              DX_ERR_ARG, "dx_conv1d_lnbwd: null pointer");
   DX_REQUIRE((film == nullptr) == (dfilm == nullptr), DX_ERR_ARG, "dx_conv1d_lnbwd: film and dfilm come together");
@@ -1346,6 +1483,7 @@ extern "C" int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void*
   ConvArgs a{x, ldx, w_packed, nullptr, y_inout, BN, nullptr, lengths, lengths, N, Cin, BN, 0, B,
              LNEpi{gamma, beta, nullptr, film, ldf, y_inout, dx_pre_lp, const_cast<float*>(s_in), const_cast<float*>(mean),
                    const_cast<float*>(rstd), p_pre, seed_pre, 2, dgamma, dbeta, dfilm, lddf}};
+  a.plan = plan; a.plan_tiles = plan_tiles;
   hipStream_t s = (hipStream_t)stream;
   if (w_dtype == DX_BF16 && x_dtype == DX_BF16) return launch_taps<bf16_t, bf16_t, float, float, 2>(a, B, taps, s);
   if (w_dtype == DX_BF16 && x_dtype == DX_F32) return launch_taps<float, bf16_t, float, float, 2>(a, B, taps, s);

@@ -177,6 +177,8 @@ class DaftExprt(nn.Module):
         self._wgrad_ws = None
         self._hop = None
         self.fuse_ln_backward = bool(int(__import__('os').environ.get('DX_FUSE_LN_BWD', '1')))   # see _fft_block_bwd
+        self.balanced_tiles = bool(int(__import__('os').environ.get('DX_BALANCED_TILES', '1')))   # see _plan
+        self._plans = {}
         self._step_id, self._site = 0, 0
         self._pos = None
         self.n_params = sum(int(np.prod(s)) for _, s, _ in self._table)
@@ -272,6 +274,18 @@ class DaftExprt(nn.Module):
             self._dgrad_version = self._packed_version
         return self._packed
 
+    def _plan(self, lengths, N):
+        ''' balanced position tiles of this step's batch for the LayerNorm-fused k = 3 GEMMs (`ops.conv_tile_plan`): one
+            small launch per distinct lengths tensor per step, shared by the 8 forward and 8 backward launches that read it.
+            Frame-level stacks only: a phoneme-level batch is too small for the tile count to matter. '''
+        if not self.balanced_tiles or self.cd != torch.bfloat16 or lengths is None or lengths.shape[0] * N < 16384:
+            return None
+        key = (lengths.data_ptr(), N)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = ops.conv_tile_plan(lengths, N)
+        return plan
+
     def _seed(self):
         self._site += 1
         return (int(self.hp.seed) * 0x9E3779B1 + self._step_id * 0x85EBCA77 + self._site * 0xC2B2AE3D) & _MASK63
@@ -335,7 +349,7 @@ class DaftExprt(nn.Module):
         # second FF conv + Dropout + residual + LayerNorm + FiLM + mask in ONE launch
         u, u_lp, s2, mean2, rstd2 = ops.conv1d_ln(h, W[f'{f_pre}.convs.2.conv.weight'], P[f'{f_pre}.convs.2.conv.bias'], a,
                                                   P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'], lengths, film=film,
-                                                  save=save, p_pre=p_conv, seed_pre=seeds[2], lp_copy=lp)
+                                                  save=save, p_pre=p_conv, seed_pre=seeds[2], lp_copy=lp, plan=self._plan(lengths, x.shape[1]))
         if save:
             s.pre, s.cfg, s.x, s.film, s.lengths = pre, cfg, xin, film, lengths
             s.qkv, s.o, s.lse, s.s1, s.mean1, s.rstd1, s.a, s.h, s.s2, s.mean2, s.rstd2 = qkv, o, lse, s1, mean1, rstd1, ain, h, s2, mean2, rstd2
@@ -460,6 +474,7 @@ class DaftExprt(nn.Module):
         ops.H.require_gpu(symbols, mel_specs)
         self._step_id += 1
         self._site = 0
+        self._plans = {}
         W = self._weights(need_dgrad=save)
         S = _Saved() if save else None
         emb, films, s_pe = self._prosody_encoder_fwd(W, frames_energy, frames_pitch, mel_specs, speaker_ids, output_lengths, train, save)
@@ -538,7 +553,8 @@ class DaftExprt(nn.Module):
         if fuse:
             dproj = ops.conv1d_lnbwd(dh, W[f'T:{f_pre}.convs.0.conv.weight'], da, s.s1, s.mean1, s.rstd1,
                                      P[f'{a_pre}.layer_norm.weight'], P[f'{a_pre}.layer_norm.bias'], s.lengths,
-                                     G[f'{a_pre}.layer_norm.weight'], G[f'{a_pre}.layer_norm.bias'], p_pre=s.p_attn, seed_pre=s.seeds[1])
+                                     G[f'{a_pre}.layer_norm.weight'], G[f'{a_pre}.layer_norm.bias'], p_pre=s.p_attn, seed_pre=s.seeds[1],
+                                     plan=self._plan(s.lengths, dh.shape[1]))
             ds1 = da
         else:
             ops.conv1d(dh, W[f'T:{f_pre}.convs.0.conv.weight'], None, out=da, accumulate=True, skip_lengths=s.lengths)

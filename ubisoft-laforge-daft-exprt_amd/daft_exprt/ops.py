@@ -78,9 +78,9 @@ def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, m
     return out
 
 
-def conv1d_ln(x, w_packed, bias, residual, gamma, beta, lengths, film=None, save=False, p_pre=0., seed_pre=0, lp_copy=False):
+def conv1d_ln(x, w_packed, bias, residual, gamma, beta, lengths, film=None, save=False, p_pre=0., seed_pre=0, lp_copy=False, plan=None):
     ''' conv / linear to 128 channels with the following LayerNorm (+dropout, residual, FiLM, mask) fused into the epilogue.
-        Returns (y, y_lp, s_out, mean, rstd) '''
+        plan: conv_tile_plan(lengths, N) of this batch (bf16 k = 3 GEMMs only).  Returns (y, y_lp, s_out, mean, rstd) '''
     B, N, Cin = x.shape
     taps, Cout, _ = w_packed.shape
     assert Cout == 128 and x.stride(2) == 1 and residual.is_contiguous()
@@ -94,12 +94,12 @@ def conv1d_ln(x, w_packed, bias, residual, gamma, beta, lengths, film=None, save
         H.check(H.lib().dx_conv1d_ln(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(bias), H.ptr(residual),
                                      H.ptr(gamma), H.ptr(beta), H.ptr(film), film.stride(0) if film is not None else 0, H.ptr(lengths),
                                      H.ptr(y), H.ptr(y_lp), H.ptr(s_out), H.ptr(mean), H.ptr(rstd), B, N, Cin, taps, float(p_pre),
-                                     int(seed_pre), H.stream()))
+                                     int(seed_pre), *_plan_args(plan, x, w_packed, B, N), H.stream()))
     return y, y_lp, s_out, mean, rstd
 
 
 def conv1d_lnbwd(x, w_packed, y_inout, s_in, mean, rstd, gamma, beta, lengths, dgamma, dbeta, film=None, dfilm=None,
-                 p_pre=0., seed_pre=0):
+                 p_pre=0., seed_pre=0, plan=None):
     ''' data gradient of a conv / linear into a 128-channel residual stream + the backward of the LayerNorm that consumed
         that stream, one launch (see dx_conv1d_lnbwd).  y_inout (B, N, 128) fp32: residual gradient in, ds out (in place).
         Returns the bf16 dropout_pre(ds).  dgamma / dbeta / dfilm accumulate. '''
@@ -113,8 +113,27 @@ def conv1d_lnbwd(x, w_packed, y_inout, s_in, mean, rstd, gamma, beta, lengths, d
         H.check(H.lib().dx_conv1d_lnbwd(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(y_inout), H.ptr(s_in),
                                         H.ptr(mean), H.ptr(rstd), H.ptr(gamma), H.ptr(beta), H.ptr(film), ldf, H.ptr(lengths),
                                         H.ptr(dx_lp), H.ptr(dgamma), H.ptr(dbeta), H.ptr(dfilm), lddf, B, N, Cin, taps,
-                                        float(p_pre), int(seed_pre), H.stream()))
+                                        float(p_pre), int(seed_pre), *_plan_args(plan, x, w_packed, B, N), H.stream()))
     return dx_lp
+
+
+def conv_tile_plan(lengths, N):
+    ''' balanced position tiles of one batch for the LayerNorm-fused k = 3 GEMMs (dx_conv_tile_plan): build once per batch,
+        pass as plan= to conv1d_ln / conv1d_lnbwd.  Returns (int32 table (n_tiles, 4) on the device, B, N) '''
+    B = lengths.shape[0]
+    n = H.lib().dx_conv_tile_plan_size(B, N)
+    table = torch.empty((n, 4), dtype=torch.int32, device=lengths.device)
+    H.check(H.lib().dx_conv_tile_plan(H.ptr(lengths), B, N, n, H.ptr(table), H.stream()))
+    return table, B, N
+
+
+def _plan_args(plan, x, w_packed, B, N):
+    ''' (table pointer, n_tiles) when the plan applies to this GEMM (bf16 operands, k = 3, same batch geometry) '''
+    if plan is None or x.dtype != torch.bfloat16 or w_packed.dtype != torch.bfloat16 or w_packed.shape[0] != 3 or x.shape[2] % 32:
+        return None, 0
+    table, pb, pn = plan
+    assert (pb, pn) == (B, N), 'tile plan built for another batch geometry'
+    return H.ptr(table), table.shape[0]
 
 
 def pack_table(entries, device):
