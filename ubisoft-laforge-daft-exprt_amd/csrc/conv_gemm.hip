@@ -908,7 +908,8 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
     const bool film = LN == 2 && a.ln.film != nullptr;
     if constexpr (sizeof(TA) == 2 && sizeof(TC) == 2) {
       if (a.plan && taps == 3) {   // balanced 256-row tiles + padding-fill workgroups (dx_conv_tile_plan)
-        dim3 gridp((unsigned)(a.plan_tiles + B * dx_cdiv(a.N, 256)));
+        static int nofill = getenv("DX_PLAN_NOFILL") ? atoi(getenv("DX_PLAN_NOFILL")) : 0;   // development: skip the padding fill
+        dim3 gridp((unsigned)(a.plan_tiles + (nofill ? 0 : B * dx_cdiv(a.N, 256))));
         if (film) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 4, 32, LN, 3>), gridp, dim3(2 * NTHREADS), 0, s, a);
         else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 4, 32, LNB, 3>), gridp, dim3(2 * NTHREADS), 0, s, a);
         DX_LAUNCH_CHECK();
@@ -1185,16 +1186,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const int ci = (tile % tiles_ci) * WG_CI + wn * 32 + (lane & 31);               // .. ci + 3 (lane % 4 == 0)
   const float* src = ws + (size_t)tile * TILE_FLOATS + e0;
   const size_t stride = (size_t)ntiles * TILE_FLOATS;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  // 8 splits in flight per thread: the kernel is a chain of dependent HBM round trips (nsplit / in-flight of them)
+  f32x4 acc8[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc8[u] = f32x4{0.f, 0.f, 0.f, 0.f};
   int k = 0;
-  for (; k + 3 < nsplit; k += 4) {
-    s0 += *reinterpret_cast<const f32x4*>(src + (size_t)k * stride);
-    s1 += *reinterpret_cast<const f32x4*>(src + (size_t)(k + 1) * stride);
-    s2 += *reinterpret_cast<const f32x4*>(src + (size_t)(k + 2) * stride);
-    s3 += *reinterpret_cast<const f32x4*>(src + (size_t)(k + 3) * stride);
+  for (; k + 7 < nsplit; k += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(k + u) * stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc8[u] += v[u];
   }
-  for (; k < nsplit; ++k) s0 += *reinterpret_cast<const f32x4*>(src + (size_t)k * stride);
-  const f32x4 sum = (s0 + s1) + (s2 + s3);
+  for (; k < nsplit; ++k) acc8[0] += *reinterpret_cast<const f32x4*>(src + (size_t)k * stride);
+  const f32x4 sum = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
   if (co < Cout) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
