@@ -88,7 +88,8 @@ int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void* w_packed, 
  * fetches the whole weight slice whatever the height of its tile; a ragged batch (model.py:21-23 masks, lengths differ
  * 10x inside a batch) cut into fixed 128-row tiles ends a few tiles above a multiple of the 256 CUs.  The plan cuts
  * each utterance into equal pieces of <= 256 rows so that the batch is exactly n_tiles = dx_conv_tile_plan_size(B, N)
- * pieces (a multiple of 256) with the smallest possible maximum height.  table: n_tiles x 4 int32 {b, n0, rows, 0},
+ * pieces (a multiple of 256) with the smallest possible maximum height.  table: n_tiles x 4 int32 {b, n0, rows, f}
+ * (f = padding rows of the batch each workgroup zero-fills beside its tile),
  * device memory, valid for every GEMM over the same lengths (one plan per batch).  Results are identical to the
  * unplanned call: same rows, same summation order per output; rows >= lengths[b] are written as zeros. */
 int dx_conv_tile_plan_size(int B, int N);

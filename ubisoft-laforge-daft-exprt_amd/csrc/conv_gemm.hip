@@ -162,24 +162,16 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
   // order keeps the weight working set of an XCD at one slice, which matters once the inner loop gets faster.)
   // PLAN (ring kernels with 256-row tiles, one channel tile): the position tiles come from a table that cuts every
   // utterance into equal pieces of <= 256 rows such that the whole batch is a multiple of 256 workgroups of (nearly) the
-  // same height -- a workgroup costs one pass over the weights whatever its height.  Workgroups past the table zero-fill
-  // the padding rows [length, N) of one utterance, 256 rows each.
+  // same height -- a workgroup costs one pass over the weights whatever its height.  The padding rows [length, N) of the
+  // batch are zero-filled by the loader waves, an equal share per workgroup, while the first chunks are in flight.
   constexpr bool PLAN = RING > 0 && MI == 4;
   int n0, b, co0, h = BM;              // h = rows of this tile
-  bool fill_only = false;
+  int fill_per = 0;                    // PLAN: padding rows (flattened over the batch) this workgroup zero-fills
   if constexpr (PLAN) {
     co0 = 0;
-    if ((int)blockIdx.x < p.plan_tiles) {
-      const int4 e = reinterpret_cast<const int4*>(p.plan)[blockIdx.x];
-      b = e.x; n0 = e.y; h = e.z;
-      if (h <= 0) return;
-    } else {
-      const int j = blockIdx.x - p.plan_tiles, per_b = dx_cdiv(p.N, BM);
-      b = j / per_b;
-      n0 = (int)p.skip_len[b] + (j - b * per_b) * BM;
-      if (n0 >= p.N) return;
-      fill_only = true;
-    }
+    const int4 e = reinterpret_cast<const int4*>(p.plan)[blockIdx.x];
+    b = e.x; n0 = e.y; h = e.z; fill_per = e.w;
+    if (h <= 0 && threadIdx.x < NTHREADS) return;       // an empty tile: only its loader waves work (padding fill)
   } else {
     const int ztiles = dx_cdiv(p.Cout, BN), ptiles = dx_cdiv(p.N, BM);
     const int Lid = blockIdx.x, jj = Lid >> 3;
@@ -199,7 +191,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
   const bool vec_out = !trans && (Cout % 8 == 0) && (p.ldy % 8 == 0);
 
   // padding early-out: a tile that starts past length + conv halo cannot reach a valid output -> zeros, no MFMA
-  if (PLAN ? fill_only : (p.skip_len && n0 >= (int)p.skip_len[b] + 2)) {
+  if (!PLAN && p.skip_len && n0 >= (int)p.skip_len[b] + 2) {
     if (RING && tid >= NTHREADS) return;             // loader waves
     if (LN == 2) {   // incoming residual gradient rows are zero there and stay; the bf16 dx_pre rows must exist as zeros
       float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -308,10 +300,52 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
       static_assert(MAXP * (RING - 2) <= 36, "vmcnt switch too short");
 #pragma unroll
       for (int st = 0; st < RING - 1; ++st)
-        if (st < nk) issue_chunk(st, st);
+        if (st < nk && h > 0) issue_chunk(st, st);
+      bool stores_in_flight = false;
+      if constexpr (PLAN) {
+        // padding fill: the batch's padding rows, flattened utterance by utterance, are split evenly over the workgroups;
+        // this one owns [lo, hi).  Each loader wave finds the utterances its range touches with a wave scan over the
+        // lengths, and the 256 loader threads share the 16-byte segments of those rows.
+        const long lo = (long)blockIdx.x * fill_per, hi = lo + fill_per;
+        const int ltid = lw * 64 + lane;
+        long carry = 0;
+        for (int base = 0; base < p.B && carry < hi; base += 64) {
+          const int ub = base + lane;
+          const int ulen = ub < p.B ? (int)p.skip_len[ub] : N;
+          const int dead = ub < p.B ? N - (ulen < 0 ? 0 : (ulen > N ? N : ulen)) : 0;
+          int incl = dead;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+          const long ustart = carry + incl - dead, uend = carry + incl;
+          const long fs = ustart > lo ? ustart : lo, fe = uend < hi ? uend : hi;
+          unsigned long long todo = __ballot(fs < fe);
+          while (todo) {
+            const int src_lane = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int fb = base + src_lane;
+            const int first = __shfl(N - dead + (int)(fs - ustart), src_lane, 64), cnt = __shfl((int)(fe - fs), src_lane, 64);
+            float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int c = ltid; c < cnt * (BN / 8); c += NTHREADS) {
+              const int n = first + (c >> 4), cl = (c & 15) * 8;
+              const size_t off = ((size_t)fb * N + n) * BN + cl;
+              store8<float>(p.ln.y + off, z);
+              if (LN == 2 || p.ln.y_lp) store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + off, z);
+              if (LN == 1) {
+                if (p.ln.s_out) store8<float>(p.ln.s_out + off, z);
+                if (p.ln.mean && cl == 0) { p.ln.mean[(size_t)fb * N + n] = 0.f; p.ln.rstd[(size_t)fb * N + n] = 0.f; }
+              }
+            }
+            stores_in_flight = true;
+          }
+          carry += __shfl(incl, 63, 64);
+        }
+        if (h <= 0) return;
+      }
       int nbuf = RING - 1, k = 0;                                // buffer that chunk k + RING - 1 goes to
       for (; k + RING - 1 < nk; ++k) {
-        wait_landed(mine * (RING - 2));
+        // (the fill's stores share the counter and may retire out of order with the loads: drain everything once)
+        if (PLAN && k == 0 && stores_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else wait_landed(mine * (RING - 2));
         __builtin_amdgcn_s_barrier();
         issue_chunk(k + RING - 1, nbuf);
         nbuf = nbuf + 1 == RING ? 0 : nbuf + 1;
@@ -908,8 +942,7 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
     const bool film = LN == 2 && a.ln.film != nullptr;
     if constexpr (sizeof(TA) == 2 && sizeof(TC) == 2) {
       if (a.plan && taps == 3) {   // balanced 256-row tiles + padding-fill workgroups (dx_conv_tile_plan)
-        static int nofill = getenv("DX_PLAN_NOFILL") ? atoi(getenv("DX_PLAN_NOFILL")) : 0;   // development: skip the padding fill
-        dim3 gridp((unsigned)(a.plan_tiles + (nofill ? 0 : B * dx_cdiv(a.N, 256))));
+        dim3 gridp((unsigned)a.plan_tiles);
         if (film) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 4, 32, LN, 3>), gridp, dim3(2 * NTHREADS), 0, s, a);
         else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 4, 32, LNB, 3>), gridp, dim3(2 * NTHREADS), 0, s, a);
         DX_LAUNCH_CHECK();
@@ -1410,16 +1443,22 @@ __global__ __launch_bounds__(64) void conv_plan_kernel(const int64_t* __restrict
     first[B] = acc;
   }
   __syncthreads();
+  // padding rows of the batch, split evenly over the T workgroups (entry.w)
+  long dead = 0;
+  for (int b = lane; b < B; b += 64) dead += N - len_of(b);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dead += __shfl_xor(dead, o, 64);
+  const int per = (int)((dead + T - 1) / T);
   for (int b = lane; b < B; b += 64) {
     const int l = len_of(b), t = first[b + 1] - first[b];
     if (t == 0) continue;
     const int hb = (l + t - 1) / t;                    // equal pieces inside the utterance
     for (int j = 0; j < t; ++j) {
       const int n0 = j * hb, rows = l - n0 < hb ? l - n0 : hb;
-      if (first[b] + j < T) table[first[b] + j] = make_int4(b, n0, rows > 0 ? rows : 0, 0);
+      if (first[b] + j < T) table[first[b] + j] = make_int4(b, n0, rows > 0 ? rows : 0, per);
     }
   }
-  for (int i = first[B] + lane; i < T; i += 64) table[i] = make_int4(0, 0, 0, 0);
+  for (int i = first[B] + lane; i < T; i += 64) table[i] = make_int4(0, 0, 0, per);
 }
 
 extern "C" int dx_conv_tile_plan_size(int B, int N) {

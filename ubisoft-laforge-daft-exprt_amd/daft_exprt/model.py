@@ -179,6 +179,7 @@ class DaftExprt(nn.Module):
         self.fuse_ln_backward = bool(int(__import__('os').environ.get('DX_FUSE_LN_BWD', '1')))   # see _fft_block_bwd
         self.balanced_tiles = bool(int(__import__('os').environ.get('DX_BALANCED_TILES', '1')))   # see _plan
         self._plans = {}
+        self._plan_min_rows = int(__import__('os').environ.get('DX_PLAN_MIN_ROWS', '0'))
         self._step_id, self._site = 0, 0
         self._pos = None
         self.n_params = sum(int(np.prod(s)) for _, s, _ in self._table)
@@ -278,7 +279,7 @@ class DaftExprt(nn.Module):
         ''' balanced position tiles of this step's batch for the LayerNorm-fused k = 3 GEMMs (`ops.conv_tile_plan`): one
             small launch per distinct lengths tensor per step, shared by the 8 forward and 8 backward launches that read it.
             Frame-level stacks only: a phoneme-level batch is too small for the tile count to matter. '''
-        if not self.balanced_tiles or self.cd != torch.bfloat16 or lengths is None or lengths.shape[0] * N < 16384:
+        if not self.balanced_tiles or self.cd != torch.bfloat16 or lengths is None or lengths.shape[0] * N < self._plan_min_rows:
             return None
         key = (lengths.data_ptr(), N)
         plan = self._plans.get(key)
