@@ -443,6 +443,7 @@ extern "C" int dx_layernorm_bwd(const void* dy, int dy_dtype, const void* s_in, 
   if (s_dtype == DX_BF16 && dy_dtype == DX_BF16 && d_dtype == DX_BF16) return launch_bwd<bf16_t, bf16_t, bf16_t>(a, C, s);
   if (s_dtype == DX_BF16 && dy_dtype == DX_F32 && d_dtype == DX_BF16) return launch_bwd<bf16_t, float, bf16_t>(a, C, s);
   if (s_dtype == DX_F32 && dy_dtype == DX_BF16 && d_dtype == DX_F32) return launch_bwd<float, bf16_t, float>(a, C, s);
+  if (s_dtype == DX_F32 && dy_dtype == DX_F32 && d_dtype == DX_BF16) return launch_bwd<float, float, bf16_t>(a, C, s);
   dx_set_error("dx_layernorm_bwd: unsupported dtypes s=%d dy=%d d=%d", s_dtype, dy_dtype, d_dtype);
   return DX_ERR_DTYPE;
 }

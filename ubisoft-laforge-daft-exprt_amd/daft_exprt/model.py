@@ -581,9 +581,11 @@ class DaftExprt(nn.Module):
     def _conv_ln_bwd(self, W, s, dy, dfilm=None, need_dx=True, dx_out=None, lengths_hint=None):
         ''' backward of `_conv_ln_fwd`; returns grad wrt its input (dtype = the input's) '''
         P, G = self._P, self._G
+        # dc only feeds GEMMs (weight and data gradient): emit it in the MFMA operand type (= rounding at operand load)
+        d_dtype = self.cd if (self.cd == torch.bfloat16 and dy.dtype == torch.float32 and s.c.dtype == torch.float32) else s.c.dtype
         dc, _ = ops.layernorm_bwd(dy, s.c, s.mean, s.rstd, P[f'{s.ln_name}.weight'], P[f'{s.ln_name}.bias'],
                                   G[f'{s.ln_name}.weight'], G[f'{s.ln_name}.bias'], film=s.film, dfilm=dfilm, lengths=s.lengths,
-                                  d_dtype=s.c.dtype, p_post=s.p, seed_post=s.seed, relu_input=True, skip_lengths=s.skip)
+                                  d_dtype=d_dtype, p_post=s.p, seed_post=s.seed, relu_input=True, skip_lengths=s.skip)
         if not need_dx:   # last op of the backward pass: nothing left on the main stream to overlap with, and the side stream
             # still has the previous (large) weight gradient queued -- launch here
             ops.conv1d_wgrad(dc, s.x, G[f'{s.conv_name}.conv.weight'], G[f'{s.conv_name}.conv.bias'], self.cd, lengths_hint)
