@@ -1137,36 +1137,44 @@ __global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wg
     commit();
     __syncthreads();
   }
-  while (left > 0) {
-    --left;
-    if (left > 0) {                                 // next item
-      n0 += WG_P;
-      if (n0 >= nlim) { ++b; n0 = 0; nlim = nlim_of(b); }
-      fetch(b, n0, nlim);
-    }
-    if (!(p.debug & 2))
+  // two copies of the item loop, with and without the bias MFMAs (a quarter of the matrix work, needed by 1 wave in 4
+  // of the ci0 == 0 tiles only); the choice is wave-uniform and made once, outside the loop
+  auto items = [&](auto bias_tag) {
+    constexpr bool BIAS = decltype(bias_tag)::value;
+    while (left > 0) {
+      --left;
+      if (left > 0) {                                 // next item
+        n0 += WG_P;
+        if (n0 >= nlim) { ++b; n0 = 0; nlim = nlim_of(b); }
+        fetch(b, n0, nlim);
+      }
+      if (!(p.debug & 2))
 #pragma unroll
-    for (int ks = 0; ks < WG_P / 16; ++ks) {
-      const int kA = ks * 16 + 8 * g, kB = kA + 4;
-      frag_t a[2];
+      for (int ks = 0; ks < WG_P / 16; ++ks) {
+        const int kA = ks * 16 + 8 * g, kB = kA + 4;
+        frag_t a[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = gather8<TC, 32>(dYs, LDA, kA, kB, wm * 64 + i * 32, lane);
-      // unconditional (branch-free): the matrix pipe has slack, a branch here makes the compiler bounce accumulators
+        for (int i = 0; i < 2; ++i) a[i] = gather8<TC, 32>(dYs, LDA, kA, kB, wm * 64 + i * 32, lane);
+        if (BIAS) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) dx_mma(bacc[i], a[i], ones);
+          for (int i = 0; i < 2; ++i) dx_mma(bacc[i], a[i], ones);
+        }
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        frag_t bx = gather8<TC, 32>(Xs, LDB, kA + t, kB + t, wn * 32, lane);
+        for (int t = 0; t < TAPS; ++t) {
+          frag_t bx = gather8<TC, 32>(Xs, LDB, kA + t, kB + t, wn * 32, lane);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) dx_mma(acc[t][i], a[i], bx);
+          for (int i = 0; i < 2; ++i) dx_mma(acc[t][i], a[i], bx);
+        }
+      }
+      __syncthreads();
+      if (left > 0) {
+        commit();
+        __syncthreads();
       }
     }
-    __syncthreads();
-    if (left > 0) {
-      commit();
-      __syncthreads();
-    }
-  }
+  };
+  if (__builtin_amdgcn_readfirstlane((int)do_bias)) items(std::true_type{});
+  else items(std::false_type{});
   if (!(p.debug & 1)) {
     if (p.ws) {
       float* out = p.ws + ((size_t)split * ntiles + tile) * SM::TILE_FLOATS;
@@ -1199,6 +1207,200 @@ __global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wg
         const int co = co0 + wm * 64 + i * 32 + dx_acc_row(r, g);
         if (co < Cout) atomicAdd(p.db + co, bacc[i][r]);
       }
+  }
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (LDS-DMA rings: "all but my pieces of the younger stages have landed")
+__device__ __forceinline__ void dx_wait_vmcnt(int n) {
+  switch (n) {
+#define DX_VMW(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+    DX_VMW(1) DX_VMW(2) DX_VMW(3) DX_VMW(4) DX_VMW(5) DX_VMW(6) DX_VMW(7) DX_VMW(8) DX_VMW(9) DX_VMW(10) DX_VMW(11) DX_VMW(12)
+    DX_VMW(13) DX_VMW(14) DX_VMW(15) DX_VMW(16) DX_VMW(17) DX_VMW(18) DX_VMW(19) DX_VMW(20) DX_VMW(21) DX_VMW(22) DX_VMW(23) DX_VMW(24)
+    DX_VMW(25) DX_VMW(26) DX_VMW(27) DX_VMW(28) DX_VMW(29) DX_VMW(30) DX_VMW(31) DX_VMW(32) DX_VMW(33) DX_VMW(34) DX_VMW(35) DX_VMW(36)
+#undef DX_VMW
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
+// transpose read from an UNPADDED row-major [rows][128] bf16 tile whose 64-byte segments are XOR-swizzled by row & 3
+// (segment s of row r sits at s ^ (r & 3)): the 4 rows x 64 bytes one 32-lane group of ds_read_b64_tr_b16 touches then
+// cover all 64 banks, and a 16-row x 64-byte LDS-DMA piece lands as 4 whole rows with the swizzle on the source side.
+__device__ __forceinline__ bf16x8 gather8_swz(const bf16_t* tile, int kA, int kB, int col0, int lane) {
+  const int i = lane & 15, half = (lane >> 4) & 1, j = i >> 2, q = i & 3;
+  const int ra = kA + j, rb = kB + j, seg = col0 >> 5, within = (col0 & 31) + 16 * half + 4 * q;
+  const bf16_t* pa = tile + ra * 128 + ((seg ^ (ra & 3)) << 5) + within;
+  const bf16_t* pb = tile + rb * 128 + ((seg ^ (rb & 3)) << 5) + within;
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+// ---- weight gradient, bf16 operands: LDS-DMA ring with loader waves (same tiles, item list, partial-tile layout and
+// reduce kernel as conv_wgrad_kernel).  768 threads: waves 0-7 own the 128 x 128 x taps accumulators (wave (wm, wn) of
+// 2 x 4: 64 co x 32 ci) and only read LDS and issue MFMAs; waves 8-11 stream the items -- dY [64][128] and the haloed X
+// [64 + taps - 1][128], unpadded rows with the gather8_swz swizzle -- into a 4-deep ring with global_load_lds_dwordx4
+// (1 KiB = 4 rows per piece; rows outside the item's utterance read a zero page), one workgroup barrier per item.  The
+// register-staged kernel spent 4800 cycles per item on 2048 cycles of MFMA work (two barriers, ds_write staging, and
+// the bias MFMAs in every wave); here the bias gradient is a column sum the loader waves take from the LDS tile.
+constexpr int WGR_THREADS = 768, WGR_RING = 4;
+template <int TAPS>
+__global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradArgs p) {
+  constexpr int HALO = TAPS / 2, XROWS = WG_P + TAPS - 1;
+  constexpr int A_PIECES = WG_P / 4, X_PIECES = (XROWS + 3) / 4, NP = A_PIECES + X_PIECES, ITEM_EL = NP * 512, MAXP = (NP + 3) / 4;
+  static_assert(MAXP * (WGR_RING - 2) <= 36, "vmcnt switch too short");
+  __shared__ __attribute__((aligned(16))) bf16_t ring[WGR_RING * ITEM_EL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
+  const int ntiles = dx_cdiv(p.Cout, WG_CO) * p.tiles_ci;
+  const int split = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+  const int co0 = (tile / p.tiles_ci) * WG_CO, ci0 = (tile % p.tiles_ci) * WG_CI;
+  const int N = p.N, Cin = p.Cin, Cout = p.Cout;
+  auto nlim_of = [&](int b) { return p.lengths ? min(N, (int)p.lengths[b] + 2) : N; };
+  int total = 0;
+  for (int b = 0; b < p.B; ++b) total += dx_cdiv(nlim_of(b), WG_P);
+  const int i0 = (int)((long)total * split / p.nsplit), i1 = (int)((long)total * (split + 1) / p.nsplit);
+  const int count = i1 - i0;
+
+  if (wave >= 8) {
+    // ---- loader waves
+    const int lw = __builtin_amdgcn_readfirstlane(wave) - 8;
+    const int mine = (NP - lw + 3) >> 2;
+    int ib = 0, in0 = 0, ilim = 0;
+    for (int cum = 0; ib < p.B; ++ib) {               // locate item i0
+      ilim = nlim_of(ib);
+      const int c = dx_cdiv(ilim, WG_P);
+      if (i0 < cum + c) { in0 = (i0 - cum) * WG_P; break; }
+      cum += c;
+    }
+    // per-piece constants (A_PIECES is a multiple of 4: slot t < A_PIECES / 4 is a dY piece for every loader): the row
+    // inside the item and this lane's column; per item only the row number changes -- the loaders are instruction-bound
+    // (the first version recomputed everything per piece and needed 4400 cycles per item for 1500 cycles of MFMA work)
+    static_assert(A_PIECES % 4 == 0, "dY pieces per loader must not depend on the loader");
+    constexpr int TA_SLOTS = A_PIECES / 4;
+    const bf16_t* zp = reinterpret_cast<const bf16_t*>(dx_zero_page);
+    int roff[MAXP], coff[MAXP];
+    bool cok[MAXP];
+#pragma unroll
+    for (int t = 0; t < MAXP; ++t) {
+      const bool isx = t >= TA_SLOTS;
+      const int q = lw + 4 * t, r = (isx ? q - A_PIECES : q) * 4 + (lane >> 4), c16 = (lane & 15) ^ ((r & 3) << 2);
+      roff[t] = isx ? r - HALO : r;
+      coff[t] = (isx ? ci0 : co0) + c16 * 8;
+      cok[t] = isx ? (r < XROWS && coff[t] < Cin) : (coff[t] < Cout);
+    }
+    const uint32_t lddy = (uint32_t)p.lddy, ldx = (uint32_t)p.ldx;
+    auto issue_item = [&](int buf) {
+      const bf16_t* dY = reinterpret_cast<const bf16_t*>(p.dy) + (size_t)ib * N * p.lddy;
+      const bf16_t* X = reinterpret_cast<const bf16_t*>(p.x) + (size_t)ib * N * p.ldx;
+      const int xlim = ilim < N - 1 ? ilim : N - 1;          // X rows are valid for 0 <= n <= min(ilim, N - 1)
+#pragma unroll
+      for (int t = 0; t < MAXP; ++t) {
+        if (lw + 4 * t < NP) {
+          const bool isx = t >= TA_SLOTS;
+          const int n = in0 + roff[t];
+          const bool ok = cok[t] && (isx ? (unsigned)n <= (unsigned)xlim : n < ilim);
+          const uint32_t off = __umul24((uint32_t)n, isx ? ldx : lddy) + (uint32_t)coff[t];
+          const bf16_t* sp = ok ? (isx ? X : dY) + off : zp + (coff[t] & 127);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                           (__attribute__((address_space(3))) void*)(ring + buf * ITEM_EL + (lw + 4 * t) * 512), 16, 0, 0);
+        }
+      }
+      in0 += WG_P;                                     // advance to the next item of the list
+      if (in0 >= ilim) { ++ib; in0 = 0; ilim = ib < p.B ? nlim_of(ib) : 0; }
+    };
+    const bool bias_wg = p.db && ci0 == 0 && !(p.debug & 4);
+    float bs0 = 0.f, bs1 = 0.f;                        // bias gradient: channels 2 * lane, 2 * lane + 1 over rows 16 lw .. 16 lw + 15
+    auto bias_rows = [&](int buf) {
+      const bf16_t* A = ring + buf * ITEM_EL;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int r = lw * 16 + rr, c16 = (lane >> 2) ^ ((r & 3) << 2);
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(A + r * 128 + c16 * 8 + (lane & 3) * 2);
+        bs0 += __uint_as_float(v << 16);
+        bs1 += __uint_as_float(v & 0xffff0000u);
+      }
+    };
+#pragma unroll
+    for (int st = 0; st < WGR_RING - 1; ++st)
+      if (st < count) issue_item(st);
+    int nbuf = WGR_RING - 1, buf = 0, k = 0;
+    for (; k + WGR_RING - 1 < count; ++k) {
+      dx_wait_vmcnt(mine * (WGR_RING - 2));
+      __builtin_amdgcn_s_barrier();
+      issue_item(nbuf);
+      if (bias_wg) bias_rows(buf);
+      nbuf = nbuf + 1 == WGR_RING ? 0 : nbuf + 1;
+      buf = buf + 1 == WGR_RING ? 0 : buf + 1;
+    }
+    for (; k < count; ++k) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (bias_wg) bias_rows(buf);
+      buf = buf + 1 == WGR_RING ? 0 : buf + 1;
+    }
+    if (bias_wg) {
+      const int co = co0 + 2 * lane;
+      if (co < Cout) atomicAdd(p.db + co, bs0);
+      if (co + 1 < Cout) atomicAdd(p.db + co + 1, bs1);
+    }
+    return;
+  }
+
+  // ---- MFMA waves
+  const int wm = wave >> 2, wn = wave & 3;
+  f32x16 acc[TAPS][2];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
+  int buf = 0;
+  for (int k = 0; k < count; ++k) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const bf16_t* A = ring + buf * ITEM_EL;
+    const bf16_t* Xs = A + A_PIECES * 512;
+    if (!(p.debug & 2))
+#pragma unroll
+    for (int ks = 0; ks < WG_P / 16; ++ks) {
+      const int kA = ks * 16 + 8 * g, kB = kA + 4;
+      bf16x8 a[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = gather8_swz(A, kA, kB, wm * 64 + i * 32, lane);
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const bf16x8 bx = gather8_swz(Xs, kA + t, kB + t, wn * 32, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dx_mma(acc[t][i], a[i], bx);
+      }
+    }
+    buf = buf + 1 == WGR_RING ? 0 : buf + 1;
+  }
+  if (p.debug & 1) return;
+  if (p.ws) {
+    float* out = p.ws + ((size_t)split * ntiles + tile) * (TAPS * 2 * 16 * WG_THREADS);
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[((t * 2 + i) * 16 + r) * WG_THREADS + tid] = acc[t][i][r];
+  } else {
+    const int ci = ci0 + wn * 32 + l31;
+    if (ci < Cin) {
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 64 + i * 32 + dx_acc_row(r, g);
+            if (co < Cout) atomicAdd(p.dw + ((size_t)co * Cin + ci) * TAPS + t, acc[t][i][r]);
+          }
+    }
   }
 }
 
@@ -1244,12 +1446,17 @@ template <typename TA, typename TB, typename TC>
 int launch_wgrad(const WgradArgs& a, int taps, hipStream_t s) {
   const int ntiles = dx_cdiv(a.Cout, WG_CO) * a.tiles_ci;
   dim3 grid(ntiles * a.nsplit), block(WG_THREADS);
+  static int use_ring = getenv("DX_WGRAD_RING") ? atoi(getenv("DX_WGRAD_RING")) : 1;
+  const bool ring = use_ring && sizeof(TA) == 2 && sizeof(TB) == 2 && sizeof(TC) == 2 && a.lddy % 8 == 0 && a.ldx % 8 == 0 &&
+                    a.Cout % 8 == 0 && a.Cin % 8 == 0;
   if (taps == 1) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 1>), grid, block, 0, s, a);
+    if (ring) hipLaunchKernelGGL((conv_wgrad_ring_kernel<1>), grid, dim3(WGR_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 1>), grid, block, 0, s, a);
     if (a.ws && !(a.debug & 1))
       hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(ntiles * (1 * 2 * 16 * WG_THREADS / 4 / 256)), dim3(256), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
   } else {
-    hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 3>), grid, block, 0, s, a);
+    if (ring) hipLaunchKernelGGL((conv_wgrad_ring_kernel<3>), grid, dim3(WGR_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 3>), grid, block, 0, s, a);
     if (a.ws && !(a.debug & 1))
       hipLaunchKernelGGL((wgrad_reduce_kernel<3>), dim3(ntiles * (3 * 2 * 16 * WG_THREADS / 4 / 256)), dim3(256), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
   }
