@@ -1449,8 +1449,9 @@ int launch_wgrad(const WgradArgs& a, int taps, hipStream_t s) {
   static int use_ring = getenv("DX_WGRAD_RING") ? atoi(getenv("DX_WGRAD_RING")) : 1;
   const bool ring = use_ring && sizeof(TA) == 2 && sizeof(TB) == 2 && sizeof(TC) == 2 && a.lddy % 8 == 0 && a.ldx % 8 == 0 &&
                     a.Cout % 8 == 0 && a.Cin % 8 == 0;
+  static int ring_k1 = getenv("DX_WGRAD_RING_K1") ? atoi(getenv("DX_WGRAD_RING_K1")) : 0;   // k = 1: fetch-bound, two register-staged workgroups per CU hide more latency
   if (taps == 1) {
-    if (ring) hipLaunchKernelGGL((conv_wgrad_ring_kernel<1>), grid, dim3(WGR_THREADS), 0, s, a);
+    if (ring && ring_k1) hipLaunchKernelGGL((conv_wgrad_ring_kernel<1>), grid, dim3(WGR_THREADS), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 1>), grid, block, 0, s, a);
     if (a.ws && !(a.debug & 1))
       hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(ntiles * (1 * 2 * 16 * WG_THREADS / 4 / 256)), dim3(256), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
