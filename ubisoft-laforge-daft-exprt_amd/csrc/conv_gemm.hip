@@ -491,6 +491,31 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
           stage[(wm * 32 + dx_acc_row(r, g)) * STG_LD + cl] = v;
         }
       }
+      // LayerNorm epilogues: the global inputs of all four passes are requested BEFORE the barrier (one round trip per
+      // 64-row slab; issued pass by pass they are four dependent trips, because the in-place stores of a pass may alias
+      // the loads of the next one as far as the compiler knows -- they never do: every row belongs to one thread group)
+      constexpr bool PFB = !(LNFILM && MI != 2);     // FiLM-gradient variants at the 128 / 256 register caps: loads stay in their pass
+      f32x8 pf_a[4], pf_b[4];
+      float pf_m[4], pf_r[4];
+      if (LN != 0 && PFB) {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int sr = (tid >> 4) + pass * 16;
+          const int trow = PLAN ? i * 64 + sr : (sr >> 5) * 32 * MI + i * 32 + (sr & 31);
+          const int n = n0 + trow, cl = (tid & 15) * 8;
+          if (n < N && trow < h) {
+            const size_t rowg = (size_t)b * N + n, offl = rowg * BN + cl;
+            if (LN == 2) {
+              pf_a[pass] = raw_load8<float>(p.ln.y + offl);
+              pf_b[pass] = raw_load8<float>(p.ln.s_out + offl);
+              pf_m[pass] = p.ln.mean[rowg];
+              pf_r[pass] = p.ln.rstd[rowg];
+            } else {
+              pf_a[pass] = raw_load8<float>(p.ln.residual + offl);
+            }
+          }
+        }
+      }
       __syncthreads();
       // phase 2: whole 16-byte row segments: gate, mask, accumulate, store
 #pragma unroll
@@ -506,12 +531,12 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
           if (LN == 2) {        // fused LayerNorm BACKWARD: v + residual gradient = dL/d(LN output) of this row
             const size_t rowg = (size_t)b * N + n, offl = rowg * BN + cl;
             {
-              const f32x8 r = raw_load8<float>(p.ln.y + offl);
+              const f32x8 r = PFB ? pf_a[pass] : raw_load8<float>(p.ln.y + offl);
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = n < len ? v[e] + r[e] : 0.f;     // masked_fill rows carry no gradient
             }
-            const f32x8 sv = raw_load8<float>(p.ln.s_out + offl);
-            const float mean = p.ln.mean[rowg], rstd = p.ln.rstd[rowg];
+            const f32x8 sv = PFB ? pf_b[pass] : raw_load8<float>(p.ln.s_out + offl);
+            const float mean = PFB ? pf_m[pass] : p.ln.mean[rowg], rstd = PFB ? pf_r[pass] : p.ln.rstd[rowg];
             const f32x8 gm = raw_load8<float>(p.ln.gamma + cl);
             float xh[8], s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -557,7 +582,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
               for (int e = 0; e < 8; ++e) v[e] = dx_keep(key, (uint32_t)rowg * BN + cl + e, th) ? v[e] * sc : 0.f;
             }
             {
-              const f32x8 r = raw_load8<float>(p.ln.residual + offl);
+              const f32x8 r = pf_a[pass];
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] += r[e];
             }
