@@ -143,6 +143,35 @@ def test_wgrad_ragged_shapes_accumulate_and_fixed_order():
         assert float((db.cpu() - b.grad).abs().max()) <= 3e-5 * float(b.grad.abs().max()) + 1e-4
 
 
+def test_wgrad_ring_kernel_ragged_bf16():
+    ''' the LDS-DMA ring weight-gradient kernel (bf16 operands, k = 3): ragged lengths incl. an empty utterance, channel
+        counts that do not fill a 128 x 128 tile, N not a multiple of the 64-row item, sliced (strided) operands, bias
+        gradient from the loader waves, run-to-run reproducibility of dW; against autograd on the bf16-rounded operands '''
+    from daft_exprt import ops
+    from oracle import daft_exprt_cpu as O
+    g = torch.Generator().manual_seed(21)
+    for (B, N, Cin, Cout, lens) in ((5, 333, 136, 200, [333, 0, 64, 65, 200]), (3, 700, 1024, 128, [700, 31, 450]), (2, 70, 128, 384, None)):
+        xw = torch.randn(B, N, Cin + 8, generator=g).to(torch.bfloat16)
+        x = xw[:, :, 8:]                                             # row stride != channel count
+        dy = torch.randn(B, N, Cout, generator=g)
+        lt = torch.tensor(lens) if lens is not None else None
+        if lt is not None:
+            dy = dy * (torch.arange(N)[None, :, None] < lt[:, None, None])
+        dy = dy.to(torch.bfloat16)
+        w = (torch.randn(Cout, Cin, 3, generator=g) / 10).requires_grad_(True)
+        b = torch.zeros(Cout, requires_grad=True)
+        (O.conv1d_cl(x.float(), w, b) * dy.float()).sum().backward()
+        outs = []
+        for _ in range(2):
+            dw, db = torch.zeros(Cout, Cin, 3, device=DEV), torch.zeros(Cout, device=DEV)
+            ops.conv1d_wgrad(dy.to(DEV), xw.to(DEV)[:, :, 8:], dw, db, torch.bfloat16, lt.to(DEV) if lt is not None else None)
+            outs.append(dw.cpu())
+        scale = float(w.grad.abs().max())
+        assert float((outs[0] - w.grad).abs().max()) <= 2e-3 * scale, (B, N, Cin, Cout, float((outs[0] - w.grad).abs().max()), scale)
+        assert torch.equal(outs[0], outs[1])
+        assert float((db.cpu() - b.grad).abs().max()) <= 2e-3 * float(b.grad.abs().max()) + 1e-3
+
+
 @pytest.mark.parametrize('taps,cin,film,p', [(3, 1024, False, 0.1), (1, 384, True, 0.2), (3, 128, True, 0.), (1, 128, False, 0.)])
 def test_conv_lnbwd_fusion_matches_two_launches(taps, cin, film, p):
     ''' dx_conv1d_lnbwd == dx_conv1d(ACCUMULATE) followed by dx_layernorm_bwd (same dropout counter stream), including
