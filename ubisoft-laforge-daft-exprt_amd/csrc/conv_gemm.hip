@@ -164,7 +164,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
   // utterance into equal pieces of <= 256 rows such that the whole batch is a multiple of 256 workgroups of (nearly) the
   // same height -- a workgroup costs one pass over the weights whatever its height.  The padding rows [length, N) of the
   // batch are zero-filled by the loader waves, an equal share per workgroup, while the first chunks are in flight.
-  constexpr bool PLAN = RING > 0 && MI == 4;
+  constexpr bool PLAN = RING > 0 && MI == 4 && LNM != 0;
   int n0, b, co0, h = BM;              // h = rows of this tile
   int fill_per = 0;                    // PLAN: padding rows (flattened over the batch) this workgroup zero-fills
   if constexpr (PLAN) {
@@ -1022,6 +1022,8 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
     dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * ztiles)), block(NTHREADS);
     if constexpr (sizeof(TC) == 2) {
       if (mi == 4) {
+        // (the loader-wave ring at this tile shape measured 918 vs 942 TFLOP/s: the activation stream comes from HBM / Infinity
+        // Cache at ~10 B/clk/CU, the pipeline is not the limit)
         hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 4, 32>), grid, block, 0, s, a);
         DX_LAUNCH_CHECK();
         return DX_OK;
