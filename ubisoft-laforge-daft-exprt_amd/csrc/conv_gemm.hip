@@ -2,13 +2,16 @@
 //
 //   Y[b, n, co] = bias[co] + sum_{tap, ci} X[b, n + tap - taps/2, ci] * W[tap][co][ci]
 //
-// Tiling: one workgroup (4 waves) computes a 128-position x 128-channel tile of ONE utterance, so the
-// conv halo is simply rows n0-1 .. n0+128 of that utterance (rows outside [0, N) are zero padding).
-// The K loop walks Cin in chunks of 32; per chunk the haloed activation tile (130 x 32) and the weight
-// tile (taps x 128 x 32) are staged in LDS (rows padded by 16 B -> conflict-free ds_read_b128 fragment
-// reads), and every tap reuses the same activation tile at a row offset -- no im2col is materialised.
-// Each wave owns a 64 x 64 sub-tile = 2 x 2 MFMA 32x32 accumulators (64 VGPRs).
+// Tiling: one workgroup (4 MFMA waves) computes a 64 / 128 / 256-position x 128-channel tile of ONE utterance, so
+// the conv halo is simply rows n0-1 .. n0+rows of that utterance (rows outside [0, N) are zero padding).
+// The K loop walks Cin in chunks of 32; per chunk the haloed activation tile and the weight tile (taps x 128 x 32)
+// are staged in LDS (bf16: unpadded XOR-swizzled rows, fp32: rows padded by 16 B -> conflict-free ds_read_b128
+// fragment reads), and every tap reuses the same activation tile at a row offset -- no im2col is materialised.
+// Each wave owns a (32 MI) x 64 sub-tile = MI x 2 MFMA 32x32 accumulators.
 // Operand type TC: bf16 (v_mfma_f32_32x32x16_bf16) or fp32 (v_mfma_f32_32x32x2_f32, exact fp32 mode).
+// Variants in this file: conv_gemm_kernel (register-staged pipeline; RING: LDS-DMA ring with loader waves, and on top
+// of it the balanced variable-height tiles of dx_conv_tile_plan), conv_wreg_kernel (weights in registers, K <= 384),
+// conv_wgrad_kernel / conv_wgrad_ring_kernel + wgrad_reduce_kernel (weight gradients), the weight packers.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -687,9 +690,11 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
 // workgroup instead of once per position tile and never touch LDS.  128-position tiles of the input stream past:
 // the A tile (130 x 128) is double-buffered in LDS, fetched into registers one tile ahead, and shared by the 8 waves;
 // per k-step a wave reads 4 A fragments for 4 MFMAs (128 rows x 32 channels).  One barrier per tile.  The epilogue is
-// wave-private: each wave stages its 64 x 32 block through its own LDS patch and leaves as 16-byte row segments, so no
-// wave waits for another between tiles.  The live position tiles of the batch (skip_lengths) are split evenly over the
-// workgroups of a channel block; dead tiles are zero-filled in a second pass.
+// wave-private and register-only: the MFMA operands are swapped (D[co][pos]) so that a lane ends up with 8 consecutive
+// channels of one position after four v_permlane32_swap, bias / ReLU / gate are applied in that layout and the block
+// leaves through 16-byte buffer stores (out-of-range rows dropped by the descriptor), issued in slices between the
+// MFMAs of the next tile, so no wave waits for another between tiles.  The live position tiles of the batch
+// (skip_lengths) are split evenly over the workgroups of a channel block; dead tiles are zero-filled in a second pass.
 constexpr int WR_THREADS = 512, WR_BN = 256, WR_BM = 128;
 #ifndef WR_ABL
 #define WR_ABL 0   // compile-time ablation (development): 1 no MFMA, 2 no epilogue, 4 no global stores
