@@ -312,7 +312,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
         const long lo = (long)blockIdx.x * fill_per, hi = lo + fill_per;
         const int ltid = lw * 64 + lane;
         long carry = 0;
-        for (int base = 0; base < p.B && carry < hi; base += 64) {
+        for (int base = 0; base < p.B && carry < hi && !(p.flags & 256); base += 64) {
           const int ub = base + lane;
           const int ulen = ub < p.B ? (int)p.skip_len[ub] : N;
           const int dead = ub < p.B ? N - (ulen < 0 ? 0 : (ulen > N ? N : ulen)) : 0;
@@ -478,6 +478,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
   for (int q = 0; q < NCS; ++q)
 #pragma unroll
     for (int e = 0; e < 8; ++e) csum[q][e] = 0.f;
+  if (PLAN && (p.flags & 1024)) return;
   if (vec_out) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -650,6 +651,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += stage[(q * 16 + r) * BN + c];
+        if (p.flags & 512) continue;
         if (q == 0) atomicAdd(p.ln.dgamma + c, t);
         else if (q == 1) atomicAdd(p.ln.dbeta + c, t);
         else atomicAdd(p.ln.dfilm + (size_t)b * p.ln.lddf + (q == 3 ? BN : 0) + c, t);
@@ -1743,6 +1745,7 @@ extern "C" int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_
   ConvArgs a{x, ldx, w_packed, bias, nullptr, BN, nullptr, lengths, lengths, N, Cin, BN, 0, B,
              LNEpi{gamma, beta, residual, film, ldf, y, y_lp, s_out, mean, rstd, p_pre, seed_pre, 1}};
   a.plan = plan; a.plan_tiles = plan_tiles;
+  { static int dbg = getenv("DX_PLAN_DEBUG") ? atoi(getenv("DX_PLAN_DEBUG")) : 0; a.flags |= dbg; }
   hipStream_t s = (hipStream_t)stream;
   if (w_dtype == DX_BF16 && x_dtype == DX_BF16) return launch_taps<bf16_t, bf16_t, float, float, 1>(a, B, taps, s);
   if (w_dtype == DX_BF16 && x_dtype == DX_F32) return launch_taps<float, bf16_t, float, float, 1>(a, B, taps, s);
@@ -1768,6 +1771,7 @@ extern "C" int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void*
              LNEpi{gamma, beta, nullptr, film, ldf, y_inout, dx_pre_lp, const_cast<float*>(s_in), const_cast<float*>(mean),
                    const_cast<float*>(rstd), p_pre, seed_pre, 2, dgamma, dbeta, dfilm, lddf}};
   a.plan = plan; a.plan_tiles = plan_tiles;
+  { static int dbg = getenv("DX_PLAN_DEBUG") ? atoi(getenv("DX_PLAN_DEBUG")) : 0; a.flags |= dbg; }
   hipStream_t s = (hipStream_t)stream;
   if (w_dtype == DX_BF16 && x_dtype == DX_BF16) return launch_taps<bf16_t, bf16_t, float, float, 2>(a, B, taps, s);
   if (w_dtype == DX_BF16 && x_dtype == DX_F32) return launch_taps<float, bf16_t, float, float, 2>(a, B, taps, s);
