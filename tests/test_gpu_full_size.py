@@ -64,3 +64,51 @@ def test_fast_paths_match_plain_paths_and_step_is_reproducible():
     # linearity in the loss-gradient scale
     t3, g3, _ = _step(model, inputs, targets, weights, 7, scale=0.5)
     assert float((g3 * 2 - g0).norm()) <= 3e-4 * gn
+
+
+def test_balanced_tiles_match_fixed_tiles_at_full_size():
+    ''' the balanced variable-height tile launches (dx_conv_tile_plan) against the fixed-tile launches on the same dropout
+        masks: every prediction bit-identical (same rows, same summation order per output), gradients equal up to the
+        order of the per-channel atomics '''
+    model, inputs, targets, weights = _setup()
+    assert model.balanced_tiles
+    t0, g0, o0 = _step(model, inputs, targets, weights, 11)
+    model.balanced_tiles = False
+    try:
+        t1, g1, o1 = _step(model, inputs, targets, weights, 11)
+    finally:
+        model.balanced_tiles = True
+    assert all(torch.equal(a, b) for a, b in zip(o0, o1))
+    assert torch.allclose(t0, t1, rtol=1e-6, atol=0.)
+    gn = float(g0.norm())
+    assert float((g0 - g1).norm()) <= 2e-4 * gn, float((g0 - g1).norm()) / gn
+
+
+def test_tile_plans_are_rebuilt_for_every_batch():
+    ''' two different batches through the same model, back to back: the plan of the first (cached by the address of its
+        lengths tensor) must not survive into the second, whose lengths tensor may reuse that address '''
+    import bench
+    from daft_exprt.data_loader import synthetic_batch
+    from daft_exprt.model import DaftExprt
+    hp = bench.make_hparams(48, 'bf16')
+    dev = torch.device('cuda:0')
+    torch.manual_seed(hp.seed)
+    model = DaftExprt(hp).to(dev).eval()
+    outs = {}
+    for rnd in range(2):
+        for seed in (1, 2):
+            cb = synthetic_batch(hp, 16, seed=seed, t_max=700, force_first_full=True)
+            inputs, _, _ = model.parse_batch(dev, cb)
+            with torch.no_grad():
+                mel = model(inputs)[3][0].clone()
+            del inputs
+            if rnd == 0:
+                outs[seed] = mel
+            else:
+                assert torch.equal(outs[seed], mel), seed
+    model.balanced_tiles = False
+    for seed in (1, 2):
+        cb = synthetic_batch(hp, 16, seed=seed, t_max=700, force_first_full=True)
+        inputs, _, _ = model.parse_batch(dev, cb)
+        with torch.no_grad():
+            assert torch.equal(outs[seed], model(inputs)[3][0]), seed

@@ -282,10 +282,10 @@ class DaftExprt(nn.Module):
         if not self.balanced_tiles or self.cd != torch.bfloat16 or lengths is None or lengths.shape[0] * N < self._plan_min_rows:
             return None
         key = (lengths.data_ptr(), N)
-        plan = self._plans.get(key)
-        if plan is None:
-            plan = self._plans[key] = ops.conv_tile_plan(lengths, N)
-        return plan
+        hit = self._plans.get(key)
+        if hit is None or hit[0] is not lengths:      # the entry keeps `lengths` alive, so its address cannot be recycled under the key
+            hit = self._plans[key] = (lengths, ops.conv_tile_plan(lengths, N))
+        return hit[1]
 
     def _seed(self):
         self._site += 1
@@ -793,6 +793,7 @@ class DaftExprt(nn.Module):
             raise NotImplementedError
         ops.H.require_gpu(symbols, mel_spec_refs)
         self._site = 0
+        self._plans = {}
         W = self._weights(need_dgrad=False)
         _, films, _ = self._prosody_encoder_fwd(W, energy_refs, pitch_refs, mel_spec_refs, speaker_ids, ref_lengths, False, False)
         enc, _ = self._phoneme_encoder_fwd(W, symbols, films[0], input_lengths, False, False)
