@@ -1330,7 +1330,7 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
       const int xlim = ilim < N - 1 ? ilim : N - 1;          // X rows are valid for 0 <= n <= min(ilim, N - 1)
 #pragma unroll
       for (int t = 0; t < MAXP; ++t) {
-        if (lw + 4 * t < NP) {
+        if (lw + 4 * t < NP && !(p.debug & 8)) {   // debug 8: no loads (MFMA waves alone)
           const bool isx = t >= TA_SLOTS;
           const int n = in0 + roff[t];
           const bool ok = cok[t] && (isx ? (unsigned)n <= (unsigned)xlim : n < ilim);
@@ -1390,6 +1390,25 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
+  // Per-lane LDS offsets of the transpose reads, computed once: the rows a lane touches are (multiple of 4) + tap + j, so
+  // the swizzle term (row & 3) = (tap + j) & 3 is a lane constant per tap and the k-step only adds a compile-time
+  // immediate -- 5 address registers instead of one per (k-step, tap, half), which leaves room to read the fragments of
+  // k-step s + 1 before the MFMAs of k-step s (two MFMA waves per SIMD do not cover a ~190-cycle LDS round trip).
+  typedef short s16x8v __attribute__((ext_vector_type(8)));
+  const int li = lane & 15, lhalf = (lane >> 4) & 1, lj = li >> 2, lq = li & 3, lwithin = 16 * lhalf + 4 * lq;
+  int offA[2], offX[TAPS];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) offA[i] = (8 * g + lj) * 128 + (((wm * 2 + i) ^ lj) << 5) + lwithin;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) offX[t] = (8 * g + t + lj) * 128 + ((wn ^ ((t + lj) & 3)) << 5) + lwithin;
+  auto tr8 = [&](const bf16_t* tile, int off, int ks) {     // rows ks * 16 + {0..3} and + {4..7} (+ the lane part in off)
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + off + ks * 16 * 128));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + off + ks * 16 * 128 + 4 * 128));
+    s16x8v r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+  };
+  constexpr int NKS = WG_P / 16;
+  if (!(p.debug & 16)) __builtin_amdgcn_s_setprio(2);   // the loader wave of this SIMD takes the issue slots the MFMA waves leave (debug 16: equal priority)
   int buf = 0;
   for (int k = 0; k < count; ++k) {
     asm volatile("" ::: "memory");
@@ -1397,22 +1416,30 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
     asm volatile("" ::: "memory");
     const bf16_t* A = ring + buf * ITEM_EL;
     const bf16_t* Xs = A + A_PIECES * 512;
-    if (!(p.debug & 2))
+    if (!(p.debug & 2)) {
+      bf16x8 a[2][2], bx[2][TAPS];
 #pragma unroll
-    for (int ks = 0; ks < WG_P / 16; ++ks) {
-      const int kA = ks * 16 + 8 * g, kB = kA + 4;
-      bf16x8 a[2];
+      for (int i = 0; i < 2; ++i) a[0][i] = tr8(A, offA[i], 0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = gather8_swz(A, kA, kB, wm * 64 + i * 32, lane);
+      for (int t = 0; t < TAPS; ++t) bx[0][t] = tr8(Xs, offX[t], 0);
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        const bf16x8 bx = gather8_swz(Xs, kA + t, kB + t, wn * 32, lane);
+      for (int ks = 0; ks < NKS; ++ks) {
+        if (ks + 1 < NKS) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) dx_mma(acc[t][i], a[i], bx);
+          for (int i = 0; i < 2; ++i) a[(ks + 1) & 1][i] = tr8(A, offA[i], ks + 1);
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t) bx[(ks + 1) & 1][t] = tr8(Xs, offX[t], ks + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) dx_mma(acc[t][i], a[ks & 1][i], bx[ks & 1][t]);
       }
     }
     buf = buf + 1 == WGR_RING ? 0 : buf + 1;
   }
+  __builtin_amdgcn_s_setprio(0);
   if (p.debug & 1) return;
   if (p.ws) {
     float* out = p.ws + ((size_t)split * ntiles + tile) * (TAPS * 2 * 16 * WG_THREADS);
