@@ -284,3 +284,27 @@ def test_planned_conv_ln_and_lnbwd_match_unplanned(film):
     assert float((r[1][0] * ~valid).abs().max()) == 0. and float((r[1][1] * ~valid).abs().max()) == 0.
     for k in (2, 3) + ((4,) if film else ()):
         assert float((r[0][k] - r[1][k]).abs().max()) <= 1e-4 * float(r[0][k].abs().max()) + 1e-5, k
+
+
+@pytest.mark.parametrize('B,N,cin', [(1, 5, 256), (300, 40, 128), (70, 130, 1024)])
+def test_planned_conv_ln_edge_batches(B, N, cin):
+    ''' balanced-tile launches on batches far from the training shape: a single 5-row utterance, more utterances than
+        tiles per pass (B > 256, several 64-utterance rounds of the padding-fill scan), zero-length utterances '''
+    from daft_exprt import ops
+    g = torch.Generator().manual_seed(B * 7 + N)
+    lens = torch.randint(0, N + 1, (B,), generator=g)
+    lens[0] = N
+    lens = lens.to(DEV)
+    n_idx = torch.arange(N, device=DEV)[None, :, None]
+    valid = n_idx < lens[:, None, None]
+    x = (torch.randn(B, N, cin, generator=g).to(DEV) * (n_idx < lens[:, None, None] + 2)).to(torch.bfloat16)
+    wp = ops.pack_conv_weight((torch.randn(128, cin, 3, generator=g) / (cin * 3) ** 0.5).to(DEV), torch.bfloat16)
+    bias, gamma, beta = (torch.randn(128, generator=g).to(DEV) for _ in range(3))
+    res = torch.randn(B, N, 128, generator=g).to(DEV) * valid
+    plan = ops.conv_tile_plan(lens, N)
+    a = ops.conv1d_ln(x, wp, bias, res, gamma, beta, lens, save=True, p_pre=0.2, seed_pre=3, lp_copy=True)
+    b_ = ops.conv1d_ln(x, wp, bias, res, gamma, beta, lens, save=True, p_pre=0.2, seed_pre=3, lp_copy=True, plan=plan)
+    for u, v, name in zip(a, b_, ('y', 'y_lp', 's', 'mean', 'rstd')):
+        m = valid if u.dim() == 3 else valid.reshape(-1)
+        assert torch.equal(u.float() * m, v.float() * m), name
+        assert float((v.float() * ~m).abs().max()) == 0., name
