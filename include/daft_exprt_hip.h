@@ -83,7 +83,8 @@ int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void* w_packed, 
                     float* dfilm, long lddf, int B, int N, int Cin, int taps, float p_pre, uint64_t seed_pre,
                     const int* plan, int plan_tiles, void* stream);
 
-/* Balanced position tiles for dx_conv1d_ln / dx_conv1d_lnbwd (optional `plan`; bf16 operands, taps = 3, Cin % 32 == 0).
+/* Balanced position tiles for dx_conv1d_ln / dx_conv1d_lnbwd (optional `plan`; bf16 operands, Cin % 32 == 0, taps = 3 --
+ * dx_conv1d_lnbwd also taps = 1).
  * The k = 3 GEMMs into the 128-channel stream are bound by what a compute unit fetches from L2, and every workgroup
  * fetches the whole weight slice whatever the height of its tile; a ragged batch (model.py:21-23 masks, lengths differ
  * 10x inside a batch) cut into fixed 128-row tiles ends a few tiles above a multiple of the 256 CUs.  The plan cuts

@@ -284,6 +284,20 @@ def test_planned_conv_ln_and_lnbwd_match_unplanned(film):
     assert float((r[1][0] * ~valid).abs().max()) == 0. and float((r[1][1] * ~valid).abs().max()) == 0.
     for k in (2, 3) + ((4,) if film else ()):
         assert float((r[0][k] - r[1][k]).abs().max()) <= 1e-4 * float(r[0][k].abs().max()) + 1e-5, k
+    # k = 1 backward variant (QKV data gradient, K = 384) on the same plan
+    xq = (torch.randn(B, N, 384, generator=g).to(DEV) * (n_idx < lens[:, None, None] + 2)).to(torch.bfloat16)
+    wq = ops.pack_conv_weight((torch.randn(384, 128, generator=g) / 384 ** 0.5).to(DEV), torch.bfloat16, transpose_flip=True)
+    r = []
+    for pl in (None, plan):
+        y = gin.clone()
+        dg, db = torch.zeros(128, device=DEV), torch.zeros(128, device=DEV)
+        df = torch.zeros(B, 256, device=DEV) if film else None
+        dx = ops.conv1d_lnbwd(xq, wq, y, s_in, mean, rstd, gamma, beta, lens, dg, db, film=fl, dfilm=df, p_pre=0.1, seed_pre=5, plan=pl)
+        r.append((y, dx.float(), dg, db, df))
+    assert torch.equal(r[0][0] * valid, r[1][0] * valid) and torch.equal(r[0][1] * valid, r[1][1] * valid)
+    assert float((r[1][0] * ~valid).abs().max()) == 0. and float((r[1][1] * ~valid).abs().max()) == 0.
+    for k in (2, 3) + ((4,) if film else ()):
+        assert float((r[0][k] - r[1][k]).abs().max()) <= 1e-4 * float(r[0][k].abs().max()) + 1e-5, k
 
 
 @pytest.mark.parametrize('B,N,cin', [(1, 5, 256), (300, 40, 128), (70, 130, 1024)])

@@ -980,6 +980,15 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
         DX_LAUNCH_CHECK();
         return DX_OK;
       }
+      if constexpr (LN == 2) {
+        if (a.plan && taps == 1) {   // k = 1 data gradient + LayerNorm backward (QKV projection, K = 384) on the same tiles
+          dim3 gridp((unsigned)a.plan_tiles);
+          if (film) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 4, 32, LN, 3>), gridp, dim3(2 * NTHREADS), 0, s, a);
+          else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 4, 32, LNB, 3>), gridp, dim3(2 * NTHREADS), 0, s, a);
+          DX_LAUNCH_CHECK();
+          return DX_OK;
+        }
+      }
       if (ring_ok(a) && taps == 3) {
         const long pt2 = (long)dx_cdiv(a.N, 128) * B;
         dim3 grid2((unsigned)(((pt2 + 7) / 8) * 8));
@@ -1748,11 +1757,11 @@ extern "C" int dx_conv_tile_plan(const int64_t* lengths, int B, int N, int n_til
 
 // plan validity for the LayerNorm-fused GEMMs: bf16 operands, k = 3, whole 32-channel chunks
 static int plan_check(const char* who, const int* plan, int plan_tiles, const int64_t* lengths, int x_dtype, int w_dtype, long ldx, int Cin,
-                      int taps, int B, int N) {
+                      int taps, int B, int N, bool lnbwd = false) {
   if (!plan) return DX_OK;
   DX_REQUIRE(lengths, DX_ERR_ARG, "%s: a tile plan needs lengths", who);
-  DX_REQUIRE(x_dtype == DX_BF16 && w_dtype == DX_BF16 && taps == 3 && Cin % 32 == 0 && Cin <= DX_ZERO_PAGE_EL && ldx % 8 == 0, DX_ERR_UNSUPPORTED,
-             "%s: tile plans are for bf16 operands, taps = 3, Cin %% 32 == 0 (got x=%d w=%d taps=%d Cin=%d)", who, x_dtype, w_dtype, taps, Cin);
+  DX_REQUIRE(x_dtype == DX_BF16 && w_dtype == DX_BF16 && (taps == 3 || (taps == 1 && lnbwd)) && Cin % 32 == 0 && Cin <= DX_ZERO_PAGE_EL && ldx % 8 == 0, DX_ERR_UNSUPPORTED,
+             "%s: tile plans are for bf16 operands, taps = 3 (or 1 for the backward variant), Cin %% 32 == 0 (got x=%d w=%d taps=%d Cin=%d)", who, x_dtype, w_dtype, taps, Cin);
   DX_REQUIRE(plan_tiles >= dx_conv_tile_plan_size(B, N), DX_ERR_ARG, "%s: plan_tiles=%d < dx_conv_tile_plan_size(B, N)=%d", who, plan_tiles,
              dx_conv_tile_plan_size(B, N));
   return DX_OK;
@@ -1786,7 +1795,7 @@ extern "C" int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void*
                                const float* beta, const float* film, long ldf, const int64_t* lengths, void* dx_pre_lp,
                                float* dgamma, float* dbeta, float* dfilm, long lddf, int B, int N, int Cin, int taps,
                                float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, void* stream) {
-  if (int rc = plan_check("dx_conv1d_lnbwd", plan, plan_tiles, lengths, x_dtype, w_dtype, ldx, Cin, taps, B, N)) return rc;
+  if (int rc = plan_check("dx_conv1d_lnbwd", plan, plan_tiles, lengths, x_dtype, w_dtype, ldx, Cin, taps, B, N, true)) return rc;
   DX_REQUIRE(x && w_packed && y_inout && s_in && mean && rstd && gamma && beta && lengths && dx_pre_lp && dgamma && dbeta,
              DX_ERR_ARG, "dx_conv1d_lnbwd: null pointer");
   DX_REQUIRE((film == nullptr) == (dfilm == nullptr), DX_ERR_ARG, "dx_conv1d_lnbwd: film and dfilm come together");

@@ -113,7 +113,7 @@ def conv1d_lnbwd(x, w_packed, y_inout, s_in, mean, rstd, gamma, beta, lengths, d
         H.check(H.lib().dx_conv1d_lnbwd(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(y_inout), H.ptr(s_in),
                                         H.ptr(mean), H.ptr(rstd), H.ptr(gamma), H.ptr(beta), H.ptr(film), ldf, H.ptr(lengths),
                                         H.ptr(dx_lp), H.ptr(dgamma), H.ptr(dbeta), H.ptr(dfilm), lddf, B, N, Cin, taps,
-                                        float(p_pre), int(seed_pre), *_plan_args(plan, x, w_packed, B, N), H.stream()))
+                                        float(p_pre), int(seed_pre), *_plan_args(plan, x, w_packed, B, N, k1_ok=True), H.stream()))
     return dx_lp
 
 
@@ -127,9 +127,11 @@ def conv_tile_plan(lengths, N):
     return table, B, N
 
 
-def _plan_args(plan, x, w_packed, B, N):
+def _plan_args(plan, x, w_packed, B, N, k1_ok=False):
     ''' (table pointer, n_tiles) when the plan applies to this GEMM (bf16 operands, k = 3, same batch geometry) '''
-    if plan is None or x.dtype != torch.bfloat16 or w_packed.dtype != torch.bfloat16 or w_packed.shape[0] != 3 or x.shape[2] % 32:
+    taps = w_packed.shape[0]
+    if plan is None or x.dtype != torch.bfloat16 or w_packed.dtype != torch.bfloat16 or x.shape[2] % 32 or \
+            not (taps == 3 or (taps == 1 and k1_ok and x.shape[2] >= 256)):
         return None, 0
     table, pb, pn = plan
     assert (pb, pn) == (B, N), 'tile plan built for another batch geometry'
