@@ -146,7 +146,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
   constexpr int STG_LD = BN + 4;
   // ring image of one K chunk: activation rows rounded up to whole 16-row DMA pieces, then the taps x 128 weight rows
   constexpr int AR16 = (AROWS + 15) & ~15, STAGE_EL = (AR16 + TAPS * BN) * 32;
-  constexpr int OPER_BYTES = RING ? RING * STAGE_EL * 2 : (AROWS + TAPS * BN) * LDS_K * (int)sizeof(TC), STG_BYTES = 64 * STG_LD * 4;
+  constexpr int OPER_BYTES = RING ? RING * STAGE_EL * 2 : (AROWS + TAPS * BN) * LDS_K * (int)sizeof(TC), STG_BYTES = 64 * STG_LD * 4 * (RING > 0 && MI == 4 ? 2 : 1);
   typedef typename Vec8<TC>::type frag_t;
   typedef typename VecN<TA, 8>::type raw_t;
   __shared__ __attribute__((aligned(16))) char smem[OPER_BYTES > STG_BYTES ? OPER_BYTES : STG_BYTES];
@@ -357,10 +357,12 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
-      return;                                                     // the epilogue belongs to the MFMA waves
+      if (!PLAN) return;                                          // fixed tiles: the epilogue belongs to the MFMA waves
     }
     // MFMA waves.  PLAN: wave (wm, wn) owns the 32-row blocks wm, wm + 2, ... (interleaved, so a short tile still
-    // spreads over both wave rows) and skips the blocks past the tile's height.
+    // spreads over both wave rows) and skips the blocks past the tile's height; the loader waves come back for the
+    // epilogue as a second 256-thread team (one 64-row slab each per round).
+    if (wave < 4) {
     auto row_of = [&](int i) { return PLAN ? (2 * i + wm) * 32 : wm * 32 * MI + i * 32; };
     const int nact = PLAN ? __builtin_amdgcn_readfirstlane((((h + 31) >> 5) - wm + 1) >> 1) : MI;
     auto mainloop = [&](auto na_tag) {
@@ -402,6 +404,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
     else if (MI > 2 && nact == 2) mainloop(std::integral_constant<int, (MI > 2 ? 2 : MI)>{});
     else if (MI > 1 && nact == 1) mainloop(std::integral_constant<int, 1>{});
     else mainloop(std::integral_constant<int, 0>{});
+    }
     __syncthreads();                                 // every MFMA wave is done with the ring: the epilogue stages through it
   } else {
   raw_t ra[A_PT];
@@ -479,20 +482,30 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
 #pragma unroll
     for (int e = 0; e < 8; ++e) csum[q][e] = 0.f;
   if (PLAN && (p.flags & 1024)) return;
+  // PLAN: two teams of 256 threads (MFMA waves / loader waves) take one 64-row slab each per round
+  constexpr int ETEAMS = PLAN ? 2 : 1;
+  const int team = PLAN ? tid >> 8 : 0, etid = PLAN ? tid & 255 : tid;
+  float* const mystage = stage + team * (64 * STG_LD);
   if (vec_out) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      if (PLAN && i * 64 >= h) break;                             // workgroup-uniform: the barriers below stay matched
-      // phase 1: bias + ReLU in the MFMA layout, accumulators -> LDS stage (64 rows x 128 channels, fp32)
+    for (int ip = 0; ip < MI / ETEAMS; ++ip) {
+      if (PLAN && ip * 64 * ETEAMS >= h) break;                   // workgroup-uniform: the barriers below stay matched
+      const int i = ip * ETEAMS + team;                           // this team's slab
+      // phase 1: bias + ReLU in the MFMA layout, accumulators -> LDS stage (64 rows x 128 channels, fp32, one per team)
+      if (!PLAN || tid < NTHREADS) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int cl = wn * 64 + j * 32 + l31, co = co0 + cl;
-        const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+        for (int sl = 0; sl < ETEAMS; ++sl) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[i][j][r] + bv;
-          if (relu) v = fmaxf(v, 0.f);
-          stage[(wm * 32 + dx_acc_row(r, g)) * STG_LD + cl] = v;
+          for (int j = 0; j < 2; ++j) {
+            const int cl = wn * 64 + j * 32 + l31, co = co0 + cl;
+            const float bv = (p.bias && co < Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float v = acc[ip * ETEAMS + sl][j][r] + bv;
+              if (relu) v = fmaxf(v, 0.f);
+              stage[sl * (64 * STG_LD) + (wm * 32 + dx_acc_row(r, g)) * STG_LD + cl] = v;
+            }
+          }
         }
       }
       // LayerNorm epilogues: the global inputs of all four passes are requested BEFORE the barrier (one round trip per
@@ -504,9 +517,9 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
       if (LN != 0 && PFB) {
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
-          const int sr = (tid >> 4) + pass * 16;
+          const int sr = (etid >> 4) + pass * 16;
           const int trow = PLAN ? i * 64 + sr : (sr >> 5) * 32 * MI + i * 32 + (sr & 31);
-          const int n = n0 + trow, cl = (tid & 15) * 8;
+          const int n = n0 + trow, cl = (etid & 15) * 8;
           if (n < N && trow < h) {
             const size_t rowg = (size_t)b * N + n, offl = rowg * BN + cl;
             if (LN == 2) {
@@ -524,13 +537,13 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
       // phase 2: whole 16-byte row segments: gate, mask, accumulate, store
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
-        const int sr = (tid >> 4) + pass * 16;                     // stage row 0..63
+        const int sr = (etid >> 4) + pass * 16;                    // stage row 0..63
         const int trow = PLAN ? i * 64 + sr : (sr >> 5) * 32 * MI + i * 32 + (sr & 31);   // row inside the tile
-        const int n = n0 + trow, cl = (tid & 15) * 8, co = co0 + cl;
+        const int n = n0 + trow, cl = (etid & 15) * 8, co = co0 + cl;
         if (n < N && co < Cout && trow < h) {
           float v[8];
-          const f32x4 lo = *reinterpret_cast<const f32x4*>(&stage[sr * STG_LD + cl]);
-          const f32x4 hi = *reinterpret_cast<const f32x4*>(&stage[sr * STG_LD + cl + 4]);
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(&mystage[sr * STG_LD + cl]);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(&mystage[sr * STG_LD + cl + 4]);
           v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
           if (LN == 2) {        // fused LayerNorm BACKWARD: v + residual gradient = dL/d(LN output) of this row
             const size_t rowg = (size_t)b * N + n, offl = rowg * BN + cl;
@@ -642,15 +655,16 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
     }
     if (LN == 2) {   // column sums: 16 row-threads per channel segment -> LDS -> one atomic per channel per workgroup
       constexpr int nq = NCS;
+      constexpr int RG = 16 * ETEAMS;                               // row groups (16 threads each) that hold partial sums
       for (int q = 0; q < nq; ++q)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) stage[(q * 16 + (tid >> 4)) * BN + (tid & 15) * 8 + e] = csum[q][e];
+        for (int e = 0; e < 8; ++e) stage[(q * RG + (tid >> 4)) * BN + (tid & 15) * 8 + e] = csum[q][e];
       __syncthreads();
-      for (int idx = tid; idx < nq * BN; idx += NTHREADS) {
+      for (int idx = tid; idx < nq * BN; idx += NTHREADS * ETEAMS) {
         const int q = idx / BN, c = idx - q * BN;
         float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t += stage[(q * 16 + r) * BN + c];
+        for (int r = 0; r < RG; ++r) t += stage[(q * RG + r) * BN + c];
         if (p.flags & 512) continue;
         if (q == 0) atomicAdd(p.ln.dgamma + c, t);
         else if (q == 1) atomicAdd(p.ln.dbeta + c, t);
