@@ -46,8 +46,10 @@ def test_train_from_feature_files_then_checkpoint_and_synthesis(golden_dir, tmp_
     model = model.cuda(0)
     sentences = [[['HH', 'AH0', 'L', 'OW1'], ' ', ['W', 'ER1', 'L', 'D'], '.', '~'], [['T', 'EH1', 'S', 'T'], '~']]
     refs = [(fx['item0_frames_energy'], fx['item0_frames_pitch'], fx['item0_mel']), (fx['item1_frames_energy'], fx['item1_frames_pitch'], fx['item1_mel'])]
-    preds, rtf = generate_mel_specs(model, sentences, ['a', 'b'], [0, 3], refs, os.path.join(out, 'synth'), hp, batch_size=2, get_time_perf=True)
-    assert set(preds) == {'a', 'b'} and rtf > 0
-    for name, p in preds.items():
-        assert p['mel_spec'].shape[0] == 80 and p['mel_spec'].shape[1] == int(p['duration_int'].sum()) and np.isfinite(p['mel_spec']).all()
+    preds = generate_mel_specs(model, sentences, ['a', 'b'], [0, 3], refs, os.path.join(out, 'synth'), hp, batch_size=2, get_time_perf=True)
+    from daft_exprt.generate import LAST_TIME_PERF
+    assert set(preds) == {'a_spk_0_ref_mem0', 'b_spk_3_ref_mem1'} and LAST_TIME_PERF['rtf'] > 0
+    for name, (duration, duration_int, energy, pitch, mel_spec, alignment) in preds.items():
+        assert mel_spec.shape[0] == 80 and mel_spec.shape[1] == int(duration_int.sum()) and np.isfinite(mel_spec).all()
+        assert alignment.shape == (len(duration), mel_spec.shape[1])
         assert os.path.isfile(os.path.join(out, 'synth', f'{name}.npz'))

@@ -12,7 +12,7 @@ from daft_exprt.hparams import HyperParams
 from daft_exprt.loss import DaftExprtLoss
 from daft_exprt.model import DaftExprt, param_table
 from daft_exprt.train import update_learning_rate
-from tests.util import make_hparams, INPUT_NAMES
+from tests.util import make_hparams, INPUT_NAMES, COLLATE_NAMES, load_driver_fixture
 
 
 def test_hparams_defaults_and_derived_fields(tmp_path):
@@ -54,6 +54,24 @@ def test_collate_contract_matches_reference(golden_dir):
         want = fx[f'in_{name}']
         assert got.numpy().dtype == want.dtype and np.array_equal(got.numpy(), want), name
     assert list(batch[11]) == list(fx['collate_dirs']) and list(batch[12]) == list(fx['collate_files'])
+
+
+@pytest.mark.parametrize('transform', ['add', 'multiply'])
+def test_inference_collate_replays_the_reference_bit_exact(golden_dir, transform, tmp_path):
+    ''' raw driver inputs (nested sentences, per-symbol factor lists, reference .npz files) -> the product's
+        `generate.collate_tensors` must give exactly what the reference's gave (`generate.py:140-239`), paths or triples '''
+    import json
+    from daft_exprt.generate import collate_tensors
+    hp = make_hparams()
+    for ref_dir in (None, str(tmp_path)):
+        sentences, dur_f, en_f, pi_f, refs, spk, names, fx = load_driver_fixture(golden_dir, transform, ref_dir)
+        col = collate_tensors(sentences, dur_f, en_f, pi_f, transform, refs, spk, list(names), hp)
+        for nm, got in zip(COLLATE_NAMES, col[:-1]):
+            want = fx[f'{transform}_col_{nm}']
+            assert got.numpy().dtype == want.dtype and np.array_equal(got.numpy(), want), nm
+        assert list(col[-1]) == json.loads(str(fx[f'{transform}_col_file_names_json']))
+    with pytest.raises(AssertionError):
+        collate_tensors(sentences, [[1.]] + dur_f[1:], en_f, pi_f, transform, refs, spk, list(names), hp)   # wrong factor count
 
 
 def test_synthetic_batches_follow_the_collate_invariants():

@@ -151,6 +151,22 @@ def test_inference(golden_dir):
         _close(weights, fx[f'{transform}_out_weights'], what='weights')
 
 
+@pytest.mark.parametrize('transform', ['add', 'multiply'])
+def test_collate_inference_replays_the_reference(golden_dir, transform):
+    ''' oracle.collate_inference (symbol-id sequences in, padded tensors out) against the reference's collate_tensors on
+        the raw driver inputs of tests/golden/inference_collate.npz '''
+    import json
+    from tests.util import COLLATE_NAMES, load_driver_fixture
+    hp = make_hparams()
+    sentences, dur_f, en_f, pi_f, refs, spk, names, fx = load_driver_fixture(golden_dir, transform)
+    ids = [[hp.symbols.index(p) for it in s for p in (it if isinstance(it, list) else [it])] for s in sentences]
+    col = O.collate_inference(ids, dur_f, en_f, pi_f, transform, refs, spk, names)
+    for nm, got in zip(COLLATE_NAMES, col[:-1]):
+        want = fx[f'{transform}_col_{nm}']
+        assert got.numpy().dtype == want.dtype and np.array_equal(got.numpy(), want), nm
+    assert list(col[-1]) == json.loads(str(fx[f'{transform}_col_file_names_json']))
+
+
 def test_duration_to_integer_kats(golden_dir):
     fx = np.load(os.path.join(golden_dir, 'duration_to_integer.npz'))
     durs, d_off, ints, i_off = fx['durs'], fx['durs_off'], fx['ints'], fx['ints_off']

@@ -27,3 +27,30 @@ def no_dropout(hp):
 def load_inputs(fx, device=None):
     out = tuple(torch.from_numpy(np.asarray(fx[f'in_{n}'])) for n in INPUT_NAMES)
     return tuple(t.to(device) for t in out) if device is not None else out
+
+
+def load_driver_fixture(golden_dir, transform, ref_dir=None):
+    ''' RAW inputs of the reference's inference driver from tests/golden/inference_collate.npz (tools/gen_goldens.py, C2):
+        (sentences, dur_factors, energy_factors, pitch_factors, refs, speaker_ids, file_names, fx).  refs are
+        (energy, pitch, mel_spec) triples, or -- with ref_dir -- `.npz` paths written there under the reference's basenames. '''
+    import json
+    import os
+    fx = np.load(os.path.join(golden_dir, 'inference_collate.npz'))
+    sentences = json.loads(str(fx['sentences_json']))
+    factors = json.loads(str(fx[f'{transform}_factors_json']))
+    names = json.loads(str(fx['file_names_json']))
+    base = json.loads(str(fx['ref_basenames_json']))
+    refs = []
+    for i in range(int(fx['n_sentences'])):
+        triple = (fx[f'ref{i}_energy'], fx[f'ref{i}_pitch'], fx[f'ref{i}_mel_spec'])
+        if ref_dir is not None:
+            path = os.path.join(ref_dir, base[i])
+            np.savez(path, energy=triple[0], pitch=triple[1], mel_spec=triple[2])
+            refs.append(path)
+        else:
+            refs.append(triple)
+    return sentences, factors['dur'], factors['energy'], factors['pitch'], refs, fx['speaker_ids'].tolist(), names, fx
+
+
+COLLATE_NAMES = ['symbols', 'dur_factors', 'energy_factors', 'pitch_factors', 'input_lengths', 'energy_refs', 'pitch_refs',
+                 'mel_spec_refs', 'ref_lengths', 'speaker_ids']

@@ -263,6 +263,68 @@ def main():
     fx['stats_pitch_std'] = np.array([hp.stats[f'spk {i}']['pitch']['std'] for i in range(11)])
     np.savez_compressed(os.path.join(OUT, 'inference.npz'), **fx)
 
+    # ------------------------------------------------------------------ C2. inference collate + driver contract (generate.py:140-437)
+    # RAW driver inputs (nested sentences, per-symbol factor lists, reference .npz contents, speaker ids, file names) next to
+    # what the reference's collate_tensors / generate_mel_specs make of them: pins the product's collate_tensors, the oracle's
+    # collate_inference, the `_spk_<id>_ref_<name>` file naming, the list-of-6 predictions and the .npz contents.
+    import json
+    from daft_exprt.generate import generate_mel_specs
+    rng = np.random.RandomState(4321)       # own stream: sections C and D above/below keep their draws
+    c2 = {'n_sentences': np.array(5)}
+    sentences, refs, spk_ids, names = [], [], [], []
+    ref_dir = os.path.join(tmp, 'refs2')
+    os.makedirs(ref_dir, exist_ok=True)
+    for i, (L, Tref) in enumerate(zip([9, 17, 17, 5, 12], [40, 61, 33, 61, 20])):    # ties in L and in T_ref
+        phones = [hp.symbols[int(s)] for s in rng.randint(7, 76, size=L - 3)]
+        cut = max(1, (L - 3) // 3)
+        sentences.append([phones[:cut], ' ', phones[cut:2 * cut], ',', phones[2 * cut:], '~'] if L - 3 - 2 * cut > 0
+                         else [phones[:cut], ' ', phones[cut:], '.', '~'])
+        ref = os.path.join(ref_dir, f'prosody_ref_{i}.npz')
+        arrs = dict(energy=rng.uniform(0, 3, size=Tref).astype(np.float32),
+                    pitch=(rng.randn(Tref) * (rng.rand(Tref) > 0.3)).astype(np.float32),
+                    mel_spec=np.clip(rng.randn(80, Tref) * 1.2 - 1.0, np.log(1e-5), 2.).astype(np.float32))
+        np.savez(ref, **arrs)
+        for k, v in arrs.items():
+            c2[f'ref{i}_{k}'] = v
+        refs.append(ref)
+        spk_ids.append(int(rng.randint(0, 11)))
+        names.append(f'sent{i}')
+    n_sym = []
+    for sent in sentences:
+        n_sym.append(sum(len(it) if isinstance(it, list) else 1 for it in sent))
+    c2['sentences_json'] = np.array(json.dumps(sentences))
+    c2['ref_basenames_json'] = np.array(json.dumps([os.path.basename(r) for r in refs]))
+    c2['speaker_ids'] = np.array(spk_ids)
+    c2['file_names_json'] = np.array(json.dumps(names))
+    for transform in ('add', 'multiply'):
+        dur_factors = [None if i % 2 == 0 else [float(np.float32(v)) for v in rng.uniform(0.8, 1.3, size=n)] for i, n in enumerate(n_sym)]
+        energy_factors = [[float(np.float32(v)) for v in rng.uniform(0.5, 1.5, size=n)] if i in (0, 3) else None for i, n in enumerate(n_sym)]
+        lo, hi = (-30, 50) if transform == 'add' else (-1.5, 1.0)
+        pitch_factors = [[float(np.float32(v)) for v in rng.uniform(lo, hi, size=n)] if i in (1, 4) else None for i, n in enumerate(n_sym)]
+        c2[f'{transform}_factors_json'] = np.array(json.dumps({'dur': dur_factors, 'energy': energy_factors, 'pitch': pitch_factors}))
+        col = collate_tensors(sentences, dur_factors, energy_factors, pitch_factors, transform, refs, spk_ids, list(names), hp)
+        for nm, t in zip(['symbols', 'dur_factors', 'energy_factors', 'pitch_factors', 'input_lengths', 'energy_refs',
+                          'pitch_refs', 'mel_spec_refs', 'ref_lengths', 'speaker_ids'], col[:-1]):
+            c2[f'{transform}_col_{nm}'] = np_(t)
+        c2[f'{transform}_col_file_names_json'] = np.array(json.dumps(list(col[-1])))
+        # the whole driver: 5 sentences in chunks of 2 (last chunk of 1), reference weights from the closed-form fill
+        out_dir = os.path.join(tmp, f'gen_{transform}')
+        drv_names = list(names)
+        preds = generate_mel_specs(model, sentences, drv_names, spk_ids, refs, out_dir, hp, dur_factors=dur_factors,
+                                   energy_factors=energy_factors, pitch_factors=[transform.upper(), pitch_factors], batch_size=2,
+                                   n_jobs=1, use_griffin_lim=False, get_time_perf=True)
+        c2[f'{transform}_drv_keys_json'] = np.array(json.dumps(list(preds.keys())))
+        c2[f'{transform}_drv_names_after_json'] = np.array(json.dumps(drv_names))     # the caller's list after the call
+        files = sorted(os.listdir(out_dir))
+        c2[f'{transform}_drv_files_json'] = np.array(json.dumps(files))
+        c2[f'{transform}_drv_npz_keys_json'] = np.array(json.dumps(sorted(np.load(os.path.join(out_dir, files[0])).files)))
+        for k, (key, vals) in enumerate(preds.items()):
+            for nm, v in zip(['duration', 'duration_int', 'energy', 'pitch', 'mel_spec', 'alignment'], vals):
+                c2[f'{transform}_drv{k}_{nm}'] = np.asarray(v)
+            assert np.array_equal(np.load(os.path.join(out_dir, f'{key}.npz'))['mel_spec'], vals[4])
+        print('driver', transform, list(preds.keys()), 'names after:', drv_names)
+    np.savez_compressed(os.path.join(OUT, 'inference_collate.npz'), **c2)
+
     # ------------------------------------------------------------------ D. duration_to_integer KATs
     rng = np.random.RandomState(99)
     flat_in, off_in, flat_out, off_out = [], [0], [], [0]

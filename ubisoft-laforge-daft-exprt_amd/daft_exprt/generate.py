@@ -73,68 +73,94 @@ def collate_tensors(batch_sentences, batch_dur_factors, batch_energy_factors, ba
         ref_lengths, speaker_ids, file_names
 
 
+def _ref_name(ref, idx):
+    ''' `_ref_<basename without .npz>` part of the output file name (`generate.py:250-251`); references handed over as
+        already-loaded triples (an extension, the reference only takes paths) are named by their position '''
+    if isinstance(ref, (str, os.PathLike)):
+        return os.path.basename(str(ref)).replace('.npz', '')
+    return f'mem{idx}'
+
+
 def generate_batch_mel_specs(model, batch_sentences, batch_refs, batch_dur_factors, batch_energy_factors, batch_pitch_factors,
                              pitch_transform, batch_speaker_ids, batch_file_names, output_dir, hparams, n_jobs=1,
-                             use_griffin_lim=False, get_time_perf=False):
-    ''' `generate.py:242-317`: returns {file_name: prediction dict}; writes `<output_dir>/<file_name>.npz` when output_dir '''
+                             use_griffin_lim=True):
+    ''' `generate.py:242-317`, same contract: every file name gets the `_spk_<id>_ref_<reference>` suffix IN PLACE
+        (the caller's list is updated like the reference does, 248-253), one `model.inference` call on the collated
+        batch, `<output_dir>/<file_name>.npz` holding `mel_spec` (298), and the return value
+        `{file_name: [duration, duration_int, energy, pitch, mel_spec, alignment]}` cropped per item (300).
+        Plots / Griffin-Lim preview audio (303-307) are outside the accelerated path: `use_griffin_lim` only warns. '''
+    for idx, file_name in enumerate(batch_file_names):
+        file_name += f'_spk_{batch_speaker_ids[idx]}'
+        file_name += f'_ref_{_ref_name(batch_refs[idx], idx)}'
+        batch_file_names[idx] = file_name
+        _logger.info(f'Generating "{batch_sentences[idx]}" as "{file_name}"')
     col = collate_tensors(batch_sentences, batch_dur_factors, batch_energy_factors, batch_pitch_factors, pitch_transform,
                           batch_refs, batch_speaker_ids, batch_file_names, hparams)
     file_names = col[-1]
-    dev = model.flat_parameters().device
-    inputs = tuple(t.to(dev, non_blocking=True) for t in col[:-1])
-    if get_time_perf:
-        torch.cuda.synchronize()
-        start = time.time()
-    inference = model.module.inference if hasattr(model, 'module') else model.inference
+    gpu = next(model.parameters()).device
+    inputs = tuple(t.to(gpu, non_blocking=True) for t in col[:-1])
+    inference = model.inference if hasattr(model, 'inference') else model.module.inference   # DDP-wrapped callers (270-278)
     encoder_preds, decoder_preds, alignments = inference(inputs, pitch_transform, hparams)
-    if get_time_perf:
-        torch.cuda.synchronize()
-        elapsed = time.time() - start
     duration, duration_int, energy, pitch, input_lengths = (t.detach().cpu().numpy() for t in encoder_preds)
     mel_spec, output_lengths = (t.detach().cpu().numpy() for t in decoder_preds)
     weights = alignments.detach().cpu().numpy()
     predictions = {}
-    for i, name in enumerate(file_names):
+    for i in range(mel_spec.shape[0]):
         l, t = int(input_lengths[i]), int(output_lengths[i])
-        predictions[name] = {'duration': duration[i, :l], 'duration_int': duration_int[i, :l], 'energy': energy[i, :l],
-                             'pitch': pitch[i, :l], 'mel_spec': mel_spec[i, :, :t], 'alignments': weights[i, :l, :t]}
-        if output_dir:
-            os.makedirs(output_dir, exist_ok=True)
-            np.savez(os.path.join(output_dir, f'{name}.npz'), **predictions[name])
+        name = file_names[i]
+        np.savez(os.path.join(output_dir, f'{name}.npz'), mel_spec=mel_spec[i, :, :t])
+        predictions[f'{name}'] = [duration[i, :l], duration_int[i, :l], energy[i, :l], pitch[i, :l], mel_spec[i, :, :t],
+                                  weights[i, :l, :t]]
     if use_griffin_lim:
-        _logger.warning('Griffin-Lim preview audio is outside the accelerated path; use a neural vocoder on the saved mel-specs')
-    if get_time_perf:
-        return predictions, elapsed
+        _logger.warning('Griffin-Lim preview audio / plots are outside the accelerated path; use a vocoder on the saved mel-specs')
     return predictions
+
+
+LAST_TIME_PERF = {}   # filled by generate_mel_specs(get_time_perf=True): what the reference only logs (generate.py:433-435)
 
 
 def generate_mel_specs(model, sentences, file_names, speaker_ids, refs, output_dir, hparams, dur_factors=None,
                        energy_factors=None, pitch_factors=None, batch_size=1, n_jobs=1, use_griffin_lim=False,
                        get_time_perf=False):
-    ''' `generate.py:320-437`: eval mode, no grad, chunks of `batch_size`; real-time factor = audio seconds / wall seconds '''
+    ''' `generate.py:320-437`, same contract: `pitch_factors = [transform, [per-sentence factor lists]]`, the list-length
+        asserts, eval mode + no grad, chunks of `batch_size`, returns the predictions dict only.  With `get_time_perf`
+        the real-time factor is logged exactly like the reference: wall time of the whole per-batch function (collate,
+        H2D, inference, D2H, file writes) against `((n_frames - 1) * hop + n_fft - 2 * (n_fft // 2)) / sr` seconds of
+        audio per sentence (413-435); the numbers are also left in `LAST_TIME_PERF`. '''
     n = len(sentences)
-    dur_factors = dur_factors or [None] * n
-    energy_factors = energy_factors or [None] * n
-    pitch_transform = 'add'
-    if pitch_factors is None:
-        pitch_factors = [None] * n
-    elif isinstance(pitch_factors, (tuple, list)) and len(pitch_factors) == 2 and isinstance(pitch_factors[0], str):
-        pitch_transform, pitch_factors = pitch_factors
+    dur_factors = [None for _ in range(n)] if dur_factors is None else dur_factors
+    energy_factors = [None for _ in range(n)] if energy_factors is None else energy_factors
+    pitch_factors = ['add', [None for _ in range(n)]] if pitch_factors is None else pitch_factors
+    pitch_transform = pitch_factors[0].lower()
+    pitch_factors = pitch_factors[1]
+    assert pitch_transform in ['add', 'multiply'], _logger.error(f'Pitch transform "{pitch_transform}" is not currently supported')
+    for what, seq in (('filenames', file_names), ('speaker IDs', speaker_ids), ('references', refs),
+                      ('duration factors', dur_factors), ('energy factors', energy_factors), ('pitch factors', pitch_factors)):
+        assert len(seq) == n, _logger.error(f'{len(seq)} {what} but there are {n} sentences to generate')
     model.eval()
-    predictions, total_time, audio_seconds = {}, 0., 0.
+    os.makedirs(output_dir, exist_ok=True)
+    predictions, time_per_batch = {}, []
     with torch.no_grad():
-        idx = list(range(n))
-        for chunk in chunker(idx, batch_size):
-            pick = lambda seq: [seq[i] for i in chunk]
-            out = generate_batch_mel_specs(model, pick(sentences), pick(refs), pick(dur_factors), pick(energy_factors),
-                                           pick(pitch_factors), pitch_transform, pick(speaker_ids), pick(file_names),
-                                           output_dir, hparams, n_jobs, use_griffin_lim, get_time_perf)
-            if get_time_perf:
-                out, elapsed = out
-                total_time += elapsed
-                audio_seconds += sum(p['mel_spec'].shape[1] for p in out.values()) * hparams.hop_length / hparams.sampling_rate
-            predictions.update(out)
+        for chunk in zip(chunker(sentences, batch_size), chunker(refs, batch_size), chunker(dur_factors, batch_size),
+                         chunker(energy_factors, batch_size), chunker(pitch_factors, batch_size),
+                         chunker(speaker_ids, batch_size), chunker(file_names, batch_size)):
+            b_sent, b_refs, b_dur, b_en, b_pi, b_spk, b_names = chunk
+            begin = time.time() if get_time_perf else None
+            predictions.update(generate_batch_mel_specs(model, b_sent, b_refs, b_dur, b_en, b_pi, pitch_transform, b_spk,
+                                                        b_names, output_dir, hparams, n_jobs, use_griffin_lim))
+            time_per_batch += [time.time() - begin] if get_time_perf else []
     if get_time_perf:
-        _logger.info(f'DaftExprt RTF: {audio_seconds / max(total_time, 1e-9):.2f}')
-        return predictions, audio_seconds / max(total_time, 1e-9)
+        durations = []
+        for prediction in predictions.values():
+            nb_frames = prediction[4].shape[1]
+            nb_wav_samples = (nb_frames - 1) * hparams.hop_length + hparams.filter_length
+            if hparams.centered:
+                nb_wav_samples -= 2 * int(hparams.filter_length / 2)
+            durations.append(nb_wav_samples / hparams.sampling_rate)
+        LAST_TIME_PERF.clear()
+        LAST_TIME_PERF.update({'sentences': len(predictions), 'audio_seconds': sum(durations), 'wall_seconds': sum(time_per_batch),
+                               'rtf': sum(durations) / sum(time_per_batch)})
+        _logger.info('')
+        _logger.info(f'{len(predictions)} sentences ({sum(durations):.2f}s) generated in {sum(time_per_batch):.2f}s')
+        _logger.info(f'DaftExprt RTF: {sum(durations) / sum(time_per_batch):.2f}')
     return predictions
