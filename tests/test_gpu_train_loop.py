@@ -13,17 +13,22 @@ pytestmark = pytest.mark.gpu
 from tests.util import make_hparams
 
 
-def test_train_from_feature_files_then_checkpoint_and_synthesis(golden_dir, tmp_path):
+@pytest.mark.parametrize('ddp_flag', [False, True])
+def test_train_from_feature_files_then_checkpoint_and_synthesis(golden_dir, tmp_path, ddp_flag):
+    ''' ddp_flag=True is the default launch path of scripts/training.py on a 1-GPU node: `--multiprocessing_distributed`
+        with world_size 1 -- process group of one rank, DistributedSampler, `module.`-prefixed checkpoints '''
     from daft_exprt.generate import generate_mel_specs
     from daft_exprt.model import DaftExprt
     from daft_exprt.train import train
     fx = np.load(os.path.join(golden_dir, 'data_loader.npz'))
     out = str(tmp_path)
     hp = make_hparams(training_files=os.path.join(golden_dir, 'train_list.txt'), validation_files=os.path.join(golden_dir, 'train_list.txt'),
-                      output_directory=out, batch_size=2, accumulation_steps=2, nb_iterations=2, iters_per_checkpoint=2)
+                      output_directory=out, batch_size=2, accumulation_steps=2, nb_iterations=2, iters_per_checkpoint=2,
+                      iters_check_for_model_improvement=1)
     hp.stats = {f'spk {i}': {'energy': {'mean': float(fx['stats_energy_mean'][i]), 'std': float(fx['stats_energy_std'][i])},
                              'pitch': {'mean': float(fx['stats_pitch_mean'][i]), 'std': float(fx['stats_pitch_std'][i])}} for i in range(11)}
-    hp.rank, hp.world_size, hp.multiprocessing_distributed = 0, 1, False
+    hp.rank, hp.world_size, hp.multiprocessing_distributed = 0, 1, ddp_flag
+    hp.ngpus_per_node, hp.dist_url = 1, 'tcp://127.0.0.1:29517'
     cwd = os.getcwd()
     os.chdir(golden_dir)
     try:
@@ -31,12 +36,21 @@ def test_train_from_feature_files_then_checkpoint_and_synthesis(golden_dir, tmp_
         train(0, hp, os.path.join(out, 'logs', 'train.log'))
     finally:
         os.chdir(cwd)
-    recs = [json.loads(l) for l in open(os.path.join(out, 'logs', 'metrics.jsonl'))]
-    assert [r['iteration'] for r in recs] == [1, 2]
+    assert not torch.distributed.is_initialized()
+    allrecs = [json.loads(l) for l in open(os.path.join(out, 'logs', 'metrics.jsonl'))]
+    recs = [r for r in allrecs if 'DaftExprt.training/loss' in r]
+    vals = [r for r in allrecs if 'DaftExprt.validation/loss' in r]
+    assert [r['iteration'] for r in recs] == [1, 2] and [r['iteration'] for r in vals] == [1, 2]
+    assert all(math.isfinite(r['DaftExprt.validation/loss']) and 'DaftExprt.validation/mel_spec_l1_loss' in r for r in vals)
+    best = torch.load(os.path.join(out, 'checkpoints', 'DaftExprt_best'), weights_only=False)   # train.py:446-451
+    assert best['best_val_loss'] == pytest.approx(min(r['DaftExprt.validation/loss'] for r in vals))
+    assert best['iteration'] in (1, 2) and len(best['state_dict']) == 193
     assert all(math.isfinite(r['DaftExprt.training/loss']) and r['DaftExprt.optimization/grad_norm'] > 0 for r in recs)
     ckpt_path = os.path.join(out, 'checkpoints', 'DaftExprt_2')
     ckpt = torch.load(ckpt_path, weights_only=False)
     assert ckpt['iteration'] == 2 and len(ckpt['state_dict']) == 193
+    assert ckpt['best_val_loss'] == pytest.approx(best['best_val_loss'])
+    assert all(k.startswith('module.') == ddp_flag for k in ckpt['state_dict'])
     # reload into a fresh model (what scripts/synthesize.py:38-44 does) and synthesise two sentences
     model = DaftExprt(hp)
     model.load_state_dict({k.replace('module.', ''): v for k, v in ckpt['state_dict'].items()})

@@ -112,10 +112,22 @@ def test_state_dict_abi_and_module_prefix():
 def test_checkpoint_round_trip(tmp_path):
     from daft_exprt.optim import FusedAdam
     from daft_exprt.train import save_checkpoint, load_checkpoint
+    import torch.distributed as dist
     hp = make_hparams()
-    hp.multiprocessing_distributed = True          # -> 'module.' prefixed keys, like a DDP-trained reference checkpoint
     m = DaftExprt(hp)
     opt = FusedAdam(m, lr=3e-4)
+    plain = os.path.join(tmp_path, 'checkpoints', 'plain')
+    save_checkpoint(m, opt, hp, 3e-4, 1, best_val_loss=2., filepath=plain)
+    assert not any(k.startswith('module.') for k in torch.load(plain, weights_only=False)['state_dict'])
+    # a live process group (any world size, like the reference's DDP wrap) -> 'module.' prefixed keys
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29533', world_size=1, rank=0)
+    try:
+        _round_trip(tmp_path, hp, m, opt, save_checkpoint, load_checkpoint, FusedAdam)
+    finally:
+        dist.destroy_process_group()
+
+
+def _round_trip(tmp_path, hp, m, opt, save_checkpoint, load_checkpoint, FusedAdam):
     opt.step_count = 7
     opt.exp_avg.uniform_(-1, 1)
     opt.exp_avg_sq.uniform_(0, 1)
@@ -166,3 +178,37 @@ def test_feature_reader_matches_reference(golden_dir):
         assert batch[8].shape == (5, 80, 30) and batch[5].tolist() == sorted(batch[5].tolist(), reverse=True)
     finally:
         os.chdir(cwd)
+
+
+def test_unsupported_widths_and_bad_ids_are_rejected_up_front():
+    hp = make_hparams()
+    hp.phoneme_encoder['hidden_embed_dim'] = 256
+    with pytest.raises(NotImplementedError):
+        DaftExprt(hp)
+    hp = make_hparams()
+    hp.prosody_encoder['attn_nb_heads'] = 4
+    with pytest.raises(NotImplementedError):
+        DaftExprt(hp)
+    hp = make_hparams()
+    m = DaftExprt(hp)
+    batch = list(synthetic_batch(hp, 3, seed=3, t_max=40, l_range=(4, 9)))
+    bad = list(batch)
+    bad[0] = batch[0].clone()
+    bad[0][0, 0] = hp.n_symbols                     # nn.Embedding would raise
+    with pytest.raises(IndexError):
+        m.parse_batch('cuda:0', tuple(bad))
+    bad = list(batch)
+    bad[10] = torch.full_like(batch[10], hp.n_speakers - 1)    # CrossEntropyLoss: target out of bounds
+    with pytest.raises(IndexError):
+        m.parse_batch('cuda:0', tuple(bad))
+    m.check_ids(batch[0], torch.full_like(batch[10], hp.n_speakers - 1), training=False)   # a valid embedding row at inference
+
+
+def test_dropout_seeds_differ_between_ranks():
+    hp = make_hparams()
+    a, b = DaftExprt(hp), DaftExprt(hp)
+    b.set_rank(1)
+    a._step_id = b._step_id = 5
+    sa = [a._seed() for _ in range(4)]
+    sb = [b._seed() for _ in range(4)]
+    assert len(set(sa + sb)) == 8 and all(0 <= v < 2 ** 63 for v in sa + sb)

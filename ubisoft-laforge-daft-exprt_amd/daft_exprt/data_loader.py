@@ -71,12 +71,16 @@ class DaftExprtDataLoader(Dataset):
         return len(self.data)
 
 
-def prepare_data_loaders(hparams, num_workers=1, drop_last=True):
-    ''' `data_loader.py:214-243`: train / validation loaders; `DistributedSampler(shuffle=False)` when distributed '''
+def prepare_data_loaders(hparams, num_workers=1, drop_last=True, distributed=None):
+    ''' `data_loader.py:214-243`: train / validation loaders; `DistributedSampler(shuffle=False)` when distributed
+        (default: whenever a process group is live -- the reference keys on `hparams.multiprocessing_distributed`, which
+        it only sets together with an initialised group) '''
+    if distributed is None:
+        distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
     train_set = DaftExprtDataLoader(hparams.training_files, hparams)
     val_set = DaftExprtDataLoader(hparams.validation_files, hparams)
     collate_fn = DaftExprtDataCollate(hparams)
-    sampler = DistributedSampler(train_set, shuffle=False) if getattr(hparams, 'multiprocessing_distributed', False) else None
+    sampler = DistributedSampler(train_set, shuffle=False) if distributed else None
     train_loader = DataLoader(train_set, num_workers=num_workers, shuffle=(sampler is None), sampler=sampler,
                               batch_size=hparams.batch_size, pin_memory=True, drop_last=drop_last, collate_fn=collate_fn)
     val_loader = DataLoader(val_set, num_workers=num_workers, shuffle=False, batch_size=hparams.batch_size, pin_memory=True,

@@ -98,6 +98,12 @@ def generate_batch_mel_specs(model, batch_sentences, batch_refs, batch_dur_facto
                           batch_refs, batch_speaker_ids, batch_file_names, hparams)
     file_names = col[-1]
     gpu = next(model.parameters()).device
+    core = model if hasattr(model, 'check_ids') else getattr(model, 'module', None)
+    if core is not None and hasattr(core, 'check_ids'):
+        core.check_ids(col[0], col[9], training=False)       # the reference's nn.Embedding would raise IndexError here
+    if pitch_transform == 'add':
+        for spk in col[9].tolist():
+            hparams.stats[f'spk {spk}']['pitch']             # KeyError like `model.py:824-825` when a speaker has no statistics
     inputs = tuple(t.to(gpu, non_blocking=True) for t in col[:-1])
     inference = model.inference if hasattr(model, 'inference') else model.module.inference   # DDP-wrapped callers (270-278)
     encoder_preds, decoder_preds, alignments = inference(inputs, pitch_transform, hparams)

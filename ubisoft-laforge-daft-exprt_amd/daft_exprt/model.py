@@ -157,6 +157,18 @@ class DaftExprt(nn.Module):
         super(DaftExprt, self).__init__()
         hparams.frame_decoder['hidden_embed_dim'] = hparams.phoneme_encoder['hidden_embed_dim']  # model.py:675
         self.hp = hparams
+        # the kernels are specialised for the published architecture family: reject anything else up front instead of
+        # failing inside an op (the reference would build any width; the checkpoint ABI of SURVEY 8b is the 128-wide one)
+        dims = (hparams.prosody_encoder['hidden_embed_dim'], hparams.phoneme_encoder['hidden_embed_dim'])
+        if dims != (128, 128):
+            raise NotImplementedError(f'hidden_embed_dim of prosody_encoder / phoneme_encoder must be 128 / 128 (got {dims}): '
+                                      'the residual-stream kernels (LayerNorm-fused GEMM epilogues, positional gather, '
+                                      'attention head split) are built for 128 channels')
+        for cfg, nm in ((hparams.prosody_encoder, 'prosody_encoder'), (hparams.phoneme_encoder, 'phoneme_encoder'),
+                        (hparams.frame_decoder, 'frame_decoder')):
+            if 128 // cfg['attn_nb_heads'] not in (16, 64) or cfg['conv_kernel'] != 3:
+                raise NotImplementedError(f'{nm}: attention kernels exist for head sizes 16 and 64 (attn_nb_heads 8 or 2) and '
+                                          f'conv_kernel 3, got attn_nb_heads={cfg["attn_nb_heads"]}, conv_kernel={cfg["conv_kernel"]}')
         self.cd = torch.bfloat16 if getattr(hparams, 'compute_dtype', 'bf16') == 'bf16' else torch.float32
         self._table = param_table(hparams)
         gen = torch.Generator().manual_seed(int(torch.initial_seed()) & 0x7fffffff)
@@ -181,7 +193,7 @@ class DaftExprt(nn.Module):
         self._plans = {}
         self._plan_min_rows = int(__import__('os').environ.get('DX_PLAN_MIN_ROWS', '0'))
         self._plan_k1 = bool(int(__import__('os').environ.get('DX_PLAN_K1', '0')))   # balanced tiles also for the k = 1 QKV data gradient + LayerNorm backward (measured: 8.78 vs 8.74 ms)
-        self._step_id, self._site = 0, 0
+        self._step_id, self._site, self._rank = 0, 0, 0
         self._pos = None
         self.n_params = sum(int(np.prod(s)) for _, s, _ in self._table)
         self._gemm_weights = [n for n, s, _ in self._table if
@@ -288,9 +300,15 @@ class DaftExprt(nn.Module):
             hit = self._plans[key] = (lengths, ops.conv_tile_plan(lengths, N))
         return hit[1]
 
+    def set_rank(self, rank):
+        ''' data-parallel rank of this replica: folded into every dropout seed so that the ranks draw independent masks
+            (torch's per-process Philox streams in the reference are independent as well) '''
+        self._rank = int(rank)
+
     def _seed(self):
         self._site += 1
-        return (int(self.hp.seed) * 0x9E3779B1 + self._step_id * 0x85EBCA77 + self._site * 0xC2B2AE3D) & _MASK63
+        return (int(self.hp.seed) * 0x9E3779B1 + self._step_id * 0x85EBCA77 + self._site * 0xC2B2AE3D +
+                self._rank * 0x27D4EB2F165667C5) & _MASK63
 
     # ------------------------------------------------------------------ reference surface
     def parse_batch(self, gpu, batch):
@@ -298,12 +316,28 @@ class DaftExprt(nn.Module):
         dev = torch.device('cuda', gpu) if isinstance(gpu, int) else torch.device(gpu)
         symbols, durations_float, durations_int, symbols_energy, symbols_pitch, input_lengths, \
             frames_energy, frames_pitch, mel_specs, output_lengths, speaker_ids, feature_dirs, feature_files = batch
+        self.check_ids(symbols, speaker_ids, training=True)
         f = lambda t: t.to(dev, non_blocking=True).float().contiguous()
         i = lambda t: t.to(dev, non_blocking=True).long().contiguous()
         inputs = (i(symbols), f(durations_float), i(durations_int), f(symbols_energy), f(symbols_pitch), i(input_lengths),
                   f(frames_energy), f(frames_pitch), f(mel_specs), i(output_lengths), i(speaker_ids))
         targets = (inputs[1], inputs[3], inputs[4], inputs[8], inputs[10])
         return inputs, targets, (feature_dirs, feature_files)
+
+    def check_ids(self, symbols, speaker_ids, training):
+        ''' index-range checks on HOST tensors (collate output), where they cost nothing: the reference raises in these
+            cases (nn.Embedding / CrossEntropyLoss index errors), the gather kernels would read out of bounds silently.
+            Device tensors are passed through unchecked (checking them would add a sync per batch). '''
+        hp = self.hp
+        if torch.is_tensor(symbols) and not symbols.is_cuda and symbols.numel():
+            lo, hi = int(symbols.min()), int(symbols.max())
+            if lo < 0 or hi >= hp.n_symbols:
+                raise IndexError(f'symbol id out of range [0, {hp.n_symbols}): min {lo}, max {hi}')
+        if torch.is_tensor(speaker_ids) and not speaker_ids.is_cuda and speaker_ids.numel():
+            lo, hi = int(speaker_ids.min()), int(speaker_ids.max())
+            top = hp.n_speakers - 1 if training else hp.n_speakers   # classifier targets (model.py:273) / embedding rows (366)
+            if lo < 0 or hi >= top:
+                raise IndexError(f'speaker id out of range [0, {top}): min {lo}, max {hi}')
 
     def forward(self, inputs):
         ''' `model.py:755-787` (teacher-forced).  Returns (speaker_preds, [post_multipliers, enc_film, pp_film,
@@ -766,6 +800,7 @@ class DaftExprt(nn.Module):
 
     def _speaker_stats(self, hparams, device):
         n = max(int(k.split(' ')[1]) for k in hparams.stats if k.startswith('spk ')) + 1 if hparams.stats else 0
+        n = max(n, int(self.hp.n_speakers))   # ids below n_speakers without statistics read (0, 1) instead of out of bounds
         mean, std = torch.zeros(max(n, 1)), torch.ones(max(n, 1))
         for k, v in hparams.stats.items():
             if k.startswith('spk '):

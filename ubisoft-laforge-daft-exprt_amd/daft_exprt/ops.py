@@ -254,9 +254,10 @@ def attention_bwd(qkv, o, d_o, lse, lengths, nb_heads, p_drop=0., seed=0):
 # ----------------------------------------------------------------------------- pointwise / small heads
 def scalar_embed_fwd(feats, ws, biases, base=None, pos_table=None, lengths=None):
     B, N = feats[0].shape
-    out = torch.empty((B, N, 128), dtype=torch.float32, device=feats[0].device)
+    C = ws[0].shape[0]
+    out = torch.empty((B, N, C), dtype=torch.float32, device=feats[0].device)
     H.check(H.lib().dx_scalar_embed_fwd(H.ptr(base), _ptr_array(feats), _ptr_array(ws), _ptr_array(biases), len(feats),
-                                        H.ptr(pos_table), H.ptr(lengths), H.ptr(out), B, N, 128, H.stream()))
+                                        H.ptr(pos_table), H.ptr(lengths), H.ptr(out), B, N, C, H.stream()))
     return out
 
 
@@ -270,14 +271,18 @@ def scalar_embed_bwd(dout, feats, dws, dbiases, lengths=None, need_dbase=False):
 
 def embed_pos_fwd(ids, table, pos_table, lengths):
     B, N = ids.shape
-    out = torch.empty((B, N, 128), dtype=torch.float32, device=ids.device)
-    H.check(H.lib().dx_embed_pos_fwd(H.ptr(ids), H.ptr(table), H.ptr(pos_table), H.ptr(lengths), H.ptr(out), B, N, 128, H.stream()))
+    C = table.shape[1]
+    assert pos_table.shape[1] == C and table.is_contiguous() and pos_table.is_contiguous()
+    out = torch.empty((B, N, C), dtype=torch.float32, device=ids.device)
+    H.check(H.lib().dx_embed_pos_fwd(H.ptr(ids), H.ptr(table), H.ptr(pos_table), H.ptr(lengths), H.ptr(out), B, N, C, H.stream()))
     return out
 
 
 def embed_pos_bwd(ids, dout, lengths, dtable):
     B, N = ids.shape
-    H.check(H.lib().dx_embed_pos_bwd(H.ptr(ids), H.ptr(dout), H.ptr(lengths), H.ptr(dtable), B, N, 128, H.stream()))
+    C = dtable.shape[1]
+    assert dout.shape[2] == C and dout.is_contiguous()
+    H.check(H.lib().dx_embed_pos_bwd(H.ptr(ids), H.ptr(dout), H.ptr(lengths), H.ptr(dtable), B, N, C, H.stream()))
 
 
 def masked_mean_fwd(x, lengths):

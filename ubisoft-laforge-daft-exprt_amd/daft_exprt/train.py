@@ -13,7 +13,8 @@ Step loop = `train.py:368-401, 475-494` with the device work restructured for MI
     8 `.item()` syncs per micro-batch, `loss.py:102-104`, `train.py:382`);
   * the NaN check that guards logging is made rank-consistent (the reference's rank-local check can deadlock
     its barrier).
-Validation figures / benchmark-sentence synthesis (MFA, librosa, Griffin-Lim) are outside the accelerated path.
+Validation scoring and the best-model checkpoint (`train.py:427-456`) are kept; validation figures and the
+benchmark-sentence synthesis (MFA, librosa, Griffin-Lim) are outside the accelerated path.
 """
 import argparse
 import json
@@ -51,7 +52,7 @@ def save_checkpoint(model, optimizer, hparams, learning_rate, iteration, best_va
         reference consumers (`synthesize.py:43`, `fine_tune.py:40`) strip it as usual '''
     os.makedirs(os.path.dirname(filepath), exist_ok=True)
     _logger.info(f'Saving model and optimizer state at iteration "{iteration}" to "{filepath}"')
-    prefix = 'module.' if getattr(hparams, 'multiprocessing_distributed', False) else ''
+    prefix = 'module.' if dist.is_available() and dist.is_initialized() else ''   # what a DDP-wrapped model's state_dict carries
     state = {prefix + k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     config = {k: v for k, v in vars(hparams).items()}
     torch.save({'iteration': iteration, 'learning_rate': learning_rate, 'best_val_loss': best_val_loss,
@@ -123,7 +124,9 @@ class Trainer(object):
 
 
 def validate(gpu, model, criterion, val_loader, hparams):
-    ''' `train.py:193-233` (scores only; figures are out of scope) '''
+    ''' `train.py:193-233`: eval mode, no grad, criterion at iteration 0 (adversarial weight 0), batch
+        means of the total and of the five reconstruction terms.  Returns (val_loss, val_indiv_loss); the per-batch
+        targets / outputs the reference also returns only feed its TensorBoard figures (out of scope). '''
     val_loss, n = 0., 0
     indiv = {k: 0. for k in KEYS[2:]}
     model.eval()
@@ -139,43 +142,52 @@ def validate(gpu, model, criterion, val_loader, hparams):
     return val_loss / max(n, 1), {k: v / max(n, 1) for k, v in indiv.items()}
 
 
-def _loaders(hparams, rank, world):
-    ''' training batches: on-disk features when `training_files` exists, else the seeded synthetic utterances '''
+def _loaders(hparams, rank, world, distributed):
+    ''' (train loader, validation loader or None): on-disk features when `training_files` exists, else the seeded synthetic
+        utterances.  The sampler keys on the live process group (one predicate everywhere), not on the hparams flag. '''
     collate = DaftExprtDataCollate(hparams)
     if os.path.isfile(str(hparams.training_files)):
-        return prepare_data_loaders(hparams, num_workers=8)[0]
+        train_loader, _, val_loader, _ = prepare_data_loaders(hparams, num_workers=8, distributed=distributed)
+        return train_loader, val_loader
     n_items = getattr(hparams, 'synthetic_items', hparams.batch_size * hparams.accumulation_steps * world * 8)
     ds = SyntheticUtterances(hparams, n_items, seed=hparams.seed, force_first_full=False)
     idx = list(range(rank, n_items, world))   # DistributedSampler(shuffle=False) striding (data_loader.py:232)
     subset = torch.utils.data.Subset(ds, idx)
     return torch.utils.data.DataLoader(subset, batch_size=hparams.batch_size, shuffle=False, drop_last=True, collate_fn=collate,
-                                       num_workers=0)
+                                       num_workers=0), None
 
 
 def train(gpu, hparams, log_file):
-    ''' one rank of the training job (`train.py:236-494`) '''
-    world = getattr(hparams, 'world_size', 1)
-    distributed = getattr(hparams, 'multiprocessing_distributed', False) and world > 1
+    ''' one rank of the training job (`train.py:236-494`).  Like the reference, the process group exists whenever
+        `multiprocessing_distributed` is set -- also with a single GPU -- and everything downstream (sampler, gradient
+        reducer, `module.` checkpoint prefix, barriers) keys on that one fact. '''
+    distributed = bool(getattr(hparams, 'multiprocessing_distributed', False))
     if distributed:
         hparams.rank = hparams.rank * hparams.ngpus_per_node + gpu
-        dist.init_process_group(backend=hparams.dist_backend, init_method=hparams.dist_url, world_size=world, rank=hparams.rank)
-    rank = getattr(hparams, 'rank', 0)
+        dist.init_process_group(backend=hparams.dist_backend, init_method=hparams.dist_url, world_size=hparams.world_size,
+                                rank=hparams.rank)
+    world = dist.get_world_size() if distributed else 1
+    rank = dist.get_rank() if distributed else 0
+    os.makedirs(os.path.dirname(os.path.abspath(log_file)), exist_ok=True)
     logging.basicConfig(handlers=[logging.StreamHandler(), logging.FileHandler(log_file)],
                         format='%(asctime)s [%(levelname)s] %(message)s', datefmt='%Y-%m-%d %H:%M:%S',
                         level=logging.INFO if rank == 0 else logging.ERROR)
     torch.cuda.set_device(gpu)
     torch.manual_seed(hparams.seed)
     model = DaftExprt(hparams).cuda(gpu)
+    model.set_rank(rank)                      # per-rank dropout streams
     model.train()
-    trainer = Trainer(model, hparams, world if distributed else 1)
+    trainer = Trainer(model, hparams, world)
+    criterion = trainer.criterion
     iteration, best_val_loss = 1, float('inf')
     if hparams.checkpoint != '':
         model, trainer.optimizer, iteration, _, best_val_loss = load_checkpoint(hparams.checkpoint, gpu, model, trainer.optimizer, hparams)
         iteration += 1
-    loader = _loaders(hparams, rank, world if distributed else 1)
-    _logger.info(f'Batch size: {hparams.batch_size * hparams.accumulation_steps * (world if distributed else 1):_}')
+    loader, val_loader = _loaders(hparams, rank, world, distributed)
+    _logger.info(f'Batch size: {hparams.batch_size * hparams.accumulation_steps * world:_}')
     metrics_path = os.path.join(os.path.dirname(log_file), 'metrics.jsonl')
-    start = time.time()
+    ckpt_dir = os.path.join(hparams.output_directory, 'checkpoints')
+    start, total_time = time.time(), 0.
     model.zero_grad()
     micro = []
     while iteration <= hparams.nb_iterations:
@@ -188,23 +200,48 @@ def train(gpu, hparams, log_file):
             micro = []
             values = torch.cat((terms, gnorm_sq.sqrt())).tolist()   # one D2H copy per optimizer step
             tot_loss, grad_norm = values[7], values[8]
+            lr = trainer.optimizer.param_groups[0]['lr']
             nan = torch.tensor([0. if math.isfinite(tot_loss) else 1.], device=f'cuda:{gpu}')
             if distributed:
                 dist.all_reduce(nan)   # rank-consistent NaN decision (see module docstring)
-            if float(nan) == 0. and rank == 0:
-                duration = time.time() - start
-                lr = trainer.optimizer.param_groups[0]['lr']
-                _logger.info(f'Train loss [{iteration}]: {tot_loss:.6f} Grad Norm {grad_norm:.6f} {duration:.2f}s/it (LR {lr:.6f})')
-                with open(metrics_path, 'a') as f:   # scalar names of DaftExprtLogger.log_training (logger.py:26-32)
-                    rec = {'iteration': iteration, 'DaftExprt.optimization/grad_norm': grad_norm,
-                           'DaftExprt.optimization/learning_rate': lr, 'DaftExprt.optimization/duration': duration,
-                           'DaftExprt.training/loss': tot_loss}
-                    rec.update({f'DaftExprt.training/{k}': v for k, v in zip(KEYS, values[:7])})
-                    f.write(json.dumps(rec) + '\n')
+            if float(nan) == 0.:
+                if rank == 0:
+                    duration = time.time() - start
+                    total_time += duration
+                    _logger.info(f'Train loss [{iteration}]: {tot_loss:.6f} Grad Norm {grad_norm:.6f} {duration:.2f}s/it (LR {lr:.6f})')
+                    with open(metrics_path, 'a') as f:   # scalar names of DaftExprtLogger.log_training (logger.py:26-32)
+                        rec = {'iteration': iteration, 'DaftExprt.optimization/grad_norm': grad_norm,
+                               'DaftExprt.optimization/learning_rate': lr, 'DaftExprt.optimization/duration': duration,
+                               'DaftExprt.training/loss': tot_loss}
+                        rec.update({f'DaftExprt.training/{k}': v for k, v in zip(KEYS, values[:7])})
+                        f.write(json.dumps(rec) + '\n')
+                if distributed:
+                    dist.barrier()
+            # ---- model evaluation (`train.py:427-456`): every rank scores the whole validation set, rank 0 keeps the best
+            if val_loader is not None and iteration % hparams.iters_check_for_model_improvement == 0:
+                _logger.info('Validating....')
+                val_loss, val_indiv = validate(gpu, model, criterion, val_loader, hparams)
+                if rank == 0:
+                    _logger.info(f'Validation loss {iteration}: {val_loss:.6f} ')
+                    remaining = int((hparams.nb_iterations - iteration) * (total_time / hparams.iters_check_for_model_improvement))
+                    _logger.info(f'estimated required time = {remaining // 86400:02}:{remaining // 3600 % 24:02}:'
+                                 f'{remaining // 60 % 60:02}:{remaining % 60:02}')
+                    total_time = 0.
+                    with open(metrics_path, 'a') as f:   # scalar names of DaftExprtLogger.log_validation (logger.py:41-45)
+                        rec = {'iteration': iteration, 'DaftExprt.validation/loss': val_loss}
+                        rec.update({f'DaftExprt.validation/{k}': v for k, v in val_indiv.items()})
+                        f.write(json.dumps(rec) + '\n')
+                    if val_loss < best_val_loss:
+                        _logger.info('Congrats!!! A new best model. You are the best!')
+                        best_val_loss = val_loss
+                        save_checkpoint(model, trainer.optimizer, hparams, lr, iteration, best_val_loss,
+                                        os.path.join(ckpt_dir, 'DaftExprt_best'))
+                if distributed:
+                    dist.barrier()
             if iteration % hparams.iters_per_checkpoint == 0:
                 if rank == 0:
-                    path = os.path.join(hparams.output_directory, 'checkpoints', f'DaftExprt_{iteration}')
-                    save_checkpoint(model, trainer.optimizer, hparams, trainer.optimizer.param_groups[0]['lr'], iteration, best_val_loss, path)
+                    save_checkpoint(model, trainer.optimizer, hparams, lr, iteration, best_val_loss,
+                                    os.path.join(ckpt_dir, f'DaftExprt_{iteration}'))
                 if distributed:
                     dist.barrier()
             iteration += 1
@@ -227,7 +264,7 @@ def launch_training(data_set_dir, config_file, benchmark_dir, log_file, world_si
     hparams.multiprocessing_distributed = multiprocessing_distributed
     hparams.world_size = ngpus * world_size if multiprocessing_distributed else 1
     torch.manual_seed(hparams.seed)
-    if multiprocessing_distributed and hparams.world_size > 1:
+    if multiprocessing_distributed:       # one process per GPU, also when there is a single one (`train.py:604-608`)
         torch.multiprocessing.spawn(train, nprocs=ngpus, args=(hparams, log_file))
     else:
         train(0, hparams, log_file)
