@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """Benchmark of the Daft-Exprt hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Either the caller launches the ranks (`python -m torch.distributed.run --nproc-per-node N
+... bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE in the environment) or bench.py does it itself: with no
+WORLD_SIZE in the environment and --gpus N > 1 it re-executes itself under torch.distributed.run (127.0.0.1 rendezvous).
+`n_gpus` in the JSON line is always the size of the RCCL world that ran; --gpus that disagrees with WORLD_SIZE is an error.
 
 A "step" = one optimizer step of the full model (forward + 7-term loss + backward + gradient all-reduce + Adam,
 dropout ON) on one synthetic batch per GPU of BASELINE.json configs[1]: 11 speakers, batch 48 per GPU, 80-bin mel,
@@ -39,9 +44,20 @@ def make_hparams(batch, dtype):
                        language='english', speakers=list(SPEAKERS), batch_size=batch, accumulation_steps=1, compute_dtype=dtype)
 
 
-def cpu_baseline(hp, batch, n_utt=8, steps=1):
-    ''' the CPU oracle (a port of the reference algorithm, oracle/daft_exprt_cpu.py) timed on this host: one full
-        train step (fwd + loss + autograd bwd + Adam, dropout on, fp32) on the first `n_utt` utterances of the batch '''
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(hp, batch, n_utt=4, warmup=2, steps=5):
+    ''' the CPU oracle (a port of the reference algorithm, oracle/daft_exprt_cpu.py) timed on this host, BASELINE.md 4
+        procedure: `warmup` + `steps` full train steps (fwd + loss + autograd bwd + Adam, dropout on, fp32) on the first
+        `n_utt` utterances of the bench batch (bounded sample: the whole B = 48 batch costs ~100 s per step), median '''
     from oracle import daft_exprt_cpu as O
     P = {k: v.requires_grad_(True) for k, v in O.random_params(hp, seed=0).items()}
     sl = slice(0, n_utt)
@@ -55,7 +71,7 @@ def cpu_baseline(hp, batch, n_utt=8, steps=1):
     state = {'step': 0, 'm': {k: torch.zeros_like(v) for k, v in P.items()}, 'v': {k: torch.zeros_like(v) for k, v in P.items()}}
     frames = int(cin[9].sum())
     times = []
-    for s in range(steps + 1):   # first pass = warm-up
+    for s in range(warmup + steps):
         t0 = time.time()
         out = O.forward(P, hp, tuple(cin), training=True)
         loss, _ = O.loss(hp, out, targets, 20000)
@@ -63,41 +79,40 @@ def cpu_baseline(hp, batch, n_utt=8, steps=1):
         with torch.no_grad():
             O.adam_step(P, dict(zip(P.keys(), grads)), state, 1e-4, hp.betas, hp.epsilon, hp.weight_decay)
         times.append(time.time() - t0)
-    best = min(times[1:]) if len(times) > 1 else times[0]
-    return {'value': frames / best, 'unit': 'mel-frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{steps} full train step(s) (fwd+loss+bwd+Adam, fp32, dropout on) of the CPU oracle on the first {n_utt} '
-                      f'utterances of the bench batch ({frames} valid frames, T_max={T}); host os.cpu_count()={os.cpu_count()}',
-            's_per_step': best}
+    timed = sorted(times[warmup:])
+    med = timed[len(timed) // 2]
+    return {'value': frames / med, 'unit': 'mel-frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{warmup} warm-up + {steps} timed full train steps (fwd+loss+bwd+Adam, fp32, dropout on) of the CPU oracle '
+                      f'on the first {n_utt} utterances of the bench batch ({frames} valid frames, T_max={T}), median; '
+                      f'host os.cpu_count()={os.cpu_count()}, torch threads={torch.get_num_threads()}, CPU "{_cpu_model()}"',
+            's_per_step_median': med, 's_per_step_min': timed[0], 's_per_step_max': timed[-1], 'cpu_model': _cpu_model()}
+
+
+def measured_traffic(kernel_family):
+    ''' HBM-side bytes per launch of the roofline kernel family from the committed PMC summary (rocprofv3 --pmc
+        FETCH_SIZE / --pmc WRITE_SIZE in separate passes, gfx950 x2 fetch correction applied; written by
+        tools/pmc_counters.py from the same bench command).  PMC counters cannot be read from inside this process, so
+        the number is the recorded one for this kernel build; None when no summary is committed. '''
+    path = os.path.join(ROOT, 'profiles', 'r02_counters.json')
+    try:
+        rec = json.load(open(path))['families'][kernel_family]
+        return {'bytes_per_launch': rec['fetch_x2_bytes'] + rec['write_bytes'], 'fetch_x2_bytes': rec['fetch_x2_bytes'],
+                'write_bytes': rec['write_bytes'], 'launches': rec['launches'], 'mfma_util': rec.get('mfma_util'),
+                'source': 'profiles/r02_counters.json (rocprofv3 --pmc, recorded run of this bench command)'}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def synth_bench(args, hp, dev, rank, world):
     ''' BASELINE configs[3]: batched prosody-transfer synthesis, forward only (prosody encoder on the reference mels ->
         phoneme encoder -> predictor -> integer durations -> Gaussian upsampling -> mel decoder), B sentences per call '''
-    import numpy as np
+    from daft_exprt.data_loader import centre_duration_head, synthetic_inference_batch
     from daft_exprt.model import DaftExprt
     model = DaftExprt(hp).to(dev).eval()
-    with torch.no_grad():   # duration head centred on ~80 ms so that random-init weights give utterances of realistic length
-        model._P['prosody_predictor.projection.linear_layer.weight'][0].mul_(0.05)
-        model._P['prosody_predictor.projection.linear_layer.bias'].copy_(torch.tensor([0.08, 0., 0.]))
-        model.mark_updated()
+    centre_duration_head(model)   # duration head centred on ~80 ms so that random-init weights give utterances of realistic length
     hp.stats = {f'spk {i}': {'pitch': {'mean': 5.0, 'std': 0.3}} for i in range(hp.n_speakers)}
-    rng = np.random.RandomState(1234 + rank)
     B = args.batch
-    L = np.sort(rng.randint(40, 161, size=B))[::-1].copy()
-    Tr = rng.randint(250, 1001, size=B)
-    Lm, Tm = int(L.max()), int(Tr.max())
-    symbols = torch.zeros(B, Lm, dtype=torch.long)
-    dur_f = torch.ones(B, Lm)
-    e_ref, p_ref, m_ref = torch.zeros(B, Tm), torch.zeros(B, Tm), torch.zeros(B, hp.n_mel_channels, Tm)
-    for b in range(B):
-        symbols[b, :L[b]] = torch.from_numpy(rng.randint(1, hp.n_symbols, size=L[b]))
-        dur_f[b, :L[b]] = min(1., 1000. / (L[b] * 0.08 * 86.13 * 1.15))     # keep every utterance <= ~1000 frames
-        e_ref[b, :Tr[b]] = torch.from_numpy(rng.uniform(0, 60, size=Tr[b]).astype(np.float32))
-        p_ref[b, :Tr[b]] = torch.from_numpy(np.where(rng.rand(Tr[b]) < 0.3, 0., rng.randn(Tr[b]) * 0.3 + 5.).astype(np.float32))
-        m_ref[b, :, :Tr[b]] = torch.from_numpy(np.clip(rng.randn(hp.n_mel_channels, Tr[b]) * 2 - 5, np.log(1e-5), 2.).astype(np.float32))
-    inputs = (symbols, dur_f, torch.ones(B, Lm), torch.zeros(B, Lm), torch.from_numpy(L), e_ref, p_ref, m_ref,
-              torch.from_numpy(Tr), torch.from_numpy(rng.randint(0, 11, size=B)))
-    inputs = tuple(t.to(dev) for t in inputs)
+    inputs = tuple(t.to(dev) for t in synthetic_inference_batch(hp, B, seed=1234 + rank))
     frames = 0
     for w in range(args.warmup):
         out = model.inference(tuple(t.clone() for t in inputs), 'add', hp)
@@ -119,6 +134,21 @@ def synth_bench(args, hp, dev, rank, world):
                           'roofline': None, 'cpu_baseline': None}))
 
 
+def spawn_ranks(n):
+    ''' re-execute this command line as n ranks (one per GPU) under torch.distributed.run; rank 0 prints the JSON line '''
+    import socket
+    import subprocess
+    if n > torch.cuda.device_count():
+        raise SystemExit(f'bench.py: --gpus {n} but only {torch.cuda.device_count()} GPU(s) visible')
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -134,14 +164,22 @@ def main():
     ap.add_argument('--tmin', type=int, default=1, help='minimum frames per synthetic utterance (configs[4]: 500)')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world)
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks or pass --gpus {world}')
+    if world > torch.cuda.device_count():
+        raise SystemExit(f'bench.py: {world} ranks requested but only {torch.cuda.device_count()} GPU(s) visible')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == world
 
     from daft_exprt import ops
     from daft_exprt.data_loader import synthetic_batch
@@ -153,6 +191,7 @@ def main():
     if args.workload == 'synth':
         return synth_bench(args, hp, dev, rank, world)
     model = DaftExprt(hp).to(dev).train()
+    model.set_rank(rank)
     trainer = Trainer(model, hp, world)
     batches, cpu_batches = [], []
     for i in range(args.pool):
@@ -217,7 +256,8 @@ def main():
         achieved = alg / (ms * 1e-3) / 1e12
         roofline = {'kernel': f'{name} (conv / linear as implicit GEMM, all call sites)', 'bound': 'mfma',
                     'achieved': achieved, 'peak': PEAK_MFMA_BF16 / 1e12 if args.dtype == 'bf16' else 157.3, 'unit': 'TFLOP/s',
-                    'frac': achieved / (PEAK_MFMA_BF16 / 1e12 if args.dtype == 'bf16' else 157.3), 'traffic': None,
+                    'frac': achieved / (PEAK_MFMA_BF16 / 1e12 if args.dtype == 'bf16' else 157.3),
+                    'traffic': measured_traffic(name) if (args.batch == 48 and args.tmin == 1 and args.dtype == 'bf16') else None,
                     'launches_per_step': n_launch // nprobe, 'avg_launch_us': ms * 1e3 / n_launch,
                     'algorithmic_gflop_per_launch': alg / n_launch / 1e9,
                     'share_of_step_time': (ms / nprobe) / (elapsed / args.steps * 1e3),

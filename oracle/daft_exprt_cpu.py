@@ -26,6 +26,59 @@ import torch.nn.functional as F
 
 
 # ----------------------------------------------------------------------------------------
+# optional emulation of the HIP path's bf16 operand mode (tests/test_gpu_parity_at_size.py)
+# ----------------------------------------------------------------------------------------
+# OPERAND_DTYPE = None (default): exact fp32 everywhere -- the restatement that is pinned against the reference fixtures.
+# OPERAND_DTYPE = torch.bfloat16: every GEMM that the HIP path runs on bf16 MFMA operands (conv / linear layers with Cin > 1
+# except the small fp32 heads, and the two attention contractions) rounds its operands -- activations, weights and, in the
+# backward pass, the incoming gradient -- to bf16 and accumulates in fp32; wide (> 128-channel) conv outputs are rounded where
+# the HIP path stores them in bf16.  Same functions, same order of operations: only roundings are inserted, so a comparison
+# against it isolates the kernels' indexing / masking / reduction logic from the (large, T-dependent) bf16 rounding noise.
+OPERAND_DTYPE = None
+
+
+class _RoundForward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        return x.to(dtype).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class _RoundBackward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype = dtype
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
+def _op(x):
+    ''' MFMA operand rounding (value); straight-through for the gradient '''
+    return x if OPERAND_DTYPE is None else _RoundForward.apply(x, OPERAND_DTYPE)
+
+
+def _og(y):
+    ''' output of an MFMA GEMM: its gradient is an MFMA operand of the backward GEMMs '''
+    return y if OPERAND_DTYPE is None else _RoundBackward.apply(y, OPERAND_DTYPE)
+
+
+def _stored_lp(y):
+    ''' tensors the HIP path keeps in the operand type between kernels: rounded value AND rounded gradient '''
+    return y if OPERAND_DTYPE is None else _RoundBackward.apply(_RoundForward.apply(y, OPERAND_DTYPE), OPERAND_DTYPE)
+
+
+def linear_mfma(x, w, b):
+    ''' x W^T + b for the layers the HIP path runs on MFMA (in/out projections, mel projection) '''
+    return _og(_op(x) @ _op(w).t()) + b
+
+
+# ----------------------------------------------------------------------------------------
 # small building blocks
 # ----------------------------------------------------------------------------------------
 def valid_mask(lengths, n_max=None):
@@ -61,6 +114,8 @@ def conv1d_cl(x, w, b):
     ''' k-tap, stride-1, zero "same" padding conv on channel-last x (B,N,Cin); w (Cout,Cin,K).
         model.py:86-94 (ConvNorm1D.forward: transpose, nn.Conv1d, transpose). '''
     pad = (w.shape[2] - 1) // 2
+    if OPERAND_DTYPE is not None and w.shape[1] > 1:      # Cin = 1 scalar embeddings are fp32 pointwise kernels
+        return _og(F.conv1d(_op(x).transpose(1, 2), _op(w), None, padding=pad).transpose(1, 2)) + b
     return F.conv1d(x.transpose(1, 2), w, b, padding=pad).transpose(1, 2)
 
 
@@ -91,17 +146,38 @@ def multi_head_attention(P, pre, x, pad, nb_heads, p_drop, training):
         softmax over keys, dropout on probs, out-proj, Dropout, +x, LayerNorm(128). '''
     B, N, E = x.shape
     d_h = E // nb_heads
-    qkv = x @ P[pre + 'multi_head_attention.in_proj_weight'].t() + P[pre + 'multi_head_attention.in_proj_bias']
+    if OPERAND_DTYPE is None:
+        qkv = x @ P[pre + 'multi_head_attention.in_proj_weight'].t() + P[pre + 'multi_head_attention.in_proj_bias']
+    else:
+        qkv = _stored_lp(linear_mfma(x, P[pre + 'multi_head_attention.in_proj_weight'], P[pre + 'multi_head_attention.in_proj_bias']))
     q, k, v = qkv.split(E, dim=-1)
 
     def heads(t):
         return t.reshape(B, N, nb_heads, d_h).permute(0, 2, 1, 3)  # (B,H,N,d)
-    q, k, v = heads(q) * (1. / math.sqrt(d_h)), heads(k), heads(v)
-    s = q @ k.transpose(-1, -2)  # (B,H,N,N)
+    if OPERAND_DTYPE is None:
+        q, k, v = heads(q) * (1. / math.sqrt(d_h)), heads(k), heads(v)
+        s = q @ k.transpose(-1, -2)  # (B,H,N,N)
+    else:   # the HIP kernels contract the bf16 q / k and apply the scale to the fp32 scores
+        q, k, v = heads(q), heads(k), heads(v)
+        s = _og(q @ k.transpose(-1, -2)) * (1. / math.sqrt(d_h))
     s = s.masked_fill(pad[:, None, None, :], float('-inf'))
-    p = dropout(torch.softmax(s, dim=-1), p_drop, training)
-    o = (p @ v).permute(0, 2, 1, 3).reshape(B, N, E)
-    o = o @ P[pre + 'multi_head_attention.out_proj.weight'].t() + P[pre + 'multi_head_attention.out_proj.bias']
+    if OPERAND_DTYPE is None:
+        p = dropout(torch.softmax(s, dim=-1), p_drop, training)
+        o = (p @ v).permute(0, 2, 1, 3).reshape(B, N, E)
+        o = o @ P[pre + 'multi_head_attention.out_proj.weight'].t() + P[pre + 'multi_head_attention.out_proj.bias']
+    else:
+        # the HIP kernel is flash-style: keys in steps of 32 with a running row maximum; what is rounded to the operand type
+        # is exp(s - running max) of that step (<= 1), later rescaled in fp32; the normaliser sums the unrounded values
+        m_fin = s.max(dim=-1, keepdim=True).values
+        n_steps = (N + 31) // 32
+        s_pad = F.pad(s, (0, n_steps * 32 - N), value=float('-inf')).reshape(B, nb_heads, N, n_steps, 32)
+        m_run = s_pad.max(dim=-1).values.cummax(dim=-1).values                          # (B,H,N,steps), finite from step 0 on
+        m_key = m_run.unsqueeze(-1).expand(-1, -1, -1, -1, 32).reshape(B, nb_heads, N, n_steps * 32)[..., :N]
+        p_step = _stored_lp(torch.exp(s - m_key)) * torch.exp(m_key - m_fin)
+        p_step = dropout(p_step, p_drop, training)
+        norm = torch.exp(s - m_fin).sum(dim=-1, keepdim=True)
+        o = _stored_lp(((p_step @ v) / norm).permute(0, 2, 1, 3).reshape(B, N, E))
+        o = linear_mfma(o, P[pre + 'multi_head_attention.out_proj.weight'], P[pre + 'multi_head_attention.out_proj.bias'])
     o = dropout(o, p_drop, training)
     return layer_norm(o + x, P[pre + 'layer_norm.weight'], P[pre + 'layer_norm.bias'])
 
@@ -147,6 +223,8 @@ def prosody_encoder(P, hp, frames_energy, frames_pitch, mel_specs, speaker_ids, 
     x = mel_specs.transpose(1, 2)
     for conv_idx, ln_idx in ((0, 2), (4, 6), (8, 10)):  # nn.Sequential indices, model.py:341-363
         x = torch.relu(conv1d_cl(x, P[f'{pre}convs.{conv_idx}.conv.weight'], P[f'{pre}convs.{conv_idx}.conv.bias']))
+        if x.shape[2] != D:
+            x = _stored_lp(x)
         x = layer_norm(x, P[f'{pre}convs.{ln_idx}.weight'], P[f'{pre}convs.{ln_idx}.bias'])
         x = dropout(x, cfg['conv_dropout'], training)
     pad = ~valid_mask(output_lengths)
@@ -200,7 +278,7 @@ def prosody_predictor(P, hp, x, film, input_lengths, training):
     cfg, pre = hp.local_prosody_predictor, 'prosody_predictor.'
     for blk in range(cfg['nb_blocks']):
         for conv_idx, ln_idx in ((0, 2), (4, 6)):
-            x = torch.relu(conv1d_cl(x, P[f'{pre}blocks.{blk}.{conv_idx}.conv.weight'], P[f'{pre}blocks.{blk}.{conv_idx}.conv.bias']))
+            x = _stored_lp(torch.relu(conv1d_cl(x, P[f'{pre}blocks.{blk}.{conv_idx}.conv.weight'], P[f'{pre}blocks.{blk}.{conv_idx}.conv.bias'])))
             x = layer_norm(x, P[f'{pre}blocks.{blk}.{ln_idx}.weight'], P[f'{pre}blocks.{blk}.{ln_idx}.bias'])
             x = dropout(x, cfg['conv_dropout'], training)
         C = film.shape[2] // 2
@@ -247,7 +325,10 @@ def frame_decoder(P, hp, x, film, output_lengths, training):
     x = (x + pos_encoding(output_lengths, D)).masked_fill(pad.unsqueeze(2), 0.)
     for blk in range(cfg['nb_blocks']):
         x = fft_block(P, f'{pre}blocks.{blk}.', x, film[:, blk, :], pad, cfg, training)
-    mel = x @ P[pre + 'projection.linear_layer.weight'].t() + P[pre + 'projection.linear_layer.bias']
+    if OPERAND_DTYPE is None:
+        mel = x @ P[pre + 'projection.linear_layer.weight'].t() + P[pre + 'projection.linear_layer.bias']
+    else:
+        mel = linear_mfma(x, P[pre + 'projection.linear_layer.weight'], P[pre + 'projection.linear_layer.bias'])
     return mel.masked_fill(pad.unsqueeze(2), 0.).transpose(1, 2)
 
 

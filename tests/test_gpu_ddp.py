@@ -1,0 +1,46 @@
+"""Data-parallel equivalence on hardware: N-rank `forward_backward` + `GradReducer` == single-process gradients (see
+tests/ddp_worker.py).  With >= 2 visible GPUs the ranks use RCCL ("nccl") on separate devices; on a 1-GPU box two ranks share
+the device and reduce through gloo (device tensors), which still drives the real model, the side-stream section hooks and the
+asynchronous-work / wait ordering."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(backend, world):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 'ddp_worker.py'), backend]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    print(r.stdout[-3000:], r.stderr[-3000:])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert '[ddp_worker]' in r.stdout
+
+
+def test_two_ranks_match_single_process_gradients():
+    if torch.cuda.device_count() >= 2:
+        _run('nccl', 2)
+    else:
+        _run('gloo', 2)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs >= 2 GPUs for an RCCL world')
+def test_bench_spawns_its_own_ranks():
+    ''' `python bench.py --gpus 2` with no launcher must come back with n_gpus == 2 (the RCCL world size) '''
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2', '--batch', '8',
+                        '--no-cpu-baseline', '--no-probe'], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['global_batch'] == 16

@@ -167,3 +167,38 @@ class SyntheticUtterances(Dataset):
 def synthetic_batch(hparams, batch_size, seed=1234, **kw):
     ds = SyntheticUtterances(hparams, batch_size, seed=seed, **kw)
     return DaftExprtDataCollate(hparams)([ds[i] for i in range(batch_size)])
+
+
+def synthetic_inference_batch(hparams, batch_size, seed=1234, l_range=(40, 160), t_ref_range=(250, 1000), mean_symbol_s=0.08):
+    ''' collated inputs of `DaftExprt.inference` for BASELINE configs[3]: L ~ U{l_range}, sorted descending like
+        `generate.collate_tensors`; reference prosody T_ref ~ U{t_ref_range} with the statistics of `SyntheticUtterances`;
+        energy factors 1, pitch shift 0 ('add'); duration factors scaled so that a predictor centred on `mean_symbol_s`
+        seconds per symbol keeps every utterance below ~1000 frames.  Returns the 10-tuple of CPU tensors. '''
+    rng = np.random.RandomState(seed)
+    B, n_mel = batch_size, hparams.n_mel_channels
+    L = np.sort(rng.randint(l_range[0], l_range[1] + 1, size=B))[::-1].copy()
+    Tr = rng.randint(t_ref_range[0], t_ref_range[1] + 1, size=B)
+    Lm, Tm = int(L.max()), int(Tr.max())
+    symbols = torch.zeros(B, Lm, dtype=torch.long)
+    dur_f = torch.ones(B, Lm)
+    e_ref, p_ref, m_ref = torch.zeros(B, Tm), torch.zeros(B, Tm), torch.zeros(B, n_mel, Tm)
+    fps = float(hparams.sampling_rate) / float(hparams.hop_length)
+    for b in range(B):
+        symbols[b, :L[b]] = torch.from_numpy(rng.randint(1, hparams.n_symbols, size=L[b]))
+        dur_f[b, :L[b]] = min(1., 1000. / (L[b] * mean_symbol_s * fps * 1.15))
+        e_ref[b, :Tr[b]] = torch.from_numpy(rng.uniform(0, 60, size=Tr[b]).astype(np.float32))
+        p_ref[b, :Tr[b]] = torch.from_numpy(np.where(rng.rand(Tr[b]) < 0.3, 0., rng.randn(Tr[b]) * 0.3 + 5.).astype(np.float32))
+        m_ref[b, :, :Tr[b]] = torch.from_numpy(np.clip(rng.randn(n_mel, Tr[b]) * 2 - 5, np.log(1e-5), 2.).astype(np.float32))
+    return (symbols, dur_f, torch.ones(B, Lm), torch.zeros(B, Lm), torch.from_numpy(L), e_ref, p_ref, m_ref,
+            torch.from_numpy(Tr), torch.from_numpy(rng.randint(0, max(1, hparams.n_speakers - 1), size=B)))
+
+
+def centre_duration_head(model, mean_symbol_s=0.08):
+    ''' random-init weights predict arbitrary durations (utterances of > 2000 frames): scale the duration row of
+        the predictor's projection down and centre its bias on `mean_symbol_s` so that synthetic synthesis runs have
+        realistic lengths.  Bench / test helper only. '''
+    with torch.no_grad():
+        model._P['prosody_predictor.projection.linear_layer.weight'][0].mul_(0.05)
+        model._P['prosody_predictor.projection.linear_layer.bias'].copy_(
+            torch.tensor([mean_symbol_s, 0., 0.], device=model._flat.device))
+        model.mark_updated()

@@ -194,6 +194,7 @@ class DaftExprt(nn.Module):
         self._plan_min_rows = int(__import__('os').environ.get('DX_PLAN_MIN_ROWS', '0'))
         self._plan_k1 = bool(int(__import__('os').environ.get('DX_PLAN_K1', '0')))   # balanced tiles also for the k = 1 QKV data gradient + LayerNorm backward (measured: 8.78 vs 8.74 ms)
         self._step_id, self._site, self._rank = 0, 0, 0
+        self._trace = None    # tests set this to a list: every stage appends (kind, names, input, film, lengths, output)
         self._pos = None
         self.n_params = sum(int(np.prod(s)) for _, s, _ in self._table)
         self._gemm_weights = [n for n, s, _ in self._table if
@@ -390,6 +391,8 @@ class DaftExprt(nn.Module):
             s.pre, s.cfg, s.x, s.film, s.lengths = pre, cfg, xin, film, lengths
             s.qkv, s.o, s.lse, s.s1, s.mean1, s.rstd1, s.a, s.h, s.s2, s.mean2, s.rstd2 = qkv, o, lse, s1, mean1, rstd1, ain, h, s2, mean2, rstd2
             s.seeds, s.p_attn, s.p_conv = seeds, p_attn, p_conv
+        if self._trace is not None:
+            self._trace.append(('fft_block', pre, x, film, lengths, (a, u)))
         return u, u_lp, s
 
     def _conv_ln_fwd(self, W, conv_name, ln_name, x, p_drop, out_dtype, save, film=None, lengths=None, skip=None):
@@ -406,6 +409,8 @@ class DaftExprt(nn.Module):
             s = _Saved()
             s.conv_name, s.ln_name, s.x, s.c, s.mean, s.rstd, s.p, s.seed, s.film, s.lengths, s.skip = \
                 conv_name, ln_name, x, c, mean, rstd, p_drop, seed, film, lengths, skip
+        if self._trace is not None:
+            self._trace.append(('conv_ln', (conv_name, ln_name, skip), x, film, lengths, y))
         return y, s
 
     def _prosody_encoder_fwd(self, W, frames_energy, frames_pitch, mel_specs, speaker_ids, output_lengths, train, save):
@@ -502,6 +507,8 @@ class DaftExprt(nn.Module):
             blocks.append(sb)
         mel = ops.conv1d(x, W[f'{pre}.projection.linear_layer.weight'], P[f'{pre}.projection.linear_layer.bias'],
                          out_dtype=torch.float32, mask_lengths=output_lengths, transposed_out=True, skip_lengths=output_lengths)
+        if self._trace is not None:
+            self._trace.append(('mel_projection', f'{pre}.projection.linear_layer', x, None, output_lengths, mel))
         return mel, (blocks, x)
 
     def _forward(self, inputs, train, save):
