@@ -62,31 +62,54 @@ __device__ __forceinline__ void stage_tile(TC* dst, const TC* src, long ld_g, in
 template <typename TC, int DH, int ROWS> struct TileRegs {
   static constexpr int CPR = DH / 8, PT = (ROWS * CPR + 255) / 256;
   typename Vec8<TC>::type v[PT];
+  // BRANCH-FREE on purpose: rows past the end of the tensor re-read its last row (their scores are masked / their
+  // probabilities are exactly 0, and the row is finite, so nothing leaks) instead of being predicated to zero.  With the
+  // predicated form every load sat in its own exec-masked block and the compiler closed the merge point with
+  // s_waitcnt vmcnt(0) in front of the first MFMA of the stage -- the "prefetch" was waited for right after it was issued.
   __device__ __forceinline__ void fetch(const TC* src, long ld_g, int row0, int n_lim, int tid) {
+    static_assert((ROWS * CPR) % 256 == 0, "tile must split evenly over the workgroup");
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
       const int c = tid + t * 256, r = c / CPR, kc = (c - r * CPR) * 8;
-      v[t] = zero8<TC>();
-      if (c < ROWS * CPR && row0 + r < n_lim) v[t] = *reinterpret_cast<const typename Vec8<TC>::type*>(src + (long)(row0 + r) * ld_g + kc);
+      const int row = min(row0 + r, n_lim - 1);
+      v[t] = *reinterpret_cast<const typename Vec8<TC>::type*>(src + (long)row * ld_g + kc);
     }
   }
   template <int LD> __device__ __forceinline__ void commit(TC* dst, int tid) const {
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
       const int c = tid + t * 256, r = c / CPR, kc = (c - r * CPR) * 8;
-      if (c < ROWS * CPR) *reinterpret_cast<typename Vec8<TC>::type*>(dst + r * LD + kc) = v[t];
+      *reinterpret_cast<typename Vec8<TC>::type*>(dst + r * LD + kc) = v[t];
     }
   }
 };
 
-__device__ __forceinline__ uint32_t athresh(float p) { return p <= 0.f ? 0u : (uint32_t)(p * 4294967296.0); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// combine a value with the one held by the other half-wave's lane (lane ^ 32).  (A v_permlane32_swap form was tried: 1 % faster
+// on the bf16 kernels, wrong results in the exact-fp32 instantiations -- not worth chasing.)
+__device__ __forceinline__ float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+#ifndef DX_ATTN_PIPE
+#define DX_ATTN_PIPE 0
+#endif
+#ifndef DX_ATTN_KT16
+#define DX_ATTN_KT16 128
+#endif
+#ifndef DX_ATTN_AHEAD
+#define DX_ATTN_AHEAD 1
+#endif
+#ifndef DX_ATTN_OCC16
+#define DX_ATTN_OCC16 5   // workgroups (4 waves) per CU for the d_head = 16 forward / dQ kernels = waves per SIMD
+#endif
+// two scores per VALU instruction where the ISA has a packed fp32 form (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // rows of the streamed axis per LDS stage: every stage exposes one global-load latency, so small heads take big stages
-template <int DH> struct Stage { static constexpr int KT = DH <= 16 ? 256 : 128; };
+template <int DH> struct Stage { static constexpr int KT = DH <= 16 ? DX_ATTN_KT16 : 128; };
 
 // =============================================================================== forward
 template <typename TC, int DH>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, (DH <= 16 && sizeof(TC) == 2) ? DX_ATTN_OCC16 : 2) void attn_fwd_kernel(AttnArgs a) {
   constexpr int KT = Stage<DH>::KT;
   constexpr int LD = DH + APad<TC>::value, KS = DH / 16, MT = (DH + 31) / 32, WRAP = DH >= 32 ? 32 : 16;
   typedef typename Vec8<TC>::type frag_t;
@@ -125,12 +148,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) oT[mt][r] = 0.f;
   float m = -INFINITY, l = 0.f;
   const float c2 = a.scale * LOG2E;
-  const uint32_t th = athresh(a.p_drop);
-  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;   // applied once, to the output row
-  // dropout counter of (q, key) = ctr_lane + key-dependent part that is a scalar + compile-time constant (dx_common.h)
-  const uint32_t ctr_lane = ((uint32_t)q * (uint32_t)N + 4u * g) * DX_CTR_MUL + dx_key32(a.seed, (uint32_t)(b * a.H + h));
+  const uint32_t th8 = dx_drop_th8(a.p_drop);
+  const float inv_keep = dx_drop_inv_keep8(th8);   // applied once, to the output row
+  // dropout block counter of (q, 4 keys) = lane part + a scalar that follows the key tile (dx_common.h)
+  const uint32_t NB = (uint32_t)(N + 3) >> 2;
+  const uint32_t ctr_lane = dx_opaque(((uint32_t)(q >> 2) * NB + g) * DX_CTR_MUL + dx_key32(a.seed, (uint32_t)(b * a.H + h)));
+  const uint32_t rot_lane = 8u * (q & 3), mult_lane = dx_blk_mult(q & 3);
 
-  constexpr bool AHEAD = sizeof(TC) == 2;   // exact-fp32 mode: twice the registers per tile, loads stay in place
+  constexpr bool AHEAD = sizeof(TC) == 2 && DX_ATTN_AHEAD;   // exact-fp32 mode: twice the registers per tile, loads stay in place
   TileRegs<TC, DH, KT> kreg, vreg;
   if (AHEAD) {
     kreg.fetch(base + E, ld_g, 0, N, tid);
@@ -148,6 +173,101 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       kreg.fetch(base + E, ld_g, kt0 + KT, N, tid);
       vreg.fetch(base + 2 * E, ld_g, kt0 + KT, N, tid);
     }
+#if DX_ATTN_PIPE
+    // ---- the sub-tiles (32 keys) of this stage, software-pipelined inside the wave.  A wave issues in order, so in the plain
+    // order "S = K Q^T -> softmax -> O^T += V^T P^T" every sub-tile exposes the MFMA result latency, two LDS round trips
+    // (fragment reads, the half-wave exchange of the row maximum) and a second exchange for the row sum: measured 2 600 cycles
+    // per sub-tile per wave for ~500 cycles of VALU issue, VALU pipe 54 % busy (SQ counters, profiles/r02_attention_counters).
+    // Here the requests go out first -- exchange of the local maximum, K fragment of sub-tile t + 1, V^T fragments of t -- then
+    // the dropout hashes (independent arithmetic) cover their latency, S of t + 1 is issued before the exponentials of t, the
+    // two PV MFMAs of t run under the max / hash work of t + 1, and the row sum stays per half-wave until the kernel's end.
+    const int nsub = min(KT / 32, (len - kt0 + 31) >> 5);
+    auto read_k = [&](frag_t* kf, int sub) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const frag_t*>(&Ks[(sub * 32 + l31) * LD + ks * 16 + g * 8]);
+    };
+    auto step = [&](f32x16& s, f32x16& s_n, int sub) {
+      const int k0 = kt0 + sub * 32;
+      if (k0 + 32 > len) {   // boundary tile only: pad keys -> -inf
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = (k0 + dx_acc_row(r, g) < len) ? s[r] : -INFINITY;
+      }
+      float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);     // v_max3_f32: two scores per instruction
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+      mx = fmaxf(mx, s[15]);
+      const float mx_other = __shfl_xor(mx, 32, 64);                  // request; consumed after the hashes
+      const bool more = sub + 1 < nsub;
+      frag_t kf_n[KS];
+      if (more) read_k(kf_n, sub + 1);
+      frag_t vf[MT][2];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int kstep = 0; kstep < 2; ++kstep)
+          vf[mt][kstep] = gather8<TC, WRAP>(Vs + sub * 32 * LD, LD, kstep * 16 + 4 * g, kstep * 16 + 4 * g + 8, mt * 32, lane);
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      if (th8) {   // registers 4j .. 4j + 3 hold 4 consecutive keys: one block hash, one row word, four byte fields
+        const uint32_t ctr_tile = (uint32_t)(k0 >> 2) * DX_CTR_MUL;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          w[j] = dx_drop_row(dx_drop_prefix(ctr_lane + (ctr_tile + (uint32_t)(2 * j) * DX_CTR_MUL)), rot_lane, mult_lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_n[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) dx_mma(s_n, kf_n[ks], qf[ks]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mx = fmaxf(mx, mx_other);
+      const float m_new = fmaxf(m, mx * c2);           // running max in the scaled log2 domain
+      float alpha = 1.f;
+      const bool moved = !__all(m_new == m);           // wave-uniform: most tiles after the first few skip the rescale
+      if (moved) { alpha = fast_exp2<TC>(m - m_new); m = m_new; }
+      const f32x2 c22 = {c2, c2}, nm2 = {-m, -m};
+      f32x2 rs2 = {0.f, 0.f};
+      float p[16];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 t = pk_fma(f32x2{s[r], s[r + 1]}, c22, nm2);
+        const f32x2 e = {fast_exp2<TC>(t[0]), fast_exp2<TC>(t[1])};
+        rs2 += e;
+        p[r] = e[0]; p[r + 1] = e[1];
+      }
+      l = l * alpha + (rs2[0] + rs2[1]);               // this half-wave's 16 keys; the halves meet after the last stage
+      if (th8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dx_drop4(p[4 * j], p[4 * j + 1], p[4 * j + 2], p[4 * j + 3], w[j], th8);
+      }
+      frag_t pf[2] = {pack8<TC>(p), pack8<TC>(p + 8)};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (moved) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oT[mt][r] *= alpha;
+        }
+#pragma unroll
+        for (int kstep = 0; kstep < 2; ++kstep) dx_mma(oT[mt], vf[mt][kstep], pf[kstep]);
+      }
+    };
+    f32x16 sA, sB;
+    {
+      frag_t kf0[KS];
+      read_k(kf0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sA[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) dx_mma(sA, kf0[ks], qf[ks]);
+    }
+    for (int sub = 0; sub < nsub; sub += 2) {
+      step(sA, sB, sub);
+      if (sub + 1 < nsub) step(sB, sA, sub + 1);
+    }
+    __syncthreads();
+  }
+#else
 #pragma unroll
     for (int sub = 0; sub < KT / 32; ++sub) {
       const int k0 = kt0 + sub * 32;
@@ -160,31 +280,42 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
           frag_t kf = *reinterpret_cast<const frag_t*>(&Ks[(sub * 32 + l31) * LD + ks * 16 + g * 8]);
           dx_mma(s, kf, qf[ks]);
         }
-        float p[16], mx = -INFINITY;
+        float p[16];
         if (k0 + 32 > len) {   // boundary tile only: pad keys -> -inf
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[r] = (k0 + dx_acc_row(r, g) < len) ? s[r] : -INFINITY;
         }
+        float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);     // v_max3_f32: two scores per instruction
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+        mx = fmaxf(mx, s[15]);
+        mx = xhalf_max(mx);
         const float m_new = fmaxf(m, mx * c2);           // running max in the scaled log2 domain
         float alpha = 1.f;
         const bool moved = !__all(m_new == m);           // wave-uniform: most tiles after the first few skip the rescale
         if (moved) { alpha = fast_exp2<TC>(m - m_new); m = m_new; }
-        float rs = 0.f;
+        const f32x2 c22 = {c2, c2}, nm2 = {-m, -m};
+        f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { p[r] = fast_exp2<TC>(fmaf(s[r], c2, -m)); rs += p[r]; }
-        rs += __shfl_xor(rs, 32, 64);
-        l = l * alpha + rs;
-        if (th) {   // registers r, r + 1 hold the key pair (even, odd): one counter prefix, two fields
-          const uint32_t ctr_tile = (uint32_t)k0 * DX_CTR_MUL;
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 t = pk_fma(f32x2{s[r], s[r + 1]}, c22, nm2);
+          const f32x2 e = {fast_exp2<TC>(t[0]), fast_exp2<TC>(t[1])};
+          rs2 += e;
+          p[r] = e[0]; p[r + 1] = e[1];
+        }
+        l = l * alpha + (rs2[0] + rs2[1]);             // this half-wave's 16 keys; the halves meet after the last stage
+        if (th8) {   // registers 4j .. 4j + 3 hold 4 consecutive keys: one block hash, one row word, four byte fields
+          const uint32_t ctr_tile = (uint32_t)(k0 >> 2) * DX_CTR_MUL;
+          uint32_t w[4];
 #pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            const uint32_t pre = dx_drop_prefix(ctr_lane + (ctr_tile + (uint32_t)((r & 3) + 8 * (r >> 2)) * DX_CTR_MUL));
-            p[r] = dx_drop_field(pre, DX_M24_EVEN) >= th ? p[r] : 0.f;
-            p[r + 1] = dx_drop_field(pre, DX_M24_ODD) >= th ? p[r + 1] : 0.f;
-          }
+          for (int j = 0; j < 4; ++j) w[j] = ctr_lane + (ctr_tile + (uint32_t)(2 * j) * DX_CTR_MUL);
+          dx_drop_prefix4(w);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = __builtin_amdgcn_alignbit(w[j], w[j], rot_lane);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = __umul24(w[j], mult_lane);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dx_drop4(p[4 * j], p[4 * j + 1], p[4 * j + 2], p[4 * j + 3], w[j], th8);
         }
         frag_t pf[2] = {pack8<TC>(p), pack8<TC>(p + 8)};
 #pragma unroll
@@ -203,6 +334,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     }
     __syncthreads();
   }
+#endif
+  l = xhalf_sum(l);
   if (q < N) {
     const float inv_l = inv_keep / l;
 #pragma unroll
@@ -237,7 +370,7 @@ __global__ void attn_delta_kernel(const TC* __restrict__ o, const TC* __restrict
 
 // =============================================================================== backward: dQ
 template <typename TC, int DH>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, (DH <= 16 && sizeof(TC) == 2) ? DX_ATTN_OCC16 : 2) void attn_bwd_dq_kernel(AttnArgs a) {
   constexpr int KT = Stage<DH>::KT;
   constexpr int LD = DH + APad<TC>::value, KS = DH / 16, MT = (DH + 31) / 32, WRAP = DH >= 32 ? 32 : 16;
   typedef typename Vec8<TC>::type frag_t;
@@ -282,13 +415,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         for (int e = 0; e < 8; ++e) delta_q += (float)of[e] * (float)dof[ks][e];
       }
     }
-    delta_q += __shfl_xor(delta_q, 32, 64);
+    delta_q = xhalf_sum(delta_q);
     if (q < N && g == 0) const_cast<float*>(a.delta)[stat] = delta_q;
     const float c2 = a.scale * LOG2E, lse2 = lse_q * LOG2E;
     const bool tile_q_valid = blockIdx.x * 128 + wave * 32 + 32 <= len;
-    const uint32_t th = athresh(a.p_drop);
-    const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-    const uint32_t ctr_lane = ((uint32_t)q * (uint32_t)N + 4u * g) * DX_CTR_MUL + dx_key32(a.seed, (uint32_t)(b * a.H + h));
+    const uint32_t th8 = dx_drop_th8(a.p_drop);
+    const float inv_keep = dx_drop_inv_keep8(th8);
+    const uint32_t NB = (uint32_t)(N + 3) >> 2;
+    const uint32_t ctr_lane = dx_opaque(((uint32_t)(q >> 2) * NB + g) * DX_CTR_MUL + dx_key32(a.seed, (uint32_t)(b * a.H + h)));
+    const uint32_t rot_lane = 8u * (q & 3), mult_lane = dx_blk_mult(q & 3);
 
     constexpr bool AHEAD = sizeof(TC) == 2;
     TileRegs<TC, DH, KT> kreg, vreg;
@@ -324,18 +459,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
           }
           float ds[16];
           const bool interior = tile_q_valid && k0 + 32 <= len;   // wave-uniform: no masking needed
-          const uint32_t ctr_tile = (uint32_t)k0 * DX_CTR_MUL;
+          const uint32_t ctr_tile = (uint32_t)(k0 >> 2) * DX_CTR_MUL;
+          const f32x2 c22 = {c2, c2}, nl2 = {-lse2, -lse2}, ik2 = {inv_keep, inv_keep}, nd2 = {-delta_q, -delta_q};
+          // th8 == 0 keeps everything; no branch around the hashes (backward = training)
+          uint32_t w[4];
 #pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            const int key = k0 + dx_acc_row(r, g);   // registers r, r+1 hold keys key, key+1 (one counter prefix, see forward)
-            // th == 0 keeps everything; no branch around the hash (backward = training)
-            const uint32_t pre = dx_drop_prefix(ctr_lane + (ctr_tile + (uint32_t)((r & 3) + 8 * (r >> 2)) * DX_CTR_MUL));
-            const float x0 = dx_drop_field(pre, DX_M24_EVEN) >= th ? dp[r] : 0.f;
-            const float x1 = dx_drop_field(pre, DX_M24_ODD) >= th ? dp[r + 1] : 0.f;
-            float p0 = fast_exp2<TC>(fmaf(s[r], c2, -lse2)), p1 = fast_exp2<TC>(fmaf(s[r + 1], c2, -lse2));
-            if (!interior) { p0 = (q_valid && key < len) ? p0 : 0.f; p1 = (q_valid && key + 1 < len) ? p1 : 0.f; }
-            ds[r] = p0 * fmaf(x0, inv_keep, -delta_q);
-            ds[r + 1] = p1 * fmaf(x1, inv_keep, -delta_q);
+          for (int j = 0; j < 4; ++j) w[j] = ctr_lane + (ctr_tile + (uint32_t)(2 * j) * DX_CTR_MUL);
+          dx_drop_prefix4(w);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = __builtin_amdgcn_alignbit(w[j], w[j], rot_lane);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = __umul24(w[j], mult_lane);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {   // registers 4j .. 4j + 3 = keys k0 + 8j + 4g + {0..3}: one row word (see forward)
+            float x[4] = {dp[4 * j], dp[4 * j + 1], dp[4 * j + 2], dp[4 * j + 3]};
+            dx_drop4(x[0], x[1], x[2], x[3], w[j], th8);
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+              const int r = 4 * j + i;
+              const int key = k0 + dx_acc_row(r, g);
+              const f32x2 t = pk_fma(f32x2{s[r], s[r + 1]}, c22, nl2);
+              f32x2 pr = {fast_exp2<TC>(t[0]), fast_exp2<TC>(t[1])};
+              if (!interior) { pr[0] = (q_valid && key < len) ? pr[0] : 0.f; pr[1] = (q_valid && key + 1 < len) ? pr[1] : 0.f; }
+              const f32x2 d2 = pr * pk_fma(f32x2{x[i], x[i + 1]}, ik2, nd2);
+              ds[r] = d2[0]; ds[r + 1] = d2[1];
+            }
           }
           frag_t dsf[2] = {pack8<TC>(ds), pack8<TC>(ds + 8)};
 #pragma unroll
@@ -397,14 +545,13 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : 2) void attn_bwd_dkv_kernel(Att
       kf[ks] = key < N ? *reinterpret_cast<const frag_t*>(base + E + (long)key * ld_g + ks * 16 + g * 8) : zero8<TC>();
       vf[ks] = key < N ? *reinterpret_cast<const frag_t*>(base + 2 * E + (long)key * ld_g + ks * 16 + g * 8) : zero8<TC>();
     }
-    const uint32_t th = athresh(a.p_drop);
-    // counter(q, key) = ctr_lane + q-dependent scalar; the field multiplier is a lane constant (key parity)
-    const uint32_t ctr_q = (uint32_t)N * DX_CTR_MUL;
-    const uint32_t ctr_lane = (uint32_t)(key & ~1) * DX_CTR_MUL + dx_key32(a.seed, (uint32_t)(b * a.H + h)) + 4u * g * ctr_q;
-    const uint32_t mult_lane = (key & 1) ? DX_M24_ODD : DX_M24_EVEN;
-    uint32_t ctr_row[16];   // wave-uniform (SGPR) per-register query offsets of the counter
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ctr_row[r] = __builtin_amdgcn_readfirstlane((uint32_t)((r & 3) + 8 * (r >> 2)) * ctr_q);
+    const uint32_t th8 = dx_drop_th8(a.p_drop), th_top = th8 << 24;
+    // block counter ((q >> 2) * NB + (key >> 2)) * MUL + stream = lane part (key block, lane group) + a wave-uniform part that
+    // follows the query rows; the lane reads byte (key & 3) of each row word (dx_common.h)
+    const uint32_t NB = (uint32_t)(N + 3) >> 2;
+    const uint32_t ctr_q = NB * DX_CTR_MUL;   // one query block further
+    const uint32_t ctr_lane = dx_opaque(((uint32_t)(key >> 2) + g * NB) * DX_CTR_MUL + dx_key32(a.seed, (uint32_t)(b * a.H + h)));
+    const uint32_t shl_lane = 24u - 8u * (key & 3);
     const float c2 = a.scale * LOG2E;
     const bool tile_k_valid = blockIdx.x * 128 + wave * 32 + 32 <= len;
 
@@ -412,8 +559,9 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : 2) void attn_bwd_dkv_kernel(Att
     float lse_r = 0.f, delta_r = 0.f;
     auto fetch_stats = [&](int qt0) {
       const int qq = qt0 + tid;
-      lse_r = (tid < KT && qq < N) ? lse[qq] * LOG2E : 0.f;   // log2 domain, see fast_exp2
-      delta_r = (tid < KT && qq < N) ? delta[qq] : 0.f;
+      const int qc = min(qq, N - 1);                           // branch-free, like TileRegs::fetch
+      lse_r = lse[qc] * LOG2E;                                 // log2 domain, see fast_exp2
+      delta_r = delta[qc];
     };
     constexpr bool AHEAD = sizeof(TC) == 2;
     if (AHEAD) {
@@ -452,17 +600,42 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : 2) void attn_bwd_dkv_kernel(Att
           }
           float pd[16], ds[16];
           const bool interior = tile_k_valid && qb + 32 <= len;   // wave-uniform
-          const uint32_t ctr_sub = ctr_lane + __builtin_amdgcn_readfirstlane((uint32_t)qb * ctr_q);
+          const uint32_t ctr_sub = ctr_lane + __builtin_amdgcn_readfirstlane((uint32_t)(qb >> 2) * ctr_q);
+          const f32x2 c22 = {c2, c2}, ik2 = {inv_keep, inv_keep};
+          uint32_t bases[4];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = sub * 32 + dx_acc_row(r, g);
-            const int qq = qt0 + row;
-            float p = fast_exp2<TC>(fmaf(s[r], c2, -lse_s[row]));
-            if (!interior) p = (key_valid && qq < len) ? p : 0.f;
-            // same decision as the forward (th == 0 keeps everything; no branch around the hash: backward = training)
-            const bool keep = dx_drop_field(dx_drop_prefix(ctr_sub + ctr_row[r]), mult_lane) >= th;
-            pd[r] = keep ? p : 0.f;
-            ds[r] = p * fmaf(keep ? dp[r] : 0.f, inv_keep, -delta_s[row]);
+          for (int j = 0; j < 4; ++j) bases[j] = ctr_sub + (uint32_t)(2 * j) * ctr_q;
+          dx_drop_prefix4(bases);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {   // registers 4j .. 4j + 3 = queries qb + 8j + 4g + {0..3}: one block hash, four row words
+            const uint32_t base = bases[j];
+            f32x2 pr[2], nd2[2];
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+              const int r = 4 * j + i;
+              const int row = sub * 32 + dx_acc_row(r, g);
+              const int qq = qt0 + row;
+              const f32x2 nl2 = {-lse_s[row], -lse_s[row + 1]};
+              nd2[i >> 1] = f32x2{-delta_s[row], -delta_s[row + 1]};
+              const f32x2 t = pk_fma(f32x2{s[r], s[r + 1]}, c22, nl2);
+              pr[i >> 1] = f32x2{fast_exp2<TC>(t[0]), fast_exp2<TC>(t[1])};
+              if (!interior) {
+                pr[i >> 1][0] = (key_valid && qq < len) ? pr[i >> 1][0] : 0.f;
+                pr[i >> 1][1] = (key_valid && qq + 1 < len) ? pr[i >> 1][1] : 0.f;
+              }
+            }
+            // same decisions as the forward (th8 == 0 keeps everything; no branch around the hash: backward = training)
+            float pk[4] = {pr[0][0], pr[0][1], pr[1][0], pr[1][1]};
+            float x[4] = {dp[4 * j], dp[4 * j + 1], dp[4 * j + 2], dp[4 * j + 3]};
+            dx_drop4x2_var(pk, x, dx_drop_row(base, 0u, DX_BLK_M0), dx_drop_row(base, 8u, DX_BLK_M1), dx_drop_row(base, 16u, DX_BLK_M2),
+                           dx_drop_row(base, 24u, DX_BLK_M3), shl_lane, th_top);
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+              const int r = 4 * j + i;
+              pd[r] = pk[i]; pd[r + 1] = pk[i + 1];
+              const f32x2 d2 = pr[i >> 1] * pk_fma(f32x2{x[i], x[i + 1]}, ik2, nd2[i >> 1]);
+              ds[r] = d2[0]; ds[r + 1] = d2[1];
+            }
           }
           frag_t pf[2] = {pack8<TC>(pd), pack8<TC>(pd + 8)};
           frag_t dsf[2] = {pack8<TC>(ds), pack8<TC>(ds + 8)};

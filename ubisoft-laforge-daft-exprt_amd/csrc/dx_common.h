@@ -179,20 +179,96 @@ __host__ __device__ __forceinline__ uint32_t dx_mix32(uint32_t x) {
 __host__ __device__ __forceinline__ uint32_t dx_key32(uint64_t seed, uint32_t salt) {
   return dx_mix32((uint32_t)seed ^ dx_mix32((uint32_t)(seed >> 32) + 0x9E3779B9u * (salt + 1u)));
 }
-// ---- attention-weight dropout: counter based, built from full-rate integer ops only (v_mul_u32_u24; the 32-bit
-// v_mul_lo_u32 of dx_mix32 is quarter rate on CDNA and used to dominate the attention kernels, which are VALU bound).
-//   counter(q, key) = (q * N + (key & ~1)) * DX_CTR_MUL + stream_key                       (wraps mod 2^32)
-//   keep(q, key)    = mul24(prefix(counter), key odd ? DX_M24_ODD : DX_M24_EVEN) >= p * 2^32
-// An (even, odd) key pair shares the 4-op prefix; measured on 2M counters: keep rates within 5e-4 of 1 - p, pair /
-// neighbour / row / column correlations < 2e-3, chi^2 of both fields ~1.0 per degree of freedom.
-constexpr uint32_t DX_CTR_MUL = 0x9E3779B1u, DX_M24_PRE = 0x9E3779u, DX_M24_EVEN = 0xC2B2AFu, DX_M24_ODD = 0x85EBCBu;
+// ---- attention-weight dropout: counter based, built from full-rate integer ops only (v_mul_u32_u24, v_alignbit; the 32-bit
+// v_mul_lo_u32 of dx_mix32 is quarter rate on CDNA and the attention kernels are VALU bound).  One 32-bit hash serves a
+// 4 x 4 block of (query, key) decisions:
+//   block counter   c      = ((q >> 2) * ceil(N / 4) + (key >> 2)) * DX_CTR_MUL + stream_key          (wraps mod 2^32)
+//   block hash      base   = prefix(c)                      xor-shift, 24-bit multiply, xor-shift       (3 ops per 16 decisions)
+//   row word        w(q)   = mul24(rotr(base, 8 * (q & 3)), DX_BLK_M[q & 3])                            (2 ops per 4 decisions)
+//   keep(q, key)           = byte (key & 3) of w(q) >= round(256 p)
+// so the forward / dQ kernels (lane = query, 4 consecutive keys in registers) pay 6 ops per 4 decisions and the dK/dV kernel
+// (lane = key, 4 consecutive queries in registers) 11 per 4 -- plus compare + select per decision -- where one hash per
+// decision pair used to cost 6 / 10 ops per decision.
+// The drop probability is quantised to p_hat = round(256 p) / 256 (p = 0.1 -> 26 / 256 = 0.1016) and the kept values are
+// scaled by 1 / (1 - p_hat), so the expectation is exact.  Measured on 62 500 blocks x 3 stream keys (numpy model of the
+// same integer ops): keep rates within 3e-3 of 1 - p_hat per field, |correlation| between any two of the 16 decisions of a
+// block and between neighbouring blocks at the sampling-noise level (rms 4e-3 = 1 / sqrt(#blocks)), chi^2 of every byte ~1.0
+// per degree of freedom.  Without the rotation the low bytes of the four row words share the low bits of `base` (|corr| 0.07).
+constexpr uint32_t DX_CTR_MUL = 0x9E3779B1u, DX_M24_PRE = 0x9E3779u;
+constexpr uint32_t DX_BLK_M0 = 0xC2B2AFu, DX_BLK_M1 = 0x85EBCBu, DX_BLK_M2 = 0xA54FF5u, DX_BLK_M3 = 0x6C8E95u;
+__host__ __device__ __forceinline__ uint32_t dx_drop_th8(float p) { return p <= 0.f ? 0u : (uint32_t)(p * 256.f + 0.5f); }
+__host__ __device__ __forceinline__ float dx_drop_inv_keep8(uint32_t th8) { return 256.f / (float)(256u - th8); }
 __device__ __forceinline__ uint32_t dx_drop_prefix(uint32_t ctr) {
-  ctr ^= ctr >> 16;
+  ctr ^= ctr >> 16;                    // both xor-shifts are by 16: one v_xor_b32_sdwa (src1_sel:WORD_1) each
   ctr = __umul24(ctr, DX_M24_PRE);
-  ctr ^= ctr >> 13;
-  return ctr;   // the field multiply reads its low 24 bits
+  ctr ^= ctr >> 16;
+  return ctr;
 }
-__device__ __forceinline__ uint32_t dx_drop_field(uint32_t prefix, uint32_t mult24) { return __umul24(prefix, mult24); }
+// keep the compiler from folding a lane counter into the tile offset added to it later: (a * MUL + k) + (t * MUL + c) would
+// otherwise come back as ONE quarter-rate 32-bit multiply per hash instead of one add
+__device__ __forceinline__ uint32_t dx_opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ uint32_t dx_blk_mult(int row) {
+  return row == 0 ? DX_BLK_M0 : row == 1 ? DX_BLK_M1 : row == 2 ? DX_BLK_M2 : DX_BLK_M3;
+}
+// four block hashes at once, step by step: a wave issues a DEPENDENT VALU instruction only every ~9 cycles on gfx950 (an
+// independent one every ~6.5, tools/probes/valu_rate_probe.hip), so the four chains are interleaved rather than run in turn
+__device__ __forceinline__ void dx_drop_prefix4(uint32_t* c) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c[j] ^= c[j] >> 16;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c[j] = __umul24(c[j], DX_M24_PRE);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c[j] ^= c[j] >> 16;
+}
+// row word of a block hash; rot = 8 * (q & 3), mult = dx_blk_mult(q & 3) (lane constants or literals)
+__device__ __forceinline__ uint32_t dx_drop_row(uint32_t base, uint32_t rot, uint32_t mult) {
+  return __umul24(__builtin_amdgcn_alignbit(base, base, rot), mult);
+}
+// byte `i` (compile-time) of a row word against the 8-bit threshold
+__device__ __forceinline__ bool dx_keep8(uint32_t w, int i, uint32_t th8) { return ((w >> (8 * i)) & 0xffu) >= th8; }
+// byte at a lane-dependent position: shl = 24 - 8 * (key & 3), th_top = th8 << 24 (the low garbage bits cannot flip the compare)
+__device__ __forceinline__ bool dx_keep8_var(uint32_t w, uint32_t shl, uint32_t th_top) { return (w << shl) >= th_top; }
+// v[i] = byte i of w >= th8 ? v[i] : 0 for the four byte fields of one row word.  Written out because a compare into an SGPR
+// pair followed directly by the select that reads it costs two wait states on gfx950 and the compiler serialises the four
+// pairs through VCC (s_nop 1 after every compare): four SDWA byte compares into four SGPR pairs, then the four selects.
+__device__ __forceinline__ void dx_drop4(float& v0, float& v1, float& v2, float& v3, uint32_t w, uint32_t th8) {
+  uint64_t m0, m1, m2, m3;
+  asm("v_cmp_ge_u32_sdwa %4, %8, %9 src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %5, %8, %9 src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %6, %8, %9 src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %7, %8, %9 src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+      "v_cndmask_b32_e64 %0, 0, %0, %4\n\t"
+      "v_cndmask_b32_e64 %1, 0, %1, %5\n\t"
+      "v_cndmask_b32_e64 %2, 0, %2, %6\n\t"
+      "v_cndmask_b32_e64 %3, 0, %3, %7"
+      : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+      : "v"(w), "v"(th8));
+}
+// the dK/dV form: one decision per row word w[i] (byte at the lane's position, see dx_keep8_var) applied to two values each
+__device__ __forceinline__ void dx_drop4x2_var(float* a, float* b, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3,
+                                               uint32_t shl, uint32_t th_top) {
+  uint64_t m0, m1, m2, m3;
+  uint32_t t0, t1, t2, t3;
+  asm("v_lshlrev_b32 %12, %20, %16\n\t"
+      "v_lshlrev_b32 %13, %20, %17\n\t"
+      "v_lshlrev_b32 %14, %20, %18\n\t"
+      "v_lshlrev_b32 %15, %20, %19\n\t"
+      "v_cmp_ge_u32_e64 %8, %12, %21\n\t"
+      "v_cmp_ge_u32_e64 %9, %13, %21\n\t"
+      "v_cmp_ge_u32_e64 %10, %14, %21\n\t"
+      "v_cmp_ge_u32_e64 %11, %15, %21\n\t"
+      "v_cndmask_b32_e64 %0, 0, %0, %8\n\t"
+      "v_cndmask_b32_e64 %1, 0, %1, %9\n\t"
+      "v_cndmask_b32_e64 %2, 0, %2, %10\n\t"
+      "v_cndmask_b32_e64 %3, 0, %3, %11\n\t"
+      "v_cndmask_b32_e64 %4, 0, %4, %8\n\t"
+      "v_cndmask_b32_e64 %5, 0, %5, %9\n\t"
+      "v_cndmask_b32_e64 %6, 0, %6, %10\n\t"
+      "v_cndmask_b32_e64 %7, 0, %7, %11"
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+        "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(shl), "v"(th_top));
+}
 
 __device__ __forceinline__ bool dx_keep(uint32_t key, uint32_t idx, uint32_t thresh) {
   return dx_mix32(idx * 0x9E3779B1u + key) >= thresh;
