@@ -1691,6 +1691,9 @@ extern "C" int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const vo
              "dx_conv1d_wgrad: Cin, Cout and the row strides must be multiples of 8");
   DX_REQUIRE(taps == 1 || taps == 3, DX_ERR_UNSUPPORTED, "dx_conv1d_wgrad: taps=%d (only 1 and 3)", taps);
   static int dbg = getenv("DX_WGRAD_DEBUG") ? atoi(getenv("DX_WGRAD_DEBUG")) : 0;
+  // k = 1 weight gradients (QKV / output projections, 16 k - 49 k elements): partial tiles + reduce launch, or fp32 atomics on dW
+  static int k1_atomic = getenv("DX_WGRAD_K1_ATOMIC") ? atoi(getenv("DX_WGRAD_K1_ATOMIC")) : 0;
+  if (taps == 1 && k1_atomic) ws = nullptr;
   WgradArgs a{dy, lddy, x, ldx, dw, db, lengths, ws, B, N, Cin, Cout, wgrad_nsplit(B, N, Cin, Cout, taps), dx_cdiv(Cin, WG_CI), dbg};
   hipStream_t s = (hipStream_t)stream;
   if (compute_dtype == DX_BF16) {

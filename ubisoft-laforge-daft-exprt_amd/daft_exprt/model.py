@@ -191,6 +191,7 @@ class DaftExprt(nn.Module):
         self.fuse_ln_backward = bool(int(__import__('os').environ.get('DX_FUSE_LN_BWD', '1')))   # see _fft_block_bwd
         self.balanced_tiles = bool(int(__import__('os').environ.get('DX_BALANCED_TILES', '1')))   # see _plan
         self._plans = {}
+        self.ff_fused = bool(int(__import__('os').environ.get('DX_FF_FUSED', '0')))   # K2: both FF convs + LayerNorm in one launch (bf16); opt-in, see DESIGN
         self._plan_min_rows = int(__import__('os').environ.get('DX_PLAN_MIN_ROWS', '0'))
         self._plan_k1 = bool(int(__import__('os').environ.get('DX_PLAN_K1', '0')))   # balanced tiles also for the k = 1 QKV data gradient + LayerNorm backward (measured: 8.78 vs 8.74 ms)
         self._step_id, self._site, self._rank = 0, 0, 0
@@ -301,6 +302,14 @@ class DaftExprt(nn.Module):
             hit = self._plans[key] = (lengths, ops.conv_tile_plan(lengths, N))
         return hit[1]
 
+    def _ff_plan(self, lengths, N):
+        ''' tile table of the fused feed-forward kernel (`ops.ff_plan`), one per distinct lengths tensor per step '''
+        key = ('ff', lengths.data_ptr(), N)
+        hit = self._plans.get(key)
+        if hit is None or hit[0] is not lengths:
+            hit = self._plans[key] = (lengths, ops.ff_plan(lengths, N))
+        return hit[1]
+
     def set_rank(self, rank):
         ''' data-parallel rank of this replica: folded into every dropout seed so that the ranks draw independent masks
             (torch's per-process Philox streams in the reference are independent as well) '''
@@ -381,12 +390,20 @@ class DaftExprt(nn.Module):
                                                   P[f'{a_pre}.layer_norm.bias'], lengths, save=save, p_pre=p_attn, seed_pre=seeds[1],
                                                   lp_copy=lp)
         ain = a_lp if lp else a
-        h = ops.conv1d(ain, W[f'{f_pre}.convs.0.conv.weight'], P[f'{f_pre}.convs.0.conv.bias'], out_dtype=cd, relu=True,
-                       skip_lengths=lengths)
-        # second FF conv + Dropout + residual + LayerNorm + FiLM + mask in ONE launch
-        u, u_lp, s2, mean2, rstd2 = ops.conv1d_ln(h, W[f'{f_pre}.convs.2.conv.weight'], P[f'{f_pre}.convs.2.conv.bias'], a,
-                                                  P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'], lengths, film=film,
-                                                  save=save, p_pre=p_conv, seed_pre=seeds[2], lp_copy=lp, plan=self._plan(lengths, x.shape[1]))
+        if lp and self.ff_fused and lengths is not None and cfg['conv_channels'] % 64 == 0 and cfg['conv_kernel'] == 3:
+            # K2: conv1 -> ReLU -> conv2 -> Dropout -> residual -> LayerNorm -> FiLM -> mask in ONE launch; the hidden
+            # tensor is written once for the backward pass and never read back in the forward pass
+            u, u_lp, s2, mean2, rstd2, h = ops.ff_fused_fwd(
+                ain, W[f'{f_pre}.convs.0.conv.weight'], P[f'{f_pre}.convs.0.conv.bias'], W[f'{f_pre}.convs.2.conv.weight'],
+                P[f'{f_pre}.convs.2.conv.bias'], a, P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'], lengths,
+                self._ff_plan(lengths, x.shape[1]), film=film, save=save, p_pre=p_conv, seed_pre=seeds[2], lp_copy=True)
+        else:
+            h = ops.conv1d(ain, W[f'{f_pre}.convs.0.conv.weight'], P[f'{f_pre}.convs.0.conv.bias'], out_dtype=cd, relu=True,
+                           skip_lengths=lengths)
+            # second FF conv + Dropout + residual + LayerNorm + FiLM + mask in ONE launch
+            u, u_lp, s2, mean2, rstd2 = ops.conv1d_ln(h, W[f'{f_pre}.convs.2.conv.weight'], P[f'{f_pre}.convs.2.conv.bias'], a,
+                                                      P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'], lengths, film=film,
+                                                      save=save, p_pre=p_conv, seed_pre=seeds[2], lp_copy=lp, plan=self._plan(lengths, x.shape[1]))
         if save:
             s.pre, s.cfg, s.x, s.film, s.lengths = pre, cfg, xin, film, lengths
             s.qkv, s.o, s.lse, s.s1, s.mean1, s.rstd1, s.a, s.h, s.s2, s.mean2, s.rstd2 = qkv, o, lse, s1, mean1, rstd1, ain, h, s2, mean2, rstd2
