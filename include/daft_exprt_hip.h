@@ -235,6 +235,15 @@ int dx_gather_add_bwd(const float* dz, const int64_t* ids, float* dtable, int B,
 int dx_add_inplace(float* dst, const float* src, long n, void* stream);           /* dst += src */
 int dx_colsum(const void* x, int dtype, float* out, long rows, int C, void* stream); /* out[c] += sum_r x[r][c] (bias grads) */
 int dx_scale(float* x, long n, float s, void* stream);
+/* Layout helpers (the reference gets these from ATen views / copies around its modules):
+ *   dx_transpose_last2: (B, R, C) -> (B, C, R) fp32 -- the mel batch arrives as (B, n_mel, T) (model.py:744), kernels want rows;
+ *   dx_unstack / dx_stack: y (M, K) interleaved <-> K planes of M floats, K <= 4 -- the duration / energy / pitch heads share one
+ *   projection (model.py:567-575);  planes = host array of K device pointers;
+ *   dx_fill_zero: stream-ordered memset of a device buffer. */
+int dx_transpose_last2(const float* x, float* y, int B, int R, int C, void* stream);
+int dx_unstack(const float* y, float* const* planes, long M, int K, void* stream);
+int dx_stack(float* y, const float* const* planes, long M, int K, void* stream);
+int dx_fill_zero(void* p, size_t bytes, void* stream);
 
 /* ---- K11: Gaussian upsampling (GaussianUpsamplingModule.forward, model.py:608-662), fp32, integer prefix sums exact.
  * dx_gu_prepare : xp = enc + conv(energy) + conv(pitch); rin = xp + conv(dur_float); r_pre = w_range . rin + b_range;

@@ -316,6 +316,37 @@ inline int grid_for(long total, int block = 256, int cap = 4096) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+
+// ---- layout helpers that used to be ATen copies on the step path ---------------------------------------------------------
+// (B, R, C) -> (B, C, R) through a 32 x 33 LDS tile: coalesced on both sides.  The reference hands the mel batch over as
+// (B, n_mel, T) (model.py:744) while every kernel here wants channel-last rows; the loss gradient of the autograd bridge
+// comes back the same way.
+__global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int C) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* xb = x + (size_t)b * R * C;
+  float* yb = y + (size_t)b * R * C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    if (r < R && c < C) tile[ty + 8 * i][tx] = xb[(size_t)r * C + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (r < R && c < C) yb[(size_t)c * R + r] = tile[tx][ty + 8 * i];
+  }
+}
+// K interleaved planes <-> K separate planes: y (M, K) <-> a_k (M)   (K <= 4: the three prosody heads share one projection)
+struct PlaneArgs { float* planes[4]; };
+__global__ __launch_bounds__(256) void unstack_kernel(const float* __restrict__ y, PlaneArgs a, long M, int K) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < M * K; i += (long)gridDim.x * 256) a.planes[i % K][i / K] = y[i];
+}
+__global__ __launch_bounds__(256) void stack_kernel(float* __restrict__ y, PlaneArgs a, long M, int K) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < M * K; i += (long)gridDim.x * 256) y[i] = a.planes[i % K][i / K];
+}
 }  // namespace
 
 extern "C" int dx_scalar_embed_fwd(const float* base, const float* const* feats, const float* const* ws,
@@ -470,5 +501,37 @@ extern "C" int dx_gather_add_bwd(const float* dz, const int64_t* ids, float* dta
   DX_REQUIRE(dz && ids && dtable && B > 0 && C > 0, DX_ERR_ARG, "dx_gather_add_bwd: bad arguments");
   hipLaunchKernelGGL(gather_add_bwd_kernel, dim3(dx_cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, dz, ids, dtable, B, C);
   DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_transpose_last2(const float* x, float* y, int B, int R, int C, void* stream) {
+  DX_REQUIRE(x && y && B > 0 && R > 0 && C > 0, DX_ERR_ARG, "dx_transpose_last2: bad arguments");
+  hipLaunchKernelGGL(transpose_last2_kernel, dim3(dx_cdiv(C, 32), dx_cdiv(R, 32), B), dim3(256), 0, (hipStream_t)stream, x, y, R, C);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_unstack(const float* y, float* const* planes, long M, int K, void* stream) {
+  DX_REQUIRE(y && planes && M > 0 && K > 0 && K <= 4, DX_ERR_ARG, "dx_unstack: bad arguments (K <= 4)");
+  PlaneArgs a{};
+  for (int k = 0; k < K; ++k) { DX_REQUIRE(planes[k], DX_ERR_ARG, "dx_unstack: null plane"); a.planes[k] = planes[k]; }
+  hipLaunchKernelGGL(unstack_kernel, dim3(grid_for(M * K)), dim3(256), 0, (hipStream_t)stream, y, a, M, K);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_stack(float* y, const float* const* planes, long M, int K, void* stream) {
+  DX_REQUIRE(y && planes && M > 0 && K > 0 && K <= 4, DX_ERR_ARG, "dx_stack: bad arguments (K <= 4)");
+  PlaneArgs a{};
+  for (int k = 0; k < K; ++k) { DX_REQUIRE(planes[k], DX_ERR_ARG, "dx_stack: null plane"); a.planes[k] = const_cast<float*>(planes[k]); }
+  hipLaunchKernelGGL(stack_kernel, dim3(grid_for(M * K)), dim3(256), 0, (hipStream_t)stream, y, a, M, K);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_fill_zero(void* p, size_t bytes, void* stream) {
+  DX_REQUIRE(p || bytes == 0, DX_ERR_ARG, "dx_fill_zero: null pointer");
+  if (bytes == 0) return DX_OK;
+  if (hipMemsetAsync(p, 0, bytes, (hipStream_t)stream) != hipSuccess) { dx_set_error("dx_fill_zero: hipMemsetAsync failed"); return DX_ERR_LAUNCH; }
   return DX_OK;
 }

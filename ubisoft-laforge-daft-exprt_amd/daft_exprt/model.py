@@ -242,7 +242,10 @@ class DaftExprt(nn.Module):
     def zero_grad(self, set_to_none=False):
         if self._gflat is None:
             return super(DaftExprt, self).zero_grad(set_to_none)
-        self._gflat.zero_()
+        if self._gflat.is_cuda:
+            ops.H.check(ops.H.lib().dx_fill_zero(ops.H.ptr(self._gflat), self._gflat.numel() * 4, ops.H.stream()))
+        else:
+            self._gflat.zero_()
         for name, p in self._params.items():   # an external optimizer may have dropped the views
             if p.grad is None or p.grad.data_ptr() != self._G[name].data_ptr():
                 p.grad = self._G[name]
@@ -435,7 +438,7 @@ class DaftExprt(nn.Module):
         P, hp, cfg, pre = self._P, self.hp, self.hp.prosody_encoder, 'prosody_encoder'
         p_conv = cfg['conv_dropout'] if train else 0.
         s = _Saved()
-        x = mel_specs.transpose(1, 2).contiguous()   # (B, T, n_mel) channel-last view of the input batch
+        x = ops.transpose_last2(mel_specs)   # (B, T, n_mel) channel-last rows of the input batch
         wide = self.cd
         l1, s.c1 = self._conv_ln_fwd(W, f'{pre}.convs.0', f'{pre}.convs.2', x, p_conv, wide, save, skip=output_lengths)
         l2, s.c2 = self._conv_ln_fwd(W, f'{pre}.convs.4', f'{pre}.convs.6', l1, p_conv, wide, save, skip=output_lengths)
@@ -545,7 +548,7 @@ class DaftExprt(nn.Module):
         dec_in, weights, _, s_gu = self._upsample_fwd(enc, durations_float, durations_int, symbols_energy, symbols_pitch,
                                                       input_lengths, output_lengths, T, save)
         mel, s_dec = self._decoder_fwd(W, dec_in, films[2], output_lengths, train, save)
-        dur, energy, pitch = y[:, :, 0].contiguous(), y[:, :, 1].contiguous(), y[:, :, 2].contiguous()
+        dur, energy, pitch = ops.unstack(y, 3)
         if save:
             S.pe, S.cls, S.enc, S.pp, S.gu, S.dec, S.films, S.symbols, S.input_lengths, S.enc_out, S.x_mel = \
                 s_pe, s_cls, s_enc, s_pp, s_gu, s_dec, films, symbols, input_lengths, enc, mel_specs
@@ -686,7 +689,7 @@ class DaftExprt(nn.Module):
         W = self._packed
         dev = S.enc_out.device
         B, L = S.symbols.shape
-        zeros = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        zeros = lambda *shape: ops.zeros(shape, dev)
         layout = film_layout(hp)
         dfilms = [zeros(B, nb, 2 * ch) for nb, ch in layout]
         # ---- decoder
@@ -695,7 +698,7 @@ class DaftExprt(nn.Module):
         if d_mel is None:
             d_dec = zeros(*dec_x.shape)
         else:
-            d_mel_bt = d_mel if d_mel_is_bt else d_mel.transpose(1, 2).contiguous()
+            d_mel_bt = d_mel if d_mel_is_bt else ops.transpose_last2(d_mel.contiguous())
             wname = f'{pre}.projection.linear_layer'
             self._wgrad(d_mel_bt, dec_x, G[f'{wname}.weight'], G[f'{wname}.bias'], S.gu.output_lengths)
             d_dec = ops.conv1d(d_mel_bt, W[f'T:{wname}.weight'], None, out_dtype=torch.float32, skip_lengths=S.gu.output_lengths)
@@ -719,7 +722,7 @@ class DaftExprt(nn.Module):
         # ---- local prosody predictor
         saved_pp, pp_x, pp_y = S.pp
         if d_dur is not None:
-            dy = torch.stack((d_dur, d_energy, d_pitch), dim=2).contiguous()
+            dy = ops.stack([d_dur.contiguous(), d_energy.contiguous(), d_pitch.contiguous()])
             ppn = 'prosody_predictor'
             dx = ops.linear_small_bwd(dy, None, pp_x, P[f'{ppn}.projection.linear_layer.weight'],
                                       G[f'{ppn}.projection.linear_layer.weight'], G[f'{ppn}.projection.linear_layer.bias'],
@@ -859,7 +862,7 @@ class DaftExprt(nn.Module):
         _, films, _ = self._prosody_encoder_fwd(W, energy_refs, pitch_refs, mel_spec_refs, speaker_ids, ref_lengths, False, False)
         enc, _ = self._phoneme_encoder_fwd(W, symbols, films[0], input_lengths, False, False)
         y, _ = self._predictor_fwd(W, enc, films[1], input_lengths, False, False)
-        dur, energy, pitch = y[:, :, 0].contiguous(), y[:, :, 1].contiguous(), y[:, :, 2].contiguous()
+        dur, energy, pitch = ops.unstack(y, 3)
         dur, dur_int = self.get_int_durations(dur, hparams, dur_factors.contiguous())
         if pitch_transform == 'add':
             mean, std = self._speaker_stats(hparams, dur.device)

@@ -390,6 +390,39 @@ def add_(dst, src):
     return dst
 
 
+def transpose_last2(x):
+    ''' (B, R, C) fp32 -> (B, C, R), contiguous '''
+    B, R, C = x.shape
+    assert x.is_contiguous() and x.dtype == torch.float32
+    y = torch.empty((B, C, R), dtype=torch.float32, device=x.device)
+    H.check(H.lib().dx_transpose_last2(H.ptr(x), H.ptr(y), B, R, C, H.stream()))
+    return y
+
+
+def unstack(y, K):
+    ''' (..., K) interleaved fp32 -> K contiguous tensors of shape (...) '''
+    assert y.is_contiguous() and y.shape[-1] == K and y.dtype == torch.float32
+    outs = [torch.empty(y.shape[:-1], dtype=torch.float32, device=y.device) for _ in range(K)]
+    H.check(H.lib().dx_unstack(H.ptr(y), _ptr_array(outs), y.numel() // K, K, H.stream()))
+    return outs
+
+
+def stack(planes):
+    ''' K contiguous fp32 tensors of one shape (...) -> (..., K) interleaved '''
+    K = len(planes)
+    assert all(p.is_contiguous() and p.dtype == torch.float32 and p.shape == planes[0].shape for p in planes)
+    y = torch.empty(planes[0].shape + (K,), dtype=torch.float32, device=planes[0].device)
+    H.check(H.lib().dx_stack(H.ptr(y), _ptr_array(planes), planes[0].numel(), K, H.stream()))
+    return y
+
+
+def zeros(shape, device, dtype=torch.float32):
+    ''' device buffer cleared by a stream-ordered memset (dx_fill_zero) '''
+    t = torch.empty(shape, dtype=dtype, device=device)
+    H.check(H.lib().dx_fill_zero(H.ptr(t), t.numel() * t.element_size(), H.stream()))
+    return t
+
+
 def colsum_(x, out):
     C = x.shape[-1]
     H.check(H.lib().dx_colsum(H.ptr(x), H.dt(x), H.ptr(out), x.numel() // C, C, H.stream()))
