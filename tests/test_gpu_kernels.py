@@ -322,3 +322,27 @@ def test_planned_conv_ln_edge_batches(B, N, cin):
         m = valid if u.dim() == 3 else valid.reshape(-1)
         assert torch.equal(u.float() * m, v.float() * m), name
         assert float((v.float() * ~m).abs().max()) == 0., name
+
+
+@pytest.mark.parametrize('shape', [(48, 128, 1280, False), (48, 128, 128, True), (48, 128, 11, False), (5, 128, 11, True), (256, 128, 1280, False),
+                                   (600, 128, 128, True)])
+def test_small_linear_heads_match_fp32_reference(shape):
+    ''' dx_linear_small_fwd / _bwd (classifier, FiLM projections; M <= 512 rows take the LDS-tiled kernels, more the generic
+        ones) against an fp64 restatement: y = relu?(x W^T + b), dx = scale * (dy * relu') W, dW += (dy * relu')^T x, db += sum '''
+    from daft_exprt import ops
+    M, K, O, relu = shape
+    g = torch.Generator().manual_seed(M + O)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(O, K, generator=g) / K ** 0.5, torch.randn(O, generator=g)
+    dy = torch.randn(M, O, generator=g)
+    y_ref = x.double() @ w.double().t() + b.double()
+    if relu:
+        y_ref = y_ref.clamp_min(0.)
+    gmask = dy.double() * ((y_ref > 0) if relu else 1.)
+    dx_ref, dw_ref, db_ref = -0.5 * gmask @ w.double(), gmask.t() @ x.double(), gmask.sum(0)
+    d = lambda t: t.to(DEV)
+    y = ops.linear_small_fwd(d(x), d(w), d(b), relu=relu)
+    dw, db = torch.ones(O, K, device=DEV), torch.ones(O, device=DEV)          # the kernels ACCUMULATE into dw / db
+    dx = ops.linear_small_bwd(d(dy), y if relu else None, d(x), d(w), dw, db, relu=relu, dx_scale=-0.5)
+    torch.cuda.synchronize()
+    close = lambda a, r, what: float((a.double().cpu() - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-6 or pytest.fail(what)
+    close(y, y_ref, 'y'); close(dx, dx_ref, 'dx'); close(dw - 1., dw_ref, 'dw'); close(db - 1., db_ref, 'db')

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Collect the round's measurement artefacts on the GPU box (run through gpurun from the repo root):
+#   bash tools/collect_profiles.sh r02      -> gpurun_out/profiles_r02/*  (copy what is to be judged into profiles/)
+# kernel trace + step timeline, three separate PMC passes (FETCH_SIZE / WRITE_SIZE / MFMA busy: they do not fit the TCC
+# slots together, and gpurun refuses --pmc combined with the other trace domains), bench lines of C2 / C5 / C4.
+set -u
+TAG=${1:-r02}
+OUT=gpurun_out/profiles_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-probe"
+python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+python bench.py --batch 256 --tmin 500 --steps 10 --warmup 15 --no-cpu-baseline > $OUT/${TAG}_bench_train_c5.json 2>> $OUT/bench.err
+python bench.py --workload synth --batch 256 --steps 10 --warmup 3 > $OUT/${TAG}_bench_synth_c4.json 2>> $OUT/bench.err
+rocprofv3 --kernel-trace -d $OUT/kt -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-probe > /dev/null 2> $OUT/kt.err
+DB=$(ls $OUT/kt/*/*.db | head -1)
+python tools/rocprof_stats.py $DB > $OUT/${TAG}_kernel_trace.md
+python tools/timeline.py $DB $OUT/${TAG}_step_timeline.txt > /dev/null
+rm -rf $OUT/kt
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -- $CMD > /dev/null 2> $OUT/pmc1.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -- $CMD > /dev/null 2> $OUT/pmc2.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES -d $OUT/pmc_mfma -- $CMD > /dev/null 2> $OUT/pmc3.err
+python tools/pmc_counters.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma --out $OUT/${TAG}_counters.json --command "$CMD" > $OUT/counters_summary.txt
+rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma
+P1="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
+P2="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_INSTS_SALU"
+rocprofv3 --kernel-trace --pmc $P1 -d $OUT/pa1 -- python tools/bench_ops.py attn > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc $P2 -d $OUT/pa2 -- python tools/bench_ops.py attn > /dev/null 2>&1
+python tools/pmc_counters.py $OUT/pa1 $OUT/pa2 --out $OUT/${TAG}_attention_counters.json --command "python tools/bench_ops.py attn" > /dev/null
+rm -rf $OUT/pa1 $OUT/pa2
+cat $OUT/counters_summary.txt
+head -c 400 $OUT/${TAG}_bench.json; echo

@@ -9,7 +9,7 @@
 
 (separate passes: FETCH_SIZE and WRITE_SIZE do not fit the TCC slots together, MI355X_MICROARCH.md "rocprofv3 PMC slots").
 Per kernel (template instance): launches, average duration, FETCH_SIZE bytes (raw and with the gfx950 x2 correction for wide
-coalesced reads, MI355X_MICROARCH.md "HBM"), WRITE_SIZE bytes, and MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE
+coalesced reads, MI355X_MICROARCH.md "HBM"), WRITE_SIZE bytes, and MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8 XCDs)
 * 256 CUs * 4 SIMDs) (the gfx94x `MfmaUtil` formula; the counter counts cycles in which a SIMD's matrix pipe is busy).
 `families` groups the kernels the way bench.py's roofline does (conv_gemm = conv_gemm_kernel + conv_wreg_kernel + the fused
 FF kernels; conv_wgrad = the weight-gradient kernels) and averages per launch, weighted by launches."""
@@ -22,6 +22,7 @@ import sqlite3
 from collections import defaultdict
 
 N_SIMD = 256 * 4
+N_XCD = 8       # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (a 72 us kernel at 2.4 GHz reads 1.38 M), SQ_* summed over all SIMDs
 FAMILIES = {'conv_gemm': ('conv_gemm_kernel', 'conv_wreg_kernel', 'ff_fused'), 'conv_wgrad': ('conv_wgrad', 'wgrad_reduce'),
             'attention': ('attn_',), 'layernorm': ('ln_fwd_kernel', 'ln_bwd_kernel')}
 
@@ -81,7 +82,7 @@ def main():
         if 'WRITE_SIZE' in rec:
             rec['write_bytes'] = rec.pop('WRITE_SIZE') * 1024.
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in rec and rec.get('GRBM_GUI_ACTIVE'):
-            rec['mfma_util'] = rec['SQ_VALU_MFMA_BUSY_CYCLES'] / (rec['GRBM_GUI_ACTIVE'] * N_SIMD)
+            rec['mfma_util'] = rec['SQ_VALU_MFMA_BUSY_CYCLES'] / (rec['GRBM_GUI_ACTIVE'] / N_XCD * N_SIMD)
     fams = {}
     for fam, keys in FAMILIES.items():
         members = {k: r for k, r in kernels.items() if any(s in k for s in keys)}
@@ -94,10 +95,10 @@ def main():
                 agg[field] = sum(r[field] * r['launches'] for r in members.values()) / n
         if all('SQ_VALU_MFMA_BUSY_CYCLES' in r and r.get('GRBM_GUI_ACTIVE') for r in members.values()):
             agg['mfma_util'] = sum(r['SQ_VALU_MFMA_BUSY_CYCLES'] * r['launches'] for r in members.values()) / \
-                (sum(r['GRBM_GUI_ACTIVE'] * r['launches'] for r in members.values()) * N_SIMD)
+                (sum(r['GRBM_GUI_ACTIVE'] * r['launches'] for r in members.values()) / N_XCD * N_SIMD)
         fams[fam] = agg
     out = {'command': args.command, 'notes': 'per-launch averages; FETCH_SIZE x2-corrected for gfx950 (MI355X_MICROARCH.md, HBM); '
-           'mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs)', 'families': fams,
+           'mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); valu_util likewise from SQ_ACTIVE_INST_VALU * 4', 'families': fams,
            'kernels': dict(sorted(kernels.items(), key=lambda kv: -kv[1].get('avg_us', 0.) * kv[1].get('launches', 0)))}
     with open(args.out, 'w') as f:
         json.dump(out, f, indent=1)

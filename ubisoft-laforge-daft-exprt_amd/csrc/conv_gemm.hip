@@ -1491,34 +1491,49 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
 // dW += sum over the splits of the partial tiles (register order, see conv_wgrad_kernel).  One thread per 4 consecutive
 // tile elements (= 4 consecutive lanes of one accumulator register: same co, 4 consecutive ci), 16-byte loads, four
 // splits in flight per thread (the first version read one float per thread per split: 1.3 TB/s).
+// Second launch of a weight gradient: dW += sum over the splits of the partial tiles (fixed order: no fp32 atomics on dW).
+// A block owns 64 output quads; its 256 threads are 4 groups that each walk a quarter of the splits (8 loads in flight) and
+// meet in LDS -- the first version gave every quad ONE thread that walked all 24-64 splits: a chain of 3-8 dependent HBM
+// round trips, 24-28 us per launch for 13-38 MB (0.5-1.5 TB/s), 1.4 ms of side-stream time per training step.
 template <int TAPS>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
                                                            int ntiles, int tiles_ci, int Cout, int Cin) {
   constexpr int TILE_FLOATS = TAPS * 2 * 16 * WG_THREADS, QUADS = TILE_FLOATS / 4;
-  const long q = blockIdx.x * 256L + threadIdx.x;
-  if (q >= (long)ntiles * QUADS) return;
-  const int tile = (int)(q / QUADS), e0 = (int)(q - (long)tile * QUADS) * 4;      // element offset inside the tile
+  __shared__ f32x4 part[4][64];
+  const int grp = threadIdx.x >> 6, ql = threadIdx.x & 63;
+  const long q = blockIdx.x * 64L + ql;
+  const bool live = q < (long)ntiles * QUADS;
+  const int tile = live ? (int)(q / QUADS) : 0, e0 = live ? (int)(q - (long)tile * QUADS) * 4 : 0;      // element offset inside the tile
+  const float* src = ws + (size_t)tile * TILE_FLOATS + e0;
+  const size_t stride = (size_t)ntiles * TILE_FLOATS;
+  const int per = (nsplit + 3) >> 2, k_lo = grp * per, k_hi = min(nsplit, k_lo + per);
+  f32x4 acc8[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc8[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    int k = k_lo;
+    for (; k + 7 < k_hi; k += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(k + u) * stride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc8[u] += v[u];
+    }
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (k + u < k_hi) ? *reinterpret_cast<const f32x4*>(src + (size_t)(k + u) * stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc8[u] += v[u];
+  }
+  part[grp][ql] = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+  __syncthreads();
+  if (grp != 0 || !live) return;
+  const f32x4 sum = (part[0][ql] + part[1][ql]) + (part[2][ql] + part[3][ql]);
   const int slot = e0 / WG_THREADS, tid = e0 % WG_THREADS;
   const int t = slot / 32, i = (slot >> 4) & 1, r = slot & 15;
   const int lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
   const int co = (tile / tiles_ci) * WG_CO + wm * 64 + i * 32 + dx_acc_row(r, lane >> 5);
   const int ci = (tile % tiles_ci) * WG_CI + wn * 32 + (lane & 31);               // .. ci + 3 (lane % 4 == 0)
-  const float* src = ws + (size_t)tile * TILE_FLOATS + e0;
-  const size_t stride = (size_t)ntiles * TILE_FLOATS;
-  // 8 splits in flight per thread: the kernel is a chain of dependent HBM round trips (nsplit / in-flight of them)
-  f32x4 acc8[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) acc8[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int k = 0;
-  for (; k + 7 < nsplit; k += 8) {
-    f32x4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(k + u) * stride);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc8[u] += v[u];
-  }
-  for (; k < nsplit; ++k) acc8[0] += *reinterpret_cast<const f32x4*>(src + (size_t)k * stride);
-  const f32x4 sum = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
   if (co < Cout) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -1538,12 +1553,12 @@ int launch_wgrad(const WgradArgs& a, int taps, hipStream_t s) {
     if (ring && ring_k1) hipLaunchKernelGGL((conv_wgrad_ring_kernel<1>), grid, dim3(WGR_THREADS), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 1>), grid, block, 0, s, a);
     if (a.ws && !(a.debug & 1))
-      hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(ntiles * (1 * 2 * 16 * WG_THREADS / 4 / 256)), dim3(256), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
+      hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(ntiles * (1 * 2 * 16 * WG_THREADS / 4 / 64)), dim3(256), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
   } else {
     if (ring) hipLaunchKernelGGL((conv_wgrad_ring_kernel<3>), grid, dim3(WGR_THREADS), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 3>), grid, block, 0, s, a);
     if (a.ws && !(a.debug & 1))
-      hipLaunchKernelGGL((wgrad_reduce_kernel<3>), dim3(ntiles * (3 * 2 * 16 * WG_THREADS / 4 / 256)), dim3(256), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
+      hipLaunchKernelGGL((wgrad_reduce_kernel<3>), dim3(ntiles * (3 * 2 * 16 * WG_THREADS / 4 / 64)), dim3(256), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
   }
   DX_LAUNCH_CHECK();
   return DX_OK;
@@ -1666,7 +1681,8 @@ static int wgrad_nsplit(int B, int N, int Cin, int Cout, int taps) {
   // 128 x 128 tiles (B = 48, T <= 1000): 64 -> 10.73 ms, 128 -> 10.46, 160 -> 10.45, 192 -> 10.30, 224 -> 10.35,
   // 256 -> 10.42, 320 -> 10.69; B = 128: 192 -> 22.1, 256 -> 22.5, 384 -> 23.2.  3/4 of the CUs, 8 waves each.
   static int fixed = getenv("DX_WGRAD_BLOCKS") ? atoi(getenv("DX_WGRAD_BLOCKS")) : 0;
-  const int target = fixed > 0 ? fixed : 192;
+  static int fixed_k1 = getenv("DX_WGRAD_BLOCKS_K1") ? atoi(getenv("DX_WGRAD_BLOCKS_K1")) : 0;
+  const int target = (taps == 1 && fixed_k1 > 0) ? fixed_k1 : (fixed > 0 ? fixed : 192);
   const int tiles = dx_cdiv(Cout, WG_CO) * dx_cdiv(Cin, WG_CI);
   // every split costs one more partial tile to write and re-read: keep >= ~8 items (64 positions each) per workgroup,
   // 16 for the linear layers (a third of the MFMA work per item)

@@ -317,6 +317,97 @@ inline int grid_for(long total, int block = 256, int cap = 4096) {
 }
 
 
+// ---- the small heads with FEW ROWS (M = batch size: classifier, FiLM projections): LDS-tiled fp32 kernels.  The generic
+// kernels above give every output element one thread that walks the rows serially -- 48 dependent global round trips for a
+// 48-utterance batch, 20-28 us per launch for a few kFLOP (profiles/r02_step_timeline.txt); here a 16 x 16 thread block
+// stages 32-row tiles of both operands in LDS and every thread owns a 4 x 4 block of outputs.
+constexpr int LT = 64, LR = 32;
+// dW[o][k] += sum_m G[m][o] x[m][k], db[o] += sum_m G[m][o], G = dy * relu'(y)
+__global__ __launch_bounds__(256) void linear_rows_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                 const float* __restrict__ x, float* __restrict__ dw,
+                                                                 float* __restrict__ db, long M, int K, int O, int relu) {
+  __shared__ float Gs[LR][LT + 4], Xs[LR][LT + 4];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int k0 = blockIdx.x * LT, o0 = blockIdx.y * LT;
+  float acc[4][4] = {}, accb[4] = {};
+  for (long m0 = 0; m0 < M; m0 += LR) {
+    for (int i = threadIdx.x; i < LR * LT; i += 256) {
+      const int r = i / LT, c = i - r * LT;
+      const long m = m0 + r;
+      float g = 0.f, xv = 0.f;
+      if (m < M) {
+        if (o0 + c < O) { g = dy[m * O + o0 + c]; if (relu && !(y[m * O + o0 + c] > 0.f)) g = 0.f; }
+        if (k0 + c < K) xv = x[m * K + k0 + c];
+      }
+      Gs[r][c] = g; Xs[r][c] = xv;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < LR; ++r) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&Gs[r][ty * 4]), b = *reinterpret_cast<const f32x4*>(&Xs[r][tx * 4]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        accb[i] += a[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = o0 + ty * 4 + i;
+    if (o >= O) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k0 + tx * 4 + j < K) atomicAdd(dw + (long)o * K + k0 + tx * 4 + j, acc[i][j]);
+    if (db && blockIdx.x == 0 && tx == 0) atomicAdd(db + o, accb[i]);
+  }
+}
+// dx[m][k] = scale * sum_o G[m][o] w[o][k]
+__global__ __launch_bounds__(256) void linear_rows_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                 const float* __restrict__ w, float* __restrict__ dx, long M, int K,
+                                                                 int O, int relu, float scale, int o_chunk) {
+  // gridDim.z splits the contraction (FiLM projections: O = 1280 against 48 x 128 outputs); partial sums meet in atomics on a
+  // zeroed dx when there is more than one split
+  __shared__ float Gt[LR][LT + 4], Ws[LR][LT + 4];     // Gt[o][m], Ws[o][k]
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int k0 = blockIdx.x * LT;
+  const long mb = (long)blockIdx.y * LT;
+  float acc[4][4] = {};
+  const int o_begin = blockIdx.z * o_chunk, o_end = min(O, o_begin + o_chunk);
+  for (int ob = o_begin; ob < o_end; ob += LR) {
+    for (int i = threadIdx.x; i < LR * LT; i += 256) {
+      const int r = i / LT, c = i - r * LT;            // Ws: o = ob + r, k = k0 + c (coalesced along k)
+      Ws[r][c] = (ob + r < o_end && k0 + c < K) ? w[(long)(ob + r) * K + k0 + c] : 0.f;
+      const int mo = i / LR, oo = i - mo * LR;         // Gt: m = mb + mo, o = ob + oo (coalesced along o)
+      float g = 0.f;
+      if (mb + mo < M && ob + oo < o_end) { g = dy[(mb + mo) * O + ob + oo]; if (relu && !(y[(mb + mo) * O + ob + oo] > 0.f)) g = 0.f; }
+      Gt[oo][mo] = g;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < LR; ++r) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&Gt[r][ty * 4]), b = *reinterpret_cast<const f32x4*>(&Ws[r][tx * 4]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long m = mb + ty * 4 + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k0 + tx * 4 + j < K) {
+        if (gridDim.z == 1) dx[m * K + k0 + tx * 4 + j] = acc[i][j] * scale; else atomicAdd(dx + m * K + k0 + tx * 4 + j, acc[i][j] * scale);
+      }
+  }
+}
+
 // ---- layout helpers that used to be ATen copies on the step path ---------------------------------------------------------
 // (B, R, C) -> (B, C, R) through a 32 x 33 LDS tile: coalesced on both sides.  The reference hands the mel batch over as
 // (B, n_mel, T) (model.py:744) while every kernel here wants channel-last rows; the loss gradient of the autograd bridge
@@ -457,6 +548,17 @@ extern "C" int dx_linear_small_bwd(const float* dy, const float* y, const float*
   DX_REQUIRE(dy && x && w && dw, DX_ERR_ARG, "dx_linear_small_bwd: null pointer");
   DX_REQUIRE(!relu || y, DX_ERR_ARG, "dx_linear_small_bwd: relu needs the forward output y");
   hipStream_t s = (hipStream_t)stream;
+  if (!mask_lengths && M <= 512) {   // few rows (M = batch size): LDS-tiled kernels
+    if (dx) {
+      const int splits = O > 128 ? dx_cdiv(O, 128) : 1, o_chunk = dx_cdiv(dx_cdiv(O, splits), LR) * LR;
+      if (splits > 1) hipMemsetAsync(dx, 0, (size_t)M * K * sizeof(float), s);
+      hipLaunchKernelGGL(linear_rows_bwd_dx_kernel, dim3(dx_cdiv(K, LT), (unsigned)((M + LT - 1) / LT), dx_cdiv(O, o_chunk)), dim3(256), 0, s,
+                         dy, y, w, dx, M, K, O, relu, dx_scale, o_chunk);
+    }
+    hipLaunchKernelGGL(linear_rows_bwd_dw_kernel, dim3(dx_cdiv(K, LT), dx_cdiv(O, LT)), dim3(256), 0, s, dy, y, x, dw, db, M, K, O, relu);
+    DX_LAUNCH_CHECK();
+    return DX_OK;
+  }
   if (dx) {
     const int chunks = (O > 64 && M * K < (1L << 18)) ? dx_cdiv(O, 64) : 1;
     if (chunks > 1) hipMemsetAsync(dx, 0, (size_t)M * K * sizeof(float), s);
