@@ -317,7 +317,7 @@ inline int grid_for(long total, int block = 256, int cap = 4096) {
 }
 
 
-// ---- the small heads with FEW ROWS (M = batch size: classifier, FiLM projections): LDS-tiled fp32 kernels.  The generic
+// ---- the small heads with FEW ROWS (M = batch size: classifier, FiLM projections): LDS-tiled fp32 weight gradient.  The generic
 // kernels above give every output element one thread that walks the rows serially -- 48 dependent global round trips for a
 // 48-utterance batch, 20-28 us per launch for a few kFLOP (profiles/r02_step_timeline.txt); here a 16 x 16 thread block
 // stages 32-row tiles of both operands in LDS and every thread owns a 4 x 4 block of outputs.
@@ -364,50 +364,6 @@ __global__ __launch_bounds__(256) void linear_rows_bwd_dw_kernel(const float* __
     if (db && blockIdx.x == 0 && tx == 0) atomicAdd(db + o, accb[i]);
   }
 }
-// dx[m][k] = scale * sum_o G[m][o] w[o][k]
-__global__ __launch_bounds__(256) void linear_rows_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                                 const float* __restrict__ w, float* __restrict__ dx, long M, int K,
-                                                                 int O, int relu, float scale, int o_chunk) {
-  // gridDim.z splits the contraction (FiLM projections: O = 1280 against 48 x 128 outputs); partial sums meet in atomics on a
-  // zeroed dx when there is more than one split
-  __shared__ float Gt[LR][LT + 4], Ws[LR][LT + 4];     // Gt[o][m], Ws[o][k]
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int k0 = blockIdx.x * LT;
-  const long mb = (long)blockIdx.y * LT;
-  float acc[4][4] = {};
-  const int o_begin = blockIdx.z * o_chunk, o_end = min(O, o_begin + o_chunk);
-  for (int ob = o_begin; ob < o_end; ob += LR) {
-    for (int i = threadIdx.x; i < LR * LT; i += 256) {
-      const int r = i / LT, c = i - r * LT;            // Ws: o = ob + r, k = k0 + c (coalesced along k)
-      Ws[r][c] = (ob + r < o_end && k0 + c < K) ? w[(long)(ob + r) * K + k0 + c] : 0.f;
-      const int mo = i / LR, oo = i - mo * LR;         // Gt: m = mb + mo, o = ob + oo (coalesced along o)
-      float g = 0.f;
-      if (mb + mo < M && ob + oo < o_end) { g = dy[(mb + mo) * O + ob + oo]; if (relu && !(y[(mb + mo) * O + ob + oo] > 0.f)) g = 0.f; }
-      Gt[oo][mo] = g;
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int r = 0; r < LR; ++r) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(&Gt[r][ty * 4]), b = *reinterpret_cast<const f32x4*>(&Ws[r][tx * 4]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long m = mb + ty * 4 + i;
-    if (m >= M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (k0 + tx * 4 + j < K) {
-        if (gridDim.z == 1) dx[m * K + k0 + tx * 4 + j] = acc[i][j] * scale; else atomicAdd(dx + m * K + k0 + tx * 4 + j, acc[i][j] * scale);
-      }
-  }
-}
-
 // ---- layout helpers that used to be ATen copies on the step path ---------------------------------------------------------
 // (B, R, C) -> (B, C, R) through a 32 x 33 LDS tile: coalesced on both sides.  The reference hands the mel batch over as
 // (B, n_mel, T) (model.py:744) while every kernel here wants channel-last rows; the loss gradient of the autograd bridge
@@ -548,22 +504,19 @@ extern "C" int dx_linear_small_bwd(const float* dy, const float* y, const float*
   DX_REQUIRE(dy && x && w && dw, DX_ERR_ARG, "dx_linear_small_bwd: null pointer");
   DX_REQUIRE(!relu || y, DX_ERR_ARG, "dx_linear_small_bwd: relu needs the forward output y");
   hipStream_t s = (hipStream_t)stream;
-  if (!mask_lengths && M <= 512) {   // few rows (M = batch size): LDS-tiled kernels
-    if (dx) {
-      const int splits = O > 128 ? dx_cdiv(O, 128) : 1, o_chunk = dx_cdiv(dx_cdiv(O, splits), LR) * LR;
-      if (splits > 1) hipMemsetAsync(dx, 0, (size_t)M * K * sizeof(float), s);
-      hipLaunchKernelGGL(linear_rows_bwd_dx_kernel, dim3(dx_cdiv(K, LT), (unsigned)((M + LT - 1) / LT), dx_cdiv(O, o_chunk)), dim3(256), 0, s,
-                         dy, y, w, dx, M, K, O, relu, dx_scale, o_chunk);
-    }
-    hipLaunchKernelGGL(linear_rows_bwd_dw_kernel, dim3(dx_cdiv(K, LT), dx_cdiv(O, LT)), dim3(256), 0, s, dy, y, x, dw, db, M, K, O, relu);
-    DX_LAUNCH_CHECK();
-    return DX_OK;
-  }
+  const bool few_rows = !mask_lengths && M <= 512;   // M = batch size: LDS-tiled weight-gradient kernel
   if (dx) {
-    const int chunks = (O > 64 && M * K < (1L << 18)) ? dx_cdiv(O, 64) : 1;
+    // few outputs (M * K small): short chains of 16 output features per thread, partial sums meet in atomics (a thread that walks
+    // 64+ features is a chain of dependent global round trips: 25 us for a 48 x 128 x 128 layer)
+    const int chunks = (O > 16 && M * K < (1L << 18)) ? dx_cdiv(O, 16) : 1;
     if (chunks > 1) hipMemsetAsync(dx, 0, (size_t)M * K * sizeof(float), s);
     hipLaunchKernelGGL(linear_small_bwd_dx_kernel, dim3(grid_for(M * K), chunks), dim3(256), 0, s, dy, y, w, dx, mask_lengths, N, M, K, O,
                        relu, dx_scale, dx_cdiv(O, chunks));
+  }
+  if (few_rows) {
+    hipLaunchKernelGGL(linear_rows_bwd_dw_kernel, dim3(dx_cdiv(K, LT), dx_cdiv(O, LT)), dim3(256), 0, s, dy, y, x, dw, db, M, K, O, relu);
+    DX_LAUNCH_CHECK();
+    return DX_OK;
   }
   int rpc = 64;
   while (rpc < 4096 && (M + rpc - 1) / rpc > 256) rpc *= 2;

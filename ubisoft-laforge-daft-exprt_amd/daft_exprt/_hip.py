@@ -74,11 +74,14 @@ def dt(t):
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
+_current_device = torch.cuda.current_device
+
+
 def stream():
     ''' raw hipStream_t of torch's current stream (the C hook is ~10x cheaper than building a torch.cuda.Stream object;
         ~340 calls per training step) '''
     if _raw_stream is not None:
-        return _raw_stream(torch.cuda.current_device())
+        return _raw_stream(_current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

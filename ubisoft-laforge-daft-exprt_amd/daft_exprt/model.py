@@ -186,6 +186,7 @@ class DaftExprt(nn.Module):
         self._anchor = None
         self._side = self._side_stream = None
         self._wgrad_keep = []
+        self._wgrad_pending = []
         self._wgrad_ws = None
         self._hop = None
         self.fuse_ln_backward = bool(int(__import__('os').environ.get('DX_FUSE_LN_BWD', '1')))   # see _fft_block_bwd
@@ -563,25 +564,36 @@ class DaftExprt(nn.Module):
             return
         if side is None:
             return ops.conv1d_wgrad(dy, x, dw, db, self.cd, lengths)
-        # dy / x were produced on the main stream: one event hop, then a launch on the side stream's raw handle with the
+        # queued: the launches of a whole FFT block (or conv + LayerNorm stage) go out together behind ONE event hop
+        # (`_flush_wgrads`) -- an event record + wait per weight gradient cost ~10 us of host time, 54 times per step, in
+        # exactly the phoneme-level stretches of the backward pass where the GPU waits for the host
+        self._wgrad_pending.append((dy, x, dw, db, lengths))
+
+    def _flush_wgrads(self):
+        pend, side = self._wgrad_pending, self._side_stream
+        if not pend:
+            return
+        self._wgrad_pending = []
+        # the operands were produced on the main stream: one event hop, then launches on the side stream's raw handle with the
         # side stream's own scratch (launches on one stream run in order, so they can share it) -- a
-        # `with torch.cuda.stream(side)` block per launch cost 15 us of host time, 54 times per step
+        # `with torch.cuda.stream(side)` block per launch cost 15 us of host time
         self._hop.record()
         side.wait_event(self._hop)
-        taps = dw.shape[2] if dw.dim() == 3 else 1
-        need = ops.wgrad_ws_floats(dy.shape[0], dy.shape[1], x.shape[2], dy.shape[2], taps)
+        need = max(ops.wgrad_ws_floats(dy.shape[0], dy.shape[1], x.shape[2], dy.shape[2], dw.shape[2] if dw.dim() == 3 else 1)
+                   for dy, x, dw, db, lengths in pend)
         if self._wgrad_ws is None or self._wgrad_ws.numel() < need:
             with torch.cuda.stream(side):
-                self._wgrad_ws = torch.empty(max(need, 1 << 24), dtype=torch.float32, device=dy.device)
+                self._wgrad_ws = torch.empty(max(need, 1 << 24), dtype=torch.float32, device=pend[0][0].device)
         probe = ops.PROBE is not None
-        if probe:                                   # bench.py's per-family HIP events must sit on the launch stream
-            with torch.cuda.stream(side):
-                ops.conv1d_wgrad(dy, x, dw, db, self.cd, lengths, ws=self._wgrad_ws)
-        else:
-            ops.conv1d_wgrad(dy, x, dw, db, self.cd, lengths, stream=side.cuda_stream, ws=self._wgrad_ws)
-        # keep the operands alive until the side stream has joined the main one at the end of the backward pass (cheaper on
-        # the host than two record_stream calls per launch; the small-N encoder blocks are host-bound)
-        self._wgrad_keep.append((dy, x))
+        for dy, x, dw, db, lengths in pend:
+            if probe:                                   # bench.py's per-family HIP events must sit on the launch stream
+                with torch.cuda.stream(side):
+                    ops.conv1d_wgrad(dy, x, dw, db, self.cd, lengths, ws=self._wgrad_ws)
+            else:
+                ops.conv1d_wgrad(dy, x, dw, db, self.cd, lengths, stream=side.cuda_stream, ws=self._wgrad_ws)
+            # keep the operands alive until the side stream has joined the main one at the end of the backward pass (cheaper on
+            # the host than two record_stream calls per launch; the small-N encoder blocks are host-bound)
+            self._wgrad_keep.append((dy, x))
 
     def _fft_stack_bwd(self, W, blocks, du, dfilms):
         ''' backward through a stack of FFT blocks, top block first.  dfilms: (B, nb_blocks, 2C) gradient view or None '''
@@ -637,8 +649,10 @@ class DaftExprt(nn.Module):
                                         G[f'{fb}.layer_norm.weight'], G[f'{fb}.layer_norm.bias'], film=below.film, dfilm=dfilm_below,
                                         p_pre=below.p_conv, seed_pre=below.seeds[2],
                                         plan=self._plan(below.lengths, dqkv.shape[1]) if self._plan_k1 else None)
+            self._flush_wgrads()
             return dx, (dx, dz_below)
         ops.conv1d(dqkv, W[f'T:{mha}.in_proj_weight'], None, out=dx, accumulate=True, skip_lengths=s.lengths)
+        self._flush_wgrads()
         return dx, None
 
     def _conv_ln_bwd(self, W, s, dy, dfilm=None, need_dx=True, dx_out=None, lengths_hint=None):
@@ -654,6 +668,7 @@ class DaftExprt(nn.Module):
             ops.conv1d_wgrad(dc, s.x, G[f'{s.conv_name}.conv.weight'], G[f'{s.conv_name}.conv.bias'], self.cd, lengths_hint)
             return None
         self._wgrad(dc, s.x, G[f'{s.conv_name}.conv.weight'], G[f'{s.conv_name}.conv.bias'], lengths_hint)
+        self._flush_wgrads()
         if dx_out is not None:
             return ops.conv1d(dc, W[f'T:{s.conv_name}.conv.weight'], None, out=dx_out, accumulate=True, skip_lengths=s.skip)
         return ops.conv1d(dc, W[f'T:{s.conv_name}.conv.weight'], None, out_dtype=s.x.dtype, skip_lengths=s.skip)
@@ -675,6 +690,7 @@ class DaftExprt(nn.Module):
                 from the side stream after it has caught up with the main stream, so the collective orders itself behind
                 both; only the end of the backward pass joins the side stream into the main one (optimizer next). '''
             side = self._side_stream
+            self._flush_wgrads()
             if section_done is not None:
                 if side is not None:
                     side.wait_stream(torch.cuda.current_stream())
@@ -701,6 +717,7 @@ class DaftExprt(nn.Module):
             d_mel_bt = d_mel if d_mel_is_bt else ops.transpose_last2(d_mel.contiguous())
             wname = f'{pre}.projection.linear_layer'
             self._wgrad(d_mel_bt, dec_x, G[f'{wname}.weight'], G[f'{wname}.bias'], S.gu.output_lengths)
+            self._flush_wgrads()
             d_dec = ops.conv1d(d_mel_bt, W[f'T:{wname}.weight'], None, out_dtype=torch.float32, skip_lengths=S.gu.output_lengths)
         d_dec = self._fft_stack_bwd(W, blocks, d_dec, dfilms[2])
         done('frame_decoder')

@@ -32,6 +32,23 @@ class _Probe(object):
             PROBE.setdefault(self.family, []).append((self.start, end, self.flops, self.n_axis))
 
 
+class _NoProbe(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_PROBE = _NoProbe()
+
+
+def _probe(family, flops_fn, n_axis):
+    ''' timing probe of bench.py when armed, a shared no-op otherwise (the step makes ~150 of these calls and its
+        phoneme-level stretches are host-bound) '''
+    return _NO_PROBE if PROBE is None else _Probe(family, flops_fn(), n_axis)
+
+
 def _ptr_array(tensors):
     arr = (ctypes.c_void_p * max(1, len(tensors)))()
     for i, t in enumerate(tensors):
@@ -70,7 +87,7 @@ def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, m
         assert not accumulate
         out = torch.empty((B, Cout, N) if transposed_out else (B, N, Cout), dtype=out_dtype, device=x.device)
     flags = (H.CONV_RELU if relu else 0) | (H.CONV_TRANSPOSED_OUT if transposed_out else 0) | (4 if accumulate else 0)
-    with _Probe('conv_gemm', 2. * B * N * Cin * Cout * taps, N):
+    with _probe('conv_gemm', lambda: 2. * B * N * Cin * Cout * taps, N):
       H.check(H.lib().dx_conv1d(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(bias),
                               H.ptr(out), H.dt(out), out.stride(1), H.ptr(relu_gate),
                               H.dt(relu_gate) if relu_gate is not None else 0,
@@ -90,7 +107,7 @@ def conv1d_ln(x, w_packed, bias, residual, gamma, beta, lengths, film=None, save
     s_out = torch.empty((B, N, 128), dtype=torch.float32, device=dev) if save else None
     mean = torch.empty(B * N, dtype=torch.float32, device=dev) if save else None
     rstd = torch.empty(B * N, dtype=torch.float32, device=dev) if save else None
-    with _Probe('conv_gemm', 2. * B * N * Cin * Cout * taps, N):
+    with _probe('conv_gemm', lambda: 2. * B * N * Cin * Cout * taps, N):
         H.check(H.lib().dx_conv1d_ln(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(bias), H.ptr(residual),
                                      H.ptr(gamma), H.ptr(beta), H.ptr(film), film.stride(0) if film is not None else 0, H.ptr(lengths),
                                      H.ptr(y), H.ptr(y_lp), H.ptr(s_out), H.ptr(mean), H.ptr(rstd), B, N, Cin, taps, float(p_pre),
@@ -109,7 +126,7 @@ def conv1d_lnbwd(x, w_packed, y_inout, s_in, mean, rstd, gamma, beta, lengths, d
     dx_lp = torch.empty((B, N, 128), dtype=torch.bfloat16, device=x.device)
     ldf = film.stride(0) if film is not None else 0
     lddf = dfilm.stride(0) if dfilm is not None else 0
-    with _Probe('conv_gemm', 2. * B * N * Cin * Cout * taps, N):
+    with _probe('conv_gemm', lambda: 2. * B * N * Cin * Cout * taps, N):
         H.check(H.lib().dx_conv1d_lnbwd(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(y_inout), H.ptr(s_in),
                                         H.ptr(mean), H.ptr(rstd), H.ptr(gamma), H.ptr(beta), H.ptr(film), ldf, H.ptr(lengths),
                                         H.ptr(dx_lp), H.ptr(dgamma), H.ptr(dbeta), H.ptr(dfilm), lddf, B, N, Cin, taps,
@@ -154,7 +171,7 @@ def ff_fused_fwd(x_lp, w1_packed, b1, w2_packed, b2, residual, gamma, beta, leng
     s_out = torch.empty((B, N, 128), dtype=torch.float32, device=dev) if save else None
     mean = torch.empty(B * N, dtype=torch.float32, device=dev) if save else None
     rstd = torch.empty(B * N, dtype=torch.float32, device=dev) if save else None
-    with _Probe('conv_gemm', 2. * B * N * 128 * C * 3 * 2, N):
+    with _probe('conv_gemm', lambda: 2. * B * N * 128 * C * 3 * 2, N):
         H.check(H.lib().dx_ff_fused_fwd(H.ptr(x_lp), H.ptr(w1_packed), H.ptr(b1), H.ptr(w2_packed), H.ptr(b2), H.ptr(residual),
                                         H.ptr(gamma), H.ptr(beta), H.ptr(film), film.stride(0) if film is not None else 0,
                                         H.ptr(lengths), H.ptr(h), H.ptr(y), H.ptr(y_lp), H.ptr(s_out), H.ptr(mean), H.ptr(rstd),
@@ -206,7 +223,7 @@ def conv1d_wgrad(dy, x, dw, db, compute_dtype, lengths=None, stream=None, ws=Non
         ws = None
     elif ws is None:
         ws = torch.empty(H.lib().dx_conv1d_wgrad_ws_floats(B, N, Cin, Cout, taps), dtype=torch.float32, device=dy.device)
-    with _Probe('conv_wgrad', 2. * B * N * Cin * Cout * taps, N):
+    with _probe('conv_wgrad', lambda: 2. * B * N * Cin * Cout * taps, N):
       H.check(H.lib().dx_conv1d_wgrad(H.ptr(dy), H.dt(dy), dy.stride(1), H.ptr(x), H.dt(x), x.stride(1),
                                     H._DT[compute_dtype], H.ptr(dw), H.ptr(db), H.ptr(lengths), H.ptr(ws), B, N, Cin, Cout, taps,
                                     H.stream() if stream is None else stream))
