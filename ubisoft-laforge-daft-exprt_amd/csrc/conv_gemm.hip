@@ -743,9 +743,12 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
   // The MFMAs run with the operands swapped (weights as A, activations as B), so the accumulator tile is D[co][position]:
   // a lane holds ONE position (l31) and, per group of 4 registers, 4 CONSECUTIVE output channels (rows (r & 3) + 8 (r >> 2)
   // + 4 g) -- row-major output leaves the registers without an LDS transpose.
-  float bvr[16];
+  // (the data-gradient instantiation has no bias: its 16 registers hold the prefetched gate values instead, see gpre)
+  float bvr[GATE ? 1 : 16];
+  if constexpr (!GATE) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) bvr[r] = p.bias ? p.bias[co0 + dx_acc_row(r, g)] : 0.f;
+    for (int r = 0; r < 16; ++r) bvr[r] = p.bias ? p.bias[co0 + dx_acc_row(r, g)] : 0.f;
+  }
 
   // ---- this workgroup's share of the live position tiles (flat list over the batch)
   auto live_of = [&](int b) { return p.skip_len ? min(ptiles, dx_cdiv(min(N, (int)p.skip_len[b] + 2), BM)) : ptiles; };
@@ -796,7 +799,23 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
   // Epilogue of one 32-position accumulator tile, straight from registers.  bf16 output: two v_permlane32_swap per
   // 8-channel group gather a lane's 8 consecutive channels (16-byte stores; lanes g = 0 / 1 of a position write
   // channels [0, 8) / [8, 16) and [16, 24) / [24, 32) of the wave's 32); fp32 output: one 16-byte store per register group.
-  auto epi_tile = [&](const f32x16& ac, const Epi& e, int row0) {
+  // gate words of ONE 32-position tile (two 16-byte loads per lane), requested by gate_fetch one or more k-steps before the
+  // epilogue slice that consumes them: issued inside epi_tile they were consumed by the very next instruction, a full
+  // memory round trip with the wave unable to issue MFMAs, four times per position tile (the GATE variant ran 62 us where
+  // the same GEMM without a gate runs 42).
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t gpre[2][2];
+  auto gate_fetch = [&](u32x4_t* dst, const Epi& e, int row0) {
+    if constexpr (GATE && sizeof(TO) == 2) {
+      const int n = e.n0 + row0 + l31;
+      const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<TG*>(G) + (size_t)e.cb * N * p.ldy, 0, (uint32_t)((size_t)N * p.ldy * sizeof(TG)), 0x00020000);
+      const uint32_t eoff = (uint32_t)n * (uint32_t)p.ldy + (uint32_t)co0;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) dst[h2] = __builtin_amdgcn_raw_buffer_load_b128(rg, (int)((eoff + 16 * h2 + 8 * g) * 2u), 0, 0);
+    }
+  };
+  auto epi_tile = [&](const f32x16& ac, const Epi& e, int row0, const u32x4_t* gw2) {
     const int n = e.n0 + row0 + l31;
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(Y + (size_t)e.cb * N * p.ldy, 0, ybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
@@ -806,7 +825,8 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
     float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      v[r] = ac[r] + bvr[r];
+      v[r] = GATE ? ac[r] : ac[r] + bvr[GATE ? 0 : r];
+      if (GATE && p.bias) v[r] += p.bias[co0 + dx_acc_row(r, g)];      // (no caller on the step path gates AND biases: loaded in place)
       if (RELU) v[r] = fmaxf(v[r], 0.f);
     }
     if constexpr (sizeof(TO) == 4) {
@@ -846,7 +866,7 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
         const uint32_t o = (eoff + 16 * h2 + 8 * g) * 2u;
         u32x4 w = {P[4 * h2], P[4 * h2 + 1], P[4 * h2 + 2], P[4 * h2 + 3]};
         if (GATE) {   // gate > 0 on the packed bf16 bits: sign clear and magnitude non-zero  <=>  bits - 1 < 0x7fff (unsigned)
-          const u32x4 gw = __builtin_amdgcn_raw_buffer_load_b128(rg, (int)o, 0, 0);
+          const u32x4 gw = gw2[h2];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const uint32_t m = (((gw[j] & 0xffffu) - 1u) < 0x7fffu ? 0x0000ffffu : 0u) | (((gw[j] >> 16) - 1u) < 0x7fffu ? 0xffff0000u : 0u);
@@ -859,11 +879,14 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
     }
   };
   // slice kk (0 .. TAPS*KSTEPS-1) of the epilogue of accumulator pair ac[0], ac[1] (rows [64 h, 64 h + 64) of tile e)
-  auto epi_slice = [&](int kk, const f32x16* ac, const Epi& e, int h) {
+  // `nx` / `nh`: the rows whose epilogue runs in the NEXT phase (the accumulators being filled now): their gate words are
+  // requested right after this phase's second drain has freed gpre -- two thirds of a phase plus the head of the next one ahead
+  auto epi_slice = [&](int kk, const f32x16* ac, const Epi& e, int h, const Epi& nx, int nh) {
     constexpr int NS = TAPS * KSTEPS;
     // early in the phase: the end-of-tile wait for the prefetched A tile (vmcnt) also covers these stores
-    if (kk == 1) epi_tile(ac[0], e, h * 64);
-    else if (kk == NS / 3) epi_tile(ac[1], e, h * 64 + 32);
+    if (kk == 1) epi_tile(ac[0], e, h * 64, gpre[0]);
+    else if (kk == NS / 3) epi_tile(ac[1], e, h * 64 + 32, gpre[1]);
+    else if (kk == NS / 3 + 1) { gate_fetch(gpre[0], nx, nh * 64); gate_fetch(gpre[1], nx, nh * 64 + 32); }
   };
 
   int buf = 0;
@@ -903,7 +926,7 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
           for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const frag_t*>(&As[(h * 64 + i * 32 + l31 + tap) * LDK + ks * 16 + g * 8]);
 #pragma unroll
           for (int i = 0; i < 2; ++i) { if (!(WR_ABL & 1)) dx_mma(acc[h * 2 + i], wreg[tap][ks], a[i]); }
-          if (!(WR_ABL & 2)) epi_slice(tap * KSTEPS + ks, &acc[h == 0 ? 2 : 0], ep, h == 0 ? 1 : 0);
+          if (!(WR_ABL & 2)) epi_slice(tap * KSTEPS + ks, &acc[h == 0 ? 2 : 0], ep, h == 0 ? 1 : 0, cur, h);
         }
       }
     }
@@ -914,7 +937,7 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
   }
   {   // drain: rows 64..127 of the last tile
 #pragma unroll
-    for (int kk = 0; kk < TAPS * KSTEPS; ++kk) epi_slice(kk, &acc[2], prev, 1);
+    for (int kk = 0; kk < TAPS * KSTEPS; ++kk) epi_slice(kk, &acc[2], prev, 1, Epi{0, N, 0}, 0);
   }
 
   // ---- dead tiles (start past length + conv halo): zeros, no reads; split evenly like the live ones
