@@ -50,7 +50,7 @@ def _worker(rank, world, port, tmp):
     covered = sorted((off, n) for _, off, n in red.buckets)
     assert covered[0][0] == 0 and sum(n for _, n in covered) == real.n_params
     assert all(covered[i][0] + covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
-    assert [s for s, _, _ in red.buckets][0] == 'frame_decoder' and [s for s, _, _ in red.buckets][-1] == 'prosody_encoder'
+    assert [s for s, _, _ in red.buckets][0] == 'frame_decoder' and [s for s, _, _ in red.buckets][-1] == 'prosody_encoder.prenet'
     red.broadcast_parameters()
     ref = [torch.zeros_like(model.flat) for _ in range(world)]
     dist.all_gather(ref, model.flat)

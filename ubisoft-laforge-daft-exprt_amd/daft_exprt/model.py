@@ -784,6 +784,7 @@ class DaftExprt(nn.Module):
         # ---- prosody encoder trunk
         dx = ops.masked_mean_bwd(d_emb, pe.output_lengths, pe.T)
         dx = self._fft_stack_bwd(W, pe.blocks, dx, None)
+        done('prosody_encoder.trunk')     # blocks, speaker embedding, FiLM projections: final
         # rows >= length of dx are exactly zero (masked LayerNorm rows carry no gradient; pad queries / keys get zero
         # attention gradients), so the gradient wrt the prenet output is dx itself: no masked copy
         ops.scalar_embed_bwd(dx, [pe.frames_energy, pe.frames_pitch],
@@ -794,19 +795,28 @@ class DaftExprt(nn.Module):
         dl2 = self._conv_ln_bwd(W, pe.c3, dl3, lengths_hint=pe.output_lengths)
         dl1 = self._conv_ln_bwd(W, pe.c2, dl2, lengths_hint=pe.output_lengths)
         self._conv_ln_bwd(W, pe.c1, dl1, need_dx=False, lengths_hint=pe.output_lengths)
-        done('prosody_encoder', last=True)
+        done('prosody_encoder.prenet', last=True)
 
     # ------------------------------------------------------------------ fused training step (no autograd graph)
-    SECTIONS = ('prosody_encoder', 'speaker_classifier', 'phoneme_encoder', 'prosody_predictor', 'gaussian_upsampling',
-                'frame_decoder')
+    # gradient sections in registration (= flat buffer) order; the backward pass reports them in REVERSE.  The prosody encoder
+    # (half of the parameters) is split where its gradients become final at different times: its FFT blocks, speaker embedding
+    # and FiLM projections are done once the trunk's backward has run, the pre-net convolutions (plus the three small tensors
+    # registered in front of them) only at the very end -- so only 15 MB, not 30 MB, of all-reduce is left without backward work
+    # to hide under.
+    SECTIONS = ('prosody_encoder.prenet', 'prosody_encoder.trunk', 'speaker_classifier', 'phoneme_encoder', 'prosody_predictor',
+                'gaussian_upsampling', 'frame_decoder')
 
     def section_slices(self):
-        ''' {top-level module: (offset, numel)} in the flat parameter / gradient buffers (registration order) '''
+        ''' {section: (offset, numel)} in the flat parameter / gradient buffers (registration order) '''
         out = {}
         for name, _, _ in self._table:
             off, n = self._offsets[name]
             sec = name.split('.')[0]
+            if sec == 'prosody_encoder':
+                tail = name.split('.')[1] in ('blocks', 'spk_embedding', 'gammas_predictor', 'betas_predictor')
+                sec = 'prosody_encoder.trunk' if tail else 'prosody_encoder.prenet'
             lo, cnt = out.get(sec, (off, 0))
+            assert lo + cnt == off, f'section {sec} is not contiguous at {name}'
             out[sec] = (lo, cnt + n)
         return out
 
