@@ -98,6 +98,9 @@ __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 3
 #ifndef DX_ATTN_AHEAD
 #define DX_ATTN_AHEAD 1
 #endif
+#ifndef DX_ATTN_OCC64
+#define DX_ATTN_OCC64 2   // minimum waves per SIMD of the d_head = 64 forward / dQ kernels
+#endif
 #ifndef DX_ATTN_OCC16
 #define DX_ATTN_OCC16 5   // workgroups (4 waves) per CU for the d_head = 16 forward / dQ kernels = waves per SIMD
 #endif
@@ -109,7 +112,7 @@ template <int DH> struct Stage { static constexpr int KT = DH <= 16 ? DX_ATTN_KT
 
 // =============================================================================== forward
 template <typename TC, int DH>
-__global__ __launch_bounds__(256, (DH <= 16 && sizeof(TC) == 2) ? DX_ATTN_OCC16 : 2) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : DX_ATTN_OCC64) : 2) void attn_fwd_kernel(AttnArgs a) {
   constexpr int KT = Stage<DH>::KT;
   constexpr int LD = DH + APad<TC>::value, KS = DH / 16, MT = (DH + 31) / 32, WRAP = DH >= 32 ? 32 : 16;
   typedef typename Vec8<TC>::type frag_t;
@@ -370,7 +373,7 @@ __global__ void attn_delta_kernel(const TC* __restrict__ o, const TC* __restrict
 
 // =============================================================================== backward: dQ
 template <typename TC, int DH>
-__global__ __launch_bounds__(256, (DH <= 16 && sizeof(TC) == 2) ? DX_ATTN_OCC16 : 2) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : DX_ATTN_OCC64) : 2) void attn_bwd_dq_kernel(AttnArgs a) {
   constexpr int KT = Stage<DH>::KT;
   constexpr int LD = DH + APad<TC>::value, KS = DH / 16, MT = (DH + 31) / 32, WRAP = DH >= 32 ? 32 : 16;
   typedef typename Vec8<TC>::type frag_t;

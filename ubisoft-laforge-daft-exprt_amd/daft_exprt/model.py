@@ -187,6 +187,9 @@ class DaftExprt(nn.Module):
         self._side = self._side_stream = None
         self._wgrad_keep = []
         self._wgrad_pending = []
+        self._wgrad_batch_rows = int(__import__('os').environ.get('DX_WGRAD_BATCH_ROWS', '1000000000'))   # GEMMs with fewer rows wait for the block's flush (measured: always waiting is best, 8.35 vs 8.42 ms)
+        self._wgrad_flush_blocks = int(__import__('os').environ.get('DX_WGRAD_FLUSH_BLOCKS', '1'))   # FFT blocks per flush
+        self._blocks_since_flush = 0
         self._wgrad_ws = None
         self._hop = None
         self.fuse_ln_backward = bool(int(__import__('os').environ.get('DX_FUSE_LN_BWD', '1')))   # see _fft_block_bwd
@@ -568,8 +571,16 @@ class DaftExprt(nn.Module):
         # (`_flush_wgrads`) -- an event record + wait per weight gradient cost ~10 us of host time, 54 times per step, in
         # exactly the phoneme-level stretches of the backward pass where the GPU waits for the host
         self._wgrad_pending.append((dy, x, dw, db, lengths))
+        if dy.shape[0] * dy.shape[1] >= self._wgrad_batch_rows:   # frame-level GEMMs: the GPU is the bottleneck, start right away
+            self._flush_wgrads()
+
+    def _block_done(self):
+        self._blocks_since_flush += 1
+        if self._blocks_since_flush >= self._wgrad_flush_blocks:
+            self._flush_wgrads()
 
     def _flush_wgrads(self):
+        self._blocks_since_flush = 0
         pend, side = self._wgrad_pending, self._side_stream
         if not pend:
             return
@@ -649,10 +660,10 @@ class DaftExprt(nn.Module):
                                         G[f'{fb}.layer_norm.weight'], G[f'{fb}.layer_norm.bias'], film=below.film, dfilm=dfilm_below,
                                         p_pre=below.p_conv, seed_pre=below.seeds[2],
                                         plan=self._plan(below.lengths, dqkv.shape[1]) if self._plan_k1 else None)
-            self._flush_wgrads()
+            self._block_done()
             return dx, (dx, dz_below)
         ops.conv1d(dqkv, W[f'T:{mha}.in_proj_weight'], None, out=dx, accumulate=True, skip_lengths=s.lengths)
-        self._flush_wgrads()
+        self._block_done()
         return dx, None
 
     def _conv_ln_bwd(self, W, s, dy, dfilm=None, need_dx=True, dx_out=None, lengths_hint=None):
