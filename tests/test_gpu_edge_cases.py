@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import daft_exprt_cpu as O
-from tests.util import make_hparams, no_dropout
+from tests.util import make_hparams, no_dropout, gradient_report
 
 DEV = 'cuda:0'
 
@@ -68,11 +68,11 @@ def test_forward_and_gradients_match_oracle(case):
     assert rel(out[4], ref[4]) < 5e-4 and rel(out[0], ref[0]) < 5e-4
     assert abs(float(loss) - float(ref_loss)) < 2e-4 * abs(float(ref_loss))
     grads = torch.autograd.grad(ref_loss, list(P.values()))
-    worst = 0.
-    for (name, p), g in zip(model.named_parameters(), grads):
-        gn, rn = float(p.grad.norm()), float(g.norm())
-        worst = max(worst, abs(gn - rn) / (rn + 1e-6 * float(grads[0].norm()) + 1e-12))
-    assert worst < 5e-3, worst
+    # every one of the 193 gradients ELEMENT-WISE (fp32 operand mode: 3e-3 of a tensor's max + 1e-5 of the model's largest element)
+    got = {n: p.grad for n, p in model.named_parameters()}
+    worst = gradient_report(got, dict(zip(P.keys(), grads)), 3e-3, 1e-5)
+    print(case, 'worst gradient tensors', worst[:4])
+    assert worst[0][0] <= 1., worst[:4]
 
 
 def test_inference_rejects_too_short_utterance_like_the_reference():

@@ -35,20 +35,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import daft_exprt_cpu as O
-from tests.util import make_hparams, no_dropout
+from tests.util import make_hparams, no_dropout, gradient_report
 
 DEV = 'cuda:0'
 TOL = {'fp32': dict(pred=2e-4, loss=1e-4, grad=2e-3, floor=2e-5),
        'bf16': dict(pred=3e-2, loss=2e-2, grad=0.10, floor=1e-3, pred_mel=1.5e-1, pred_weights=3e-1)}
 TOL['bf16_emulated'] = TOL['bf16']
-RELU_GATED = ('feed_forward.convs.0.conv.weight', 'feed_forward.convs.0.conv.bias', 'prosody_encoder.convs.0.conv.weight',
-              'prosody_encoder.convs.0.conv.bias', 'prosody_encoder.convs.4.conv.weight', 'prosody_encoder.convs.4.conv.bias',
-              'prosody_encoder.convs.8.conv.weight', 'prosody_encoder.convs.8.conv.bias', 'prosody_predictor.blocks.0.0.conv.weight',
-              'prosody_predictor.blocks.0.0.conv.bias', 'prosody_predictor.blocks.0.4.conv.weight', 'prosody_predictor.blocks.0.4.conv.bias')
-SIGMA_PATH = ('gaussian_upsampling.projection.0.linear_layer.weight', 'gaussian_upsampling.projection.0.linear_layer.bias',
-              'gaussian_upsampling.duration_projection.conv.weight', 'gaussian_upsampling.duration_projection.conv.bias')
-
-
 def _rel(a, b):
     a, b = a.detach().float().cpu(), b.detach().float()
     assert a.shape == b.shape, (a.shape, b.shape)
@@ -123,24 +115,7 @@ def _compare(mode, hip, ora, what):
     lerr = float((hp_terms - or_terms).abs().max() / or_terms.abs().max())
     print(what, mode, 'loss terms', hp_terms.tolist(), or_terms.tolist())
     assert lerr <= tol['loss'], (what, mode, lerr)
-    gmax = max(float(g.abs().max()) for g in or_grads.values())
-    worst = []
-    for name, ref in or_grads.items():
-        got = hp_grads[name]
-        assert got.shape == ref.shape, name
-        rel = tol['grad'] * ((2. if mode == 'fp32' else 3.5) if name in SIGMA_PATH else 1.)
-        bound = rel * float(ref.abs().max()) + tol['floor'] * gmax
-        err = (got - ref).abs()
-        if name.endswith(RELU_GATED):
-            # a pre-activation within rounding distance of 0 takes the other branch of ReLU' in one of the two computations: the
-            # whole dW row (and the db element) of that channel moves by one position's contribution.  Allow 0.5 % of the elements
-            # to leave the bound, and hold the tensor as a whole to the norm.
-            bad = float((err > bound).float().mean())
-            nrm = float((got - ref).norm() / (ref.norm() + 1e-30))
-            worst.append((max(bad / 5e-3, nrm / (5. * rel)), name + ' [relu-gated: outlier share, norm]', bad, nrm))
-        else:
-            worst.append((float(err.max()) / bound, name, float(err.max()), float(ref.abs().max())))
-    worst.sort(reverse=True)
+    worst = gradient_report(hp_grads, or_grads, tol['grad'], tol['floor'], sigma_factor=2. if mode == 'fp32' else 3.5)
     print(what, mode, 'worst gradient tensors (err / bound, name, max abs err, max abs ref):')
     for w in worst[:6]:
         print('   ', f'{w[0]:.3f}', w[1], f'{w[2]:.3e}', f'{w[3]:.3e}')
