@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DX_ABI_VERSION 6
+#define DX_ABI_VERSION 7
 
 enum { DX_F32 = 0, DX_BF16 = 1, DX_I64 = 2 };
 enum { DX_OK = 0, DX_ERR_ARG = -1, DX_ERR_SHAPE = -2, DX_ERR_DTYPE = -3, DX_ERR_LAUNCH = -4, DX_ERR_UNSUPPORTED = -5 };
@@ -177,14 +177,21 @@ long dx_layernorm_bwd_ws_floats(int B, int N, int C);
  * dropout on the probabilities, P v -- without materialising (B, H, N, N).
  *   qkv (B, N, 3E) = in-projection output [q | k | v], dtype = MFMA operand type (DX_BF16 or DX_F32)
  *   o   (B, N, E) same dtype;  lse (B, H, N) fp32 log-sum-exp per query (NULL at inference)
- * Queries n >= lengths[b] are not attended (their rows are zeroed by the following masked LayerNorm). */
-int dx_attention_fwd(const void* qkv, int dtype, const int64_t* lengths, void* o, float* lse, int B, int N,
+ * Queries n >= lengths[b] are not attended (their rows are zeroed by the following masked LayerNorm).
+ * order: NULL, or the (B) int32 table of dx_length_order -- workgroups are then launched longest utterance first
+ * (same results; a ragged batch finishes sooner). */
+int dx_attention_fwd(const void* qkv, int dtype, const int64_t* lengths, const int* order, void* o, float* lse, int B, int N,
                      int H, int E, float p_drop, uint64_t seed, void* stream);
 
 /* Backward of dx_attention_fwd: dqkv (B, N, 3E) <- d_o (B, N, E).  delta_ws: (B, H, N) fp32 workspace. */
 int dx_attention_bwd(const void* qkv, const void* o, const void* d_o, int dtype, const float* lse,
-                     const int64_t* lengths, void* dqkv, float* delta_ws, int B, int N, int H, int E,
+                     const int64_t* lengths, const int* order, void* dqkv, float* delta_ws, int B, int N, int H, int E,
                      float p_drop, uint64_t seed, void* stream);
+
+/* order[r] = index of the utterance with the r-th largest length (ties: lower index first), B <= 65536.  Host-side
+ * analogue: the reference's collate sorts a batch by decreasing phoneme count (data_loader.py:246-250); the attention
+ * kernels only use it as a launch order, so any batch order stays valid. */
+int dx_length_order(const int64_t* lengths, int B, int* order, void* stream);
 
 /* ---- K6: out = base + sum_f conv1d(1 -> 128, k=3)(feat_f) + pos_table[n], zero where n >= lengths[b].
  * Energy / pitch embeddings + positional add + mask of the prosody encoder (model.py:400-414); the duration /

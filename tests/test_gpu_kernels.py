@@ -46,6 +46,27 @@ def test_attention_dropout_mask_is_shared_by_forward_and_backward(H, dtype):
     assert float((o2.float() - o.float()).abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize('H', [2, 8])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_attention_launch_order_does_not_change_results(H, dtype):
+    ''' dx_length_order: a permutation by decreasing length (ties: lower index first); attention launched in that order
+        returns the bits of the identity order, forward and backward '''
+    from daft_exprt import ops
+    B, N, E, p, seed = 7, 300, 128, 0.1, 99
+    qkv, _ = _attn_inputs(B, N, H, E, 5, dtype)
+    lens = torch.tensor([120, 300, 1, 64, 300, 257, 129], device=DEV)
+    order = ops.length_order(lens)
+    assert order.dtype == torch.int32 and order.tolist() == [1, 4, 5, 6, 0, 3, 2]
+    o0, lse0 = ops.attention_fwd(qkv, lens, H, p, seed)
+    o1, lse1 = ops.attention_fwd(qkv, lens, H, p, seed, order=order)
+    valid = (torch.arange(N, device=DEV)[None, :] < lens[:, None])
+    assert torch.equal(o0[valid], o1[valid]) and torch.equal(lse0.transpose(1, 2)[valid], lse1.transpose(1, 2)[valid])
+    d_o = (torch.randn(B, N, E, device=DEV) * valid.unsqueeze(2)).to(dtype)
+    g0 = ops.attention_bwd(qkv, o0, d_o, lse0, lens, H, p, seed)
+    g1 = ops.attention_bwd(qkv, o0, d_o, lse0, lens, H, p, seed, order=order)
+    assert torch.equal(g0[valid], g1[valid])
+
+
 def test_attention_dropout_keep_rate():
     ''' with v = 1 every output equals sum_j P_drop[i, j] = (kept probability mass) / (1 - p): its mean over queries is 1 '''
     from daft_exprt import ops

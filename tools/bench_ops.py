@@ -118,22 +118,24 @@ if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'convln':
 
 def bench_attn():
     dev = torch.device('cuda:0')
-    B, N, E = 48, 1000, 128
+    B, N, E = int(os.environ.get('ATTN_B', '48')), 1000, 128
     g = torch.Generator().manual_seed(0)
-    lens = torch.randint(250, 1001, (B,), generator=g)
-    lens[0] = N
-    lens = lens.sort(descending=True).values.to(dev)
-    for H in (8, 2):
-        qkv = torch.randn(B, N, 3 * E, device=dev).to(torch.bfloat16)
-        o, lse = ops.attention_fwd(qkv, lens, H, 0.1, 7)
-        d_o = torch.randn(B, N, E, device=dev).to(torch.bfloat16)
-        t_f = timeit(lambda: ops.attention_fwd(qkv, lens, H, 0.1, 7))
-        t_f0 = timeit(lambda: ops.attention_fwd(qkv, lens, H, 0., 7))
-        t_b = timeit(lambda: ops.attention_bwd(qkv, o, d_o, lse, lens, H, 0.1, 7))
-        el = float((lens.double() ** 2).sum()) * H
-        print(f'attn d_h={E // H}: fwd {t_f * 1e3:6.1f} us (no dropout {t_f0 * 1e3:6.1f}) bwd {t_b * 1e3:6.1f} us | '
-              f'{el / 1e6:.0f} M (q,k) pairs -> fwd {t_f * 1e-3 / el * 1e12:.2f} ps/pair bwd {t_b * 1e-3 / el * 1e12:.2f} ps/pair')
-
+    lo = int(os.environ.get('ATTN_LMIN', '250'))
+    base = torch.randint(lo, 1001, (B,), generator=g)
+    base[0] = N
+    orders = {'sorted': base.sort(descending=True).values, 'random': base, 'ascending': base.sort().values}
+    for tag in os.environ.get('ATTN_ORDER', 'sorted').split(','):
+        lens = orders[tag].to(dev)
+        for H in (8, 2):
+            qkv = torch.randn(B, N, 3 * E, device=dev).to(torch.bfloat16)
+            o, lse = ops.attention_fwd(qkv, lens, H, 0.1, 7)
+            d_o = torch.randn(B, N, E, device=dev).to(torch.bfloat16)
+            t_f = timeit(lambda: ops.attention_fwd(qkv, lens, H, 0.1, 7))
+            t_f0 = timeit(lambda: ops.attention_fwd(qkv, lens, H, 0., 7))
+            t_b = timeit(lambda: ops.attention_bwd(qkv, o, d_o, lse, lens, H, 0.1, 7))
+            el = float((lens.double() ** 2).sum()) * H
+            print(f'attn[{tag}] d_h={E // H}: fwd {t_f * 1e3:6.1f} us (no dropout {t_f0 * 1e3:6.1f}) bwd {t_b * 1e3:6.1f} us | '
+                  f'{el / 1e6:.0f} M (q,k) pairs -> fwd {t_f * 1e-3 / el * 1e12:.2f} ps/pair bwd {t_b * 1e-3 / el * 1e12:.2f} ps/pair')
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'attn':
     bench_attn()

@@ -195,6 +195,7 @@ class DaftExprt(nn.Module):
         self.fuse_ln_backward = bool(int(__import__('os').environ.get('DX_FUSE_LN_BWD', '1')))   # see _fft_block_bwd
         self.balanced_tiles = bool(int(__import__('os').environ.get('DX_BALANCED_TILES', '1')))   # see _plan
         self._plans = {}
+        self.attn_lpt = bool(int(__import__('os').environ.get('DX_ATTN_LPT', '1')))   # see _order
         self.ff_fused = bool(int(__import__('os').environ.get('DX_FF_FUSED', '0')))   # K2: both FF convs + LayerNorm in one launch (bf16); opt-in, see DESIGN
         self._plan_min_rows = int(__import__('os').environ.get('DX_PLAN_MIN_ROWS', '0'))
         self._plan_k1 = bool(int(__import__('os').environ.get('DX_PLAN_K1', '0')))   # balanced tiles also for the k = 1 QKV data gradient + LayerNorm backward (measured: 8.78 vs 8.74 ms)
@@ -309,6 +310,16 @@ class DaftExprt(nn.Module):
             hit = self._plans[key] = (lengths, ops.conv_tile_plan(lengths, N))
         return hit[1]
 
+    def _order(self, lengths):
+        ''' longest-first launch order of the attention kernels (`ops.length_order`), one per distinct lengths tensor per step '''
+        if not self.attn_lpt or lengths.shape[0] < 2:
+            return None
+        key = ('order', lengths.data_ptr())
+        hit = self._plans.get(key)
+        if hit is None or hit[0] is not lengths:
+            hit = self._plans[key] = (lengths, ops.length_order(lengths))
+        return hit[1]
+
     def _ff_plan(self, lengths, N):
         ''' tile table of the fused feed-forward kernel (`ops.ff_plan`), one per distinct lengths tensor per step '''
         key = ('ff', lengths.data_ptr(), N)
@@ -390,7 +401,7 @@ class DaftExprt(nn.Module):
         xin = x_lp if x_lp is not None else x
         qkv = ops.conv1d(xin, W[f'{a_pre}.multi_head_attention.in_proj_weight'], P[f'{a_pre}.multi_head_attention.in_proj_bias'],
                          out_dtype=cd, skip_lengths=lengths)
-        o, lse = ops.attention_fwd(qkv, lengths, cfg['attn_nb_heads'], p_attn, seeds[0], need_lse=save)
+        o, lse = ops.attention_fwd(qkv, lengths, cfg['attn_nb_heads'], p_attn, seeds[0], need_lse=save, order=self._order(lengths))
         # out-projection + Dropout + residual + LayerNorm + mask in ONE launch (the GEMM tile holds complete 128-ch rows)
         a, a_lp, s1, mean1, rstd1 = ops.conv1d_ln(o, W[f'{a_pre}.multi_head_attention.out_proj.weight'],
                                                   P[f'{a_pre}.multi_head_attention.out_proj.bias'], x, P[f'{a_pre}.layer_norm.weight'],
@@ -651,7 +662,7 @@ class DaftExprt(nn.Module):
         mha = f'{a_pre}.multi_head_attention'
         self._wgrad(dproj, s.o, G[f'{mha}.out_proj.weight'], G[f'{mha}.out_proj.bias'], s.lengths)
         d_o = ops.conv1d(dproj, W[f'T:{mha}.out_proj.weight'], None, out_dtype=cd, skip_lengths=s.lengths)
-        dqkv = ops.attention_bwd(s.qkv, s.o, d_o, s.lse, s.lengths, s.cfg['attn_nb_heads'], s.p_attn, s.seeds[0])
+        dqkv = ops.attention_bwd(s.qkv, s.o, d_o, s.lse, s.lengths, s.cfg['attn_nb_heads'], s.p_attn, s.seeds[0], order=self._order(s.lengths))
         self._wgrad(dqkv, s.x, G[f'{mha}.in_proj_weight'], G[f'{mha}.in_proj_bias'], s.lengths)
         if fuse and below is not None:
             fb = f'{below.pre}.feed_forward'

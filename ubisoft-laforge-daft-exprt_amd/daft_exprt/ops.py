@@ -281,24 +281,31 @@ def layernorm_bwd(dy, s_in, mean, rstd, gamma, beta, dgamma, dbeta, film=None, d
 
 
 # ----------------------------------------------------------------------------- attention
-def attention_fwd(qkv, lengths, nb_heads, p_drop=0., seed=0, need_lse=True):
+def length_order(lengths):
+    ''' int32 (B): utterance indices by decreasing length (dx_length_order) -- the launch order of the attention kernels '''
+    order = torch.empty((lengths.shape[0],), dtype=torch.int32, device=lengths.device)
+    H.check(H.lib().dx_length_order(H.ptr(lengths), lengths.shape[0], H.ptr(order), H.stream()))
+    return order
+
+
+def attention_fwd(qkv, lengths, nb_heads, p_drop=0., seed=0, need_lse=True, order=None):
     B, N, E3 = qkv.shape
     E = E3 // 3
     assert qkv.is_contiguous()
     o = torch.empty((B, N, E), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, nb_heads, N), dtype=torch.float32, device=qkv.device) if need_lse else None
-    H.check(H.lib().dx_attention_fwd(H.ptr(qkv), H.dt(qkv), H.ptr(lengths), H.ptr(o), H.ptr(lse), B, N, nb_heads, E,
+    H.check(H.lib().dx_attention_fwd(H.ptr(qkv), H.dt(qkv), H.ptr(lengths), H.ptr(order), H.ptr(o), H.ptr(lse), B, N, nb_heads, E,
                                      float(p_drop), int(seed), H.stream()))
     return o, lse
 
 
-def attention_bwd(qkv, o, d_o, lse, lengths, nb_heads, p_drop=0., seed=0):
+def attention_bwd(qkv, o, d_o, lse, lengths, nb_heads, p_drop=0., seed=0, order=None):
     B, N, E3 = qkv.shape
     E = E3 // 3
     assert d_o.is_contiguous() and d_o.dtype == qkv.dtype
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, nb_heads, N), dtype=torch.float32, device=qkv.device)
-    H.check(H.lib().dx_attention_bwd(H.ptr(qkv), H.ptr(o), H.ptr(d_o), H.dt(qkv), H.ptr(lse), H.ptr(lengths), H.ptr(dqkv),
+    H.check(H.lib().dx_attention_bwd(H.ptr(qkv), H.ptr(o), H.ptr(d_o), H.dt(qkv), H.ptr(lse), H.ptr(lengths), H.ptr(order), H.ptr(dqkv),
                                      H.ptr(delta), B, N, nb_heads, E, float(p_drop), int(seed), H.stream()))
     return dqkv
 
