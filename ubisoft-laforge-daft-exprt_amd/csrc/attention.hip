@@ -126,7 +126,10 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
   __shared__ __attribute__((aligned(16))) TC Vs[KT * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
   constexpr int SP = Split<DH>::value, QB = 128 / SP, WQ = 4 / SP;
-  const int wq = wave % WQ, kh = wave / WQ;
+  // the wave index as a scalar (the compiler cannot see that tid >> 6 is wave-uniform) -- not for d_head = 64 here: the scalar
+  // form of this kernel measured 45 vs 41 us
+  const int wv = DH >= 64 ? wave : __builtin_amdgcn_readfirstlane(wave);
+  const int wq = wv % WQ, kh = wv / WQ;
   const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, N = a.N, E = a.E;
   const int len = (int)a.lengths[b];
   const int q = blockIdx.x * QB + wq * 32 + l31;
@@ -147,6 +150,9 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
     return;
   }
 
+  // a wave whose 32 queries are all padding (the ragged end of an utterance: half the waves of its last tile on average)
+  // still stages tiles and meets the barriers, but issues no MFMA / softmax work; its rows leave as zeros
+  const bool wave_live = blockIdx.x * QB + wq * 32 < len;
   frag_t qf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
     for (int s2 = 0; s2 < KT / 32 / SP; ++s2) {
       const int sub = s2 * SP + kh;   // SP = 2: the wave groups take alternate sub-tiles
       const int k0 = kt0 + sub * 32;
-      if (k0 < len) {
+      if (k0 < len && wave_live) {
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
       for (int r = 0; r < 16; ++r) oT[mt][r] = oT[mt][r] * a0 + red[(mt * 16 + r) * 64] * a1;
   }
   if (q < N) {
-    const float inv_l = inv_keep / l;
+    const float inv_l = wave_live ? inv_keep / l : 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -285,11 +291,11 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
         const int d0 = 8 * r4 + 4 * g;  // rows d0..d0+3 = registers 4*r4 .. 4*r4+3
         if (mt * 32 + d0 < DH) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) O[(long)q * E + mt * 32 + d0 + t] = (TC)(oT[mt][r4 * 4 + t] * inv_l);
+          for (int t = 0; t < 4; ++t) O[(long)q * E + mt * 32 + d0 + t] = (TC)(wave_live ? oT[mt][r4 * 4 + t] * inv_l : 0.f);
         }
       }
     }
-    if (lse && g == 0) lse[q] = m * LN2 + logf(l);
+    if (lse && g == 0) lse[q] = wave_live ? m * LN2 + logf(l) : 0.f;
   }
 }
 
@@ -318,7 +324,8 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
   __shared__ __attribute__((aligned(16))) TC Vs[KT * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
   constexpr int SP = Split<DH>::value, QB = 128 / SP, WQ = 4 / SP;
-  const int wq = wave % WQ, kh = wave / WQ;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);   // scalar: the row-group tests below become s_cbranch (5 % on the backward kernels)
+  const int wq = wv % WQ, kh = wv / WQ;
   const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, N = a.N, E = a.E;
   const int len = (int)a.lengths[b];
   const int q = blockIdx.x * QB + wq * 32 + l31;
@@ -361,6 +368,7 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
     if (q < N && g == 0 && kh == 0) const_cast<float*>(a.delta)[stat] = delta_q;
     const float c2 = a.scale * LOG2E, lse2 = lse_q * LOG2E;
     const bool tile_q_valid = blockIdx.x * QB + wq * 32 + 32 <= len;
+    const bool wave_live = blockIdx.x * QB + wq * 32 < len;
     const uint32_t th8 = dx_drop_th8(a.p_drop);
     const float inv_keep = dx_drop_inv_keep8(th8);
     const uint32_t NB = (uint32_t)(N + 3) >> 2;
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
       for (int s2 = 0; s2 < KT / 32 / SP; ++s2) {
         const int sub = s2 * SP + kh;   // SP = 2: the wave groups take alternate sub-tiles
         const int k0 = kt0 + sub * 32;
-        if (k0 < len) {
+        if (k0 < len && wave_live) {   // all-padding waves: dQ stays zero (see the forward)
           f32x16 s, dp;
 #pragma unroll
           for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -480,7 +488,8 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : 2) void attn_bwd_dkv_kernel(Att
   __shared__ float lse_s[KT], delta_s[KT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
   constexpr int SP = Split<DH>::value, QB = 128 / SP, WQ = 4 / SP;
-  const int wq = wave % WQ, kh = wave / WQ;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);   // scalar: the row-group tests below become s_cbranch (5 % on the backward kernels)
+  const int wq = wv % WQ, kh = wv / WQ;
   const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, N = a.N, E = a.E;
   const int len = (int)a.lengths[b];
   const int key = blockIdx.x * QB + wq * 32 + l31;
@@ -516,6 +525,7 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : 2) void attn_bwd_dkv_kernel(Att
     const uint32_t shl_lane = 24u - 8u * (key & 3);
     const float c2 = a.scale * LOG2E;
     const bool tile_k_valid = blockIdx.x * QB + wq * 32 + 32 <= len;
+    const bool wave_live = blockIdx.x * QB + wq * 32 < len;
 
     TileRegs<TC, DH, KT> qreg, doreg;
     float lse_r = 0.f, delta_r = 0.f;
@@ -550,7 +560,7 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : 2) void attn_bwd_dkv_kernel(Att
       for (int s2 = 0; s2 < KT / 32 / SP; ++s2) {
         const int sub = s2 * SP + kh;   // SP = 2: the wave groups take alternate sub-tiles
         const int qb = qt0 + sub * 32;
-        if (qb < len) {
+        if (qb < len && wave_live) {   // all-padding key waves: dK / dV stay zero
           f32x16 s, dp;
 #pragma unroll
           for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
