@@ -63,8 +63,12 @@ RELU_GATED = ('feed_forward.convs.0.conv.weight', 'feed_forward.convs.0.conv.bia
               'prosody_encoder.convs.0.conv.bias', 'prosody_encoder.convs.4.conv.weight', 'prosody_encoder.convs.4.conv.bias',
               'prosody_encoder.convs.8.conv.weight', 'prosody_encoder.convs.8.conv.bias', 'prosody_predictor.blocks.0.0.conv.weight',
               'prosody_predictor.blocks.0.0.conv.bias', 'prosody_predictor.blocks.0.4.conv.weight', 'prosody_predictor.blocks.0.4.conv.bias')
+# tensors whose gradient flows through sigma = softplus(Linear(x + E + P + Dur)) of the upsampler (model.py:618-640): the range
+# parameters' gradient sums exp(-d^2 / 2 sigma^2)-weighted terms over every (phoneme, frame) pair and amplifies operand rounding
 SIGMA_PATH = ('gaussian_upsampling.projection.0.linear_layer.weight', 'gaussian_upsampling.projection.0.linear_layer.bias',
-              'gaussian_upsampling.duration_projection.conv.weight', 'gaussian_upsampling.duration_projection.conv.bias')
+              'gaussian_upsampling.duration_projection.conv.weight', 'gaussian_upsampling.duration_projection.conv.bias',
+              'gaussian_upsampling.energy_projection.conv.weight', 'gaussian_upsampling.energy_projection.conv.bias',
+              'gaussian_upsampling.pitch_projection.conv.weight', 'gaussian_upsampling.pitch_projection.conv.bias')
 
 
 def gradient_report(got, ref, rel, floor, sigma_factor=2.):
