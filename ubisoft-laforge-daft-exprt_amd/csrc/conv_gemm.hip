@@ -715,6 +715,10 @@ constexpr int WR_THREADS = 512, WR_BN = 256, WR_BM = 128;
 #ifndef WR_ABL
 #define WR_ABL 0   // compile-time ablation (development): 1 no MFMA, 2 no epilogue, 4 no global stores
 #endif
+#ifdef WR_TIMING
+__device__ unsigned long long dx_wreg_ts[8 * 64];   // [wave][stamp] of workgroup WR_TIMING - 1 (development)
+__device__ unsigned long long dx_wreg_wg[1024 * 4]; // [workgroup]{start, after prologue, end of tile loop, end} in s_memrealtime ticks (10 ns)
+#endif
 template <typename TO, typename TG, int TAPS, bool RELU, bool GATE>
 __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, int ngrp) {
   typedef bf16_t TC;
@@ -725,6 +729,9 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
   typedef typename Vec8<TC>::type frag_t;
   __shared__ __attribute__((aligned(16))) char smem[2 * A_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef WR_TIMING
+  if (tid == 0) dx_wreg_wg[blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();
+#endif
   const int l31 = lane & 31, g = lane >> 5;
   const int ztiles = p.Cout / WR_BN, ptiles = dx_cdiv(p.N, BM);
   const int grp = blockIdx.x / ztiles, co0 = (blockIdx.x % ztiles) * WR_BN + wave * 32;
@@ -734,12 +741,26 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
   const TG* G = reinterpret_cast<const TG*>(p.gate);
 
   // ---- this wave's weights, once: B fragment of k-step (tap, ks) = W[tap][co0 + l31][16 ks + 8 g .. + 8]
+  // Read straight from global memory a fragment load touches 32 rows x 2 x 16 bytes -- 64 sectors for 1 KB -- and the prologue
+  // took 9.3 us of a 43 us launch (s_memrealtime stamps per workgroup, tools/wreg_timing.py): five dependent global round trips
+  // (three taps of weights, bias, the first A tile) behind the kernel-argument load.  Now the workgroup's slice of each tap,
+  // W[tap][256 channels][128] = 64 KB CONTIGUOUS, is requested with whole-row 16-byte loads at the very top, the bias, the tile
+  // bookkeeping and the first A tile are requested behind it, and only then do the slices pass through the (still unused) A
+  // buffers, one tap at a time, for the waves to pick up their fragments.
   frag_t wreg[TAPS][KSTEPS];
+  static_assert(WR_BN * LDK * (int)sizeof(TC) <= 2 * A_BYTES, "a tap's weight slice must fit in the A buffers");
+  static_assert((WR_BN * KCH) % WR_THREADS == 0, "weight slice must split evenly over the workgroup");
+  constexpr int W_PT = WR_BN * KCH / WR_THREADS;
+  bf16x8 wtmp[TAPS][W_PT];
+  {
+    const int cblk = (blockIdx.x % ztiles) * WR_BN;
 #pragma unroll
-  for (int tap = 0; tap < TAPS; ++tap)
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const TC* src = W + ((size_t)tap * Cout + cblk) * CIN;
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks)
-      wreg[tap][ks] = *reinterpret_cast<const frag_t*>(W + ((size_t)tap * Cout + co0 + l31) * CIN + ks * 16 + g * 8);
+      for (int t = 0; t < W_PT; ++t) wtmp[tap][t] = *reinterpret_cast<const bf16x8*>(src + (size_t)(tid + t * WR_THREADS) * 8);
+    }
+  }
   // The MFMAs run with the operands swapped (weights as A, activations as B), so the accumulator tile is D[co][position]:
   // a lane holds ONE position (l31) and, per group of 4 registers, 4 CONSECUTIVE output channels (rows (r & 3) + 8 (r >> 2)
   // + 4 g) -- row-major output leaves the registers without an LDS transpose.
@@ -890,10 +911,25 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
   };
 
   int buf = 0;
-  if (left > 0) {
-    fetch(b, pt);
-    commit(0);
+  if (left > 0) fetch(b, pt);
+  {   // weights: registers (whole rows) -> LDS -> registers (MFMA fragments), see the top of the kernel
+    TC* Ws = reinterpret_cast<TC*>(smem);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      if (tap) __syncthreads();   // the previous tap's fragments have been read
+#pragma unroll
+      for (int t = 0; t < W_PT; ++t) {
+        const int c = tid + t * WR_THREADS;
+        *reinterpret_cast<bf16x8*>(&Ws[(c >> 4) * LDK + (c & 15) * 8]) = wtmp[tap][t];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks)
+        wreg[tap][ks] = *reinterpret_cast<const frag_t*>(&Ws[(wave * 32 + l31) * LDK + ks * 16 + g * 8]);
+    }
+    __syncthreads();   // the A tile of the first position tile goes into the same memory
   }
+  if (left > 0) commit(0);
   __syncthreads();
   f32x16 acc[4];
 #pragma unroll
@@ -901,6 +937,12 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   Epi prev{0, N, 0};   // n0 = N: every row out of range, nothing is stored before the first tile
+#ifdef WR_TIMING
+  if (tid == 0) dx_wreg_wg[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+  int nts = 0;
+  auto stamp = [&]() { if (blockIdx.x == WR_TIMING - 1 && lane == 0 && nts < 64) dx_wreg_ts[wave * 64 + nts] = __builtin_amdgcn_s_memtime(); ++nts; };
+  stamp();
+#endif
   while (left > 0) {
     const Epi cur{b, pt * BM, p.mask_len ? (int)p.mask_len[b] : N};
     const TC* As = reinterpret_cast<const TC*>(smem + buf * A_BYTES);
@@ -911,6 +953,9 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+#ifdef WR_TIMING
+      stamp();
+#endif
       // epilogue partner: phase A drains acc[2..3] of the previous tile, phase B drains acc[0..1] of this tile
       const Epi& ep = h == 0 ? prev : cur;
 #pragma unroll
@@ -931,15 +976,27 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
       }
     }
     prev = cur;
+#ifdef WR_TIMING
+    stamp();
+#endif
     if (left > 0) commit(buf ^ 1);
     buf ^= 1;
     __syncthreads();
+#ifdef WR_TIMING
+    stamp();
+#endif
   }
+#ifdef WR_TIMING
+  if (tid == 0) dx_wreg_wg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
   {   // drain: rows 64..127 of the last tile
 #pragma unroll
     for (int kk = 0; kk < TAPS * KSTEPS; ++kk) epi_slice(kk, &acc[2], prev, 1, Epi{0, N, 0}, 0);
   }
 
+#ifdef WR_TIMING
+  if (tid == 0) dx_wreg_wg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- dead tiles (start past length + conv halo): zeros, no reads; split evenly like the live ones
   if (p.skip_len) {
     const int cblk = (blockIdx.x % ztiles) * WR_BN;
@@ -962,6 +1019,16 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
   }
 }
 
+#ifdef WR_TIMING
+}  // namespace
+extern "C" int dx_debug_wreg_timing(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dx_wreg_ts), sizeof(unsigned long long) * 8 * 64);
+}
+extern "C" int dx_debug_wreg_wg(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dx_wreg_wg), sizeof(unsigned long long) * 1024 * 4);
+}
+namespace {
+#endif
 // weight-stationary dispatch: bf16 operands, plain row-major vectorised output, no fused LayerNorm / accumulate
 template <typename TA, typename TC, typename TO, typename TG>
 bool try_weight_stationary(const ConvArgs& a, int B, int taps, hipStream_t s) {
