@@ -122,10 +122,19 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
 #ifndef DX_RING
 #define DX_RING 4
 #endif
+#ifndef DX_PLAN_RING
+#define DX_PLAN_RING 3   // stages of the balanced-tile (plan) kernels: 3 x 41 KB (2: main loop 39.5 vs 36.1 us)
+#endif
 #ifndef DX_RING_ABL
 #define DX_RING_ABL 0   // compile-time ablation (development): 1 no fragment reads / MFMAs, 2 no loads
 #endif
 // RING: 0 = register-staged single-buffer pipeline; S >= 2 = S-stage LDS ring filled by four loader waves (512 threads, bf16)
+#ifdef CG_TIMING
+__device__ unsigned long long dx_cg_wg[1024 * 4];   // [workgroup]{start, main loop start, main loop end, end}, s_memrealtime ticks; ring kernels with LNM == CG_TIMING
+#define CG_STAMP(i) do { if (LNM == CG_TIMING && RING && tid == 0) dx_cg_wg[(blockIdx.x & 1023) * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CG_STAMP(i)
+#endif
 template <typename TA, typename TC, typename TO, typename TG, int TAPS, int MI, int BK, int LNM = 0, int RING = 0>
 __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1 ? DX_CONV_WPS_NARROW : DX_CONV_WPS)) void conv_gemm_kernel(ConvArgs p) {
   constexpr int LN = LNM == 3 ? 2 : LNM;
@@ -155,6 +164,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
   float* stage = reinterpret_cast<float*>(smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  CG_STAMP(0);
   const int l31 = lane & 31, g = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware, weight-stationary order.  Workgroup L runs on XCD L % 8 (observed dispatch order).  Every workgroup
@@ -399,11 +409,13 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
         buf = buf + 1 == RING ? 0 : buf + 1;
       }
     };
+    CG_STAMP(1);
     if (nact >= MI) mainloop(std::integral_constant<int, MI>{});
     else if (MI > 3 && nact == 3) mainloop(std::integral_constant<int, (MI > 3 ? 3 : MI)>{});
     else if (MI > 2 && nact == 2) mainloop(std::integral_constant<int, (MI > 2 ? 2 : MI)>{});
     else if (MI > 1 && nact == 1) mainloop(std::integral_constant<int, 1>{});
     else mainloop(std::integral_constant<int, 0>{});
+    CG_STAMP(2);
     }
     __syncthreads();                                 // every MFMA wave is done with the ring: the epilogue stages through it
   } else {
@@ -671,6 +683,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
         else atomicAdd(p.ln.dfilm + (size_t)b * p.ln.lddf + (q == 3 ? BN : 0) + c, t);
       }
     }
+    CG_STAMP(3);
     return;
   }
   // scalar path: transposed output (mel projection) or channel counts that are not multiples of 8
@@ -695,6 +708,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
       }
     }
   }
+  CG_STAMP(3);
 }
 
 // ---- weight-stationary variant for short contractions (Cin = 128, Cout a multiple of 256: the FF block's 128 -> 1024
@@ -1019,6 +1033,13 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
   }
 }
 
+#ifdef CG_TIMING
+}  // namespace
+extern "C" int dx_debug_cg_wg(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dx_cg_wg), sizeof(unsigned long long) * 1024 * 4);
+}
+namespace {
+#endif
 #ifdef WR_TIMING
 }  // namespace
 extern "C" int dx_debug_wreg_timing(unsigned long long* host_out) {
@@ -1079,8 +1100,8 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
     if constexpr (sizeof(TA) == 2 && sizeof(TC) == 2) {
       if (a.plan && taps == 3) {   // balanced 256-row tiles + padding-fill workgroups (dx_conv_tile_plan)
         dim3 gridp((unsigned)a.plan_tiles);
-        if (film) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 4, 32, LN, 3>), gridp, dim3(2 * NTHREADS), 0, s, a);
-        else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 4, 32, LNB, 3>), gridp, dim3(2 * NTHREADS), 0, s, a);
+        if (film) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 4, 32, LN, DX_PLAN_RING>), gridp, dim3(2 * NTHREADS), 0, s, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 4, 32, LNB, DX_PLAN_RING>), gridp, dim3(2 * NTHREADS), 0, s, a);
         DX_LAUNCH_CHECK();
         return DX_OK;
       }
