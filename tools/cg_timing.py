@@ -24,3 +24,14 @@ print('%d workgroups; start: max %.2f us | main loop start: mean %.2f max %.2f |
     len(a), a[:, 0].max(), a[:, 1].mean(), a[:, 1].max(), a[:, 2].mean(), a[:, 2].max(), a[:, 3].mean(), a[:, 3].max()))
 print('main loop: mean %.2f us (min %.2f max %.2f); epilogue: mean %.2f us (min %.2f max %.2f)' % (
     (a[:, 2] - a[:, 1]).mean(), (a[:, 2] - a[:, 1]).min(), (a[:, 2] - a[:, 1]).max(), (a[:, 3] - a[:, 2]).mean(), (a[:, 3] - a[:, 2]).min(), (a[:, 3] - a[:, 2]).max()))
+
+ch = (ctypes.c_ulonglong * 512)()
+lib.dx_debug_cg_chunk(ch)
+c = np.array(list(ch), dtype=np.int64).reshape(2, 64, 4)
+ld, mf = c[0, :30], c[1, :30]
+print('loader wave 0 of workgroup 40, s_memtime ticks per chunk: wait for landing | barrier | issue | (chunk period)')
+for k in range(2, 14):
+    print('  chunk %2d: %5d | %5d | %5d | %5d' % (k, ld[k, 1] - ld[k, 0], ld[k, 2] - ld[k, 1], ld[k, 3] - ld[k, 2], ld[k + 1, 0] - ld[k, 0]))
+print('MFMA wave 0: barrier wait | fragment reads + MFMAs | (chunk period)')
+for k in range(2, 14):
+    print('  chunk %2d: %5d | %5d | %5d' % (k, mf[k, 2] - mf[k, 1], mf[k, 3] - mf[k, 2], mf[k + 1, 1] - mf[k, 1]))

@@ -131,9 +131,12 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
 // RING: 0 = register-staged single-buffer pipeline; S >= 2 = S-stage LDS ring filled by four loader waves (512 threads, bf16)
 #ifdef CG_TIMING
 __device__ unsigned long long dx_cg_wg[1024 * 4];   // [workgroup]{start, main loop start, main loop end, end}, s_memrealtime ticks; ring kernels with LNM == CG_TIMING
+__device__ unsigned long long dx_cg_chunk[2 * 64 * 4];   // workgroup 40, loader wave 0 / MFMA wave 0: per chunk {before wait, after wait, after barrier, after issue / MFMAs} (s_memtime)
+#define CG_CHUNK(who, k, i) do { if (LNM == CG_TIMING && RING && blockIdx.x == 40 && lane == 0 && (k) < 64) dx_cg_chunk[((who) * 64 + (k)) * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define CG_STAMP(i) do { if (LNM == CG_TIMING && RING && tid == 0) dx_cg_wg[(blockIdx.x & 1023) * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define CG_STAMP(i)
+#define CG_CHUNK(who, k, i)
 #endif
 template <typename TA, typename TC, typename TO, typename TG, int TAPS, int MI, int BK, int LNM = 0, int RING = 0>
 __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1 ? DX_CONV_WPS_NARROW : DX_CONV_WPS)) void conv_gemm_kernel(ConvArgs p) {
@@ -357,10 +360,14 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
       int nbuf = RING - 1, k = 0;                                // buffer that chunk k + RING - 1 goes to
       for (; k + RING - 1 < nk; ++k) {
         // (the fill's stores share the counter and may retire out of order with the loads: drain everything once)
+        if (lw == 0) CG_CHUNK(0, k, 0);
         if (PLAN && k == 0 && stores_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else wait_landed(mine * (RING - 2));
+        if (lw == 0) CG_CHUNK(0, k, 1);
         __builtin_amdgcn_s_barrier();
+        if (lw == 0) CG_CHUNK(0, k, 2);
         issue_chunk(k + RING - 1, nbuf);
+        if (lw == 0) CG_CHUNK(0, k, 3);
         nbuf = nbuf + 1 == RING ? 0 : nbuf + 1;
       }
       for (; k < nk; ++k) {
@@ -379,9 +386,11 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
       constexpr int NA = decltype(na_tag)::value;
       int buf = 0;
       for (int k = 0; k < nk; ++k) {
+        if (wave == 0) CG_CHUNK(1, k, 1);
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (wave == 0) CG_CHUNK(1, k, 2);
         if constexpr (NA > 0) {
           const TC* Ar = ring + buf * STAGE_EL;
           const TC* Wr = Ar + AR16 * 32;
@@ -406,6 +415,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
             }
           }
         }
+        if (wave == 0) CG_CHUNK(1, k, 3);
         buf = buf + 1 == RING ? 0 : buf + 1;
       }
     };
@@ -1035,6 +1045,9 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
 
 #ifdef CG_TIMING
 }  // namespace
+extern "C" int dx_debug_cg_chunk(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dx_cg_chunk), sizeof(unsigned long long) * 2 * 64 * 4);
+}
 extern "C" int dx_debug_cg_wg(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dx_cg_wg), sizeof(unsigned long long) * 1024 * 4);
 }
