@@ -231,3 +231,26 @@ def test_adam_steps_match_reference_golden(golden_dir):
         off += p.numel()
     dn = np.array(dn)
     assert np.abs(dn - fx['adam_delta_norms']).max() <= 3e-2 * fx['adam_delta_norms'].max()
+
+
+def test_weight_copies_follow_the_parameters(golden_dir):
+    ''' the bf16 MFMA-operand copies of the weights are refreshed whenever the parameters changed through torch (in-place op,
+        load_state_dict, a torch optimizer): the model watches the version counter of its flat parameter buffer '''
+    fx = np.load(os.path.join(golden_dir, 'forward_eval.npz'))
+    hp = make_hparams(compute_dtype='bf16')
+    m = _model(hp).eval()
+    assert not m.always_repack
+    inputs = load_inputs(fx, DEV)
+    with torch.no_grad():
+        mel0 = m(inputs)[3][0].clone()
+        mel0b = m(inputs)[3][0].clone()
+        assert torch.equal(mel0, mel0b)
+        w = dict(m.named_parameters())['frame_decoder.projection.linear_layer.weight']
+        w.mul_(2.)                                        # in-place under no_grad
+        mel1 = m(inputs)[3][0].clone()
+        assert float((mel1 - mel0).abs().max()) > 1e-3
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        sd['frame_decoder.projection.linear_layer.weight'] *= 0.5
+        m.load_state_dict(sd)                             # back to the original weights
+        mel2 = m(inputs)[3][0].clone()
+    assert torch.equal(mel2, mel0)

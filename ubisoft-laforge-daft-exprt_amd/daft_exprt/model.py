@@ -182,7 +182,10 @@ class DaftExprt(nn.Module):
         assert [n for n, _ in self.named_parameters()] == [n for n, _, _ in self._table]
         self._flat = self._gflat = None
         self._packed, self._packed_version, self._param_version = {}, -1, 0
-        self.always_repack = True   # safe default for external optimizers; the fused trainer turns it off
+        # True: re-pack the bf16 weight copies on every call.  Not needed for anything that goes through torch: `_weights` watches
+        # the version counters of the GEMM weights, so load_state_dict, torch.optim steps and in-place ops under no_grad are all
+        # seen; only writes through `.data` (or a foreign kernel) are invisible -- those callers use `mark_updated()`
+        self.always_repack = False
         self._anchor = None
         self._side = self._side_stream = None
         self._wgrad_keep = []
@@ -289,9 +292,10 @@ class DaftExprt(nn.Module):
                     bwd.append((w, self._packed['T:' + name], True))
             self._pack_fwd, self._pack_bwd = ops.pack_table(fwd, dev), ops.pack_table(bwd, dev)
             self._packed_version = self._dgrad_version = -1
-        if self._packed_version != self._param_version or self.always_repack:
+        version = (self._param_version, tuple(self._params[n]._version for n in self._gemm_weights))
+        if self._packed_version != version or self.always_repack:
             ops.pack_weights_batched(*self._pack_fwd, self.cd)
-            self._packed_version = self._param_version
+            self._packed_version = version
             self._dgrad_version = -1
         if need_dgrad and self._dgrad_version != self._packed_version:
             ops.pack_weights_batched(*self._pack_bwd, self.cd)
