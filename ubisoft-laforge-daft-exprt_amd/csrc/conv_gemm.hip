@@ -126,7 +126,7 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
 #define DX_PLAN_RING 3   // stages of the balanced-tile (plan) kernels: 3 x 41 KB (2: main loop 39.5 vs 36.1 us)
 #endif
 #ifndef DX_RING_ABL
-#define DX_RING_ABL 0   // compile-time ablation (development): 1 no fragment reads / MFMAs, 2 no loads
+#define DX_RING_ABL 0   // compile-time ablation (development): 1 no fragment reads / MFMAs, 2 no loads, 4 no activation pieces, 8 no weight pieces
 #endif
 // RING: 0 = register-staged single-buffer pipeline; S >= 2 = S-stage LDS ring filled by four loader waves (512 threads, bf16)
 #ifdef CG_TIMING
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
         if (DX_RING_ABL & 2) return;
 #pragma unroll
         for (int t = 0; t < MAXP; ++t)
-          if (t < mine)
+          if (t < mine && !((DX_RING_ABL & 4) && dst[t] < (AR16 / 16) * 512) && !((DX_RING_ABL & 8) && dst[t] >= (AR16 / 16) * 512))   // ablations: 4 no activation pieces, 8 no weight pieces
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + kc * 32),
                                              (__attribute__((address_space(3))) void*)(ring + buf * STAGE_EL + dst[t]), 16, 0, 0);
       };
