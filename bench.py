@@ -38,6 +38,42 @@ def f_fwd(T, L):
     return T * (21222912 + 4096 * T + 256 * L) + L * (7409664 + 2048 * L) + 723712
 
 
+def f_synth(T_ref, T_gen, L):
+    ''' the same model split for the synthesis path (forward only): prosody encoder on the T_ref reference frames (pre-net
+        7 570 944 + 4 FFT blocks of 1 703 936 + 512 T_ref per frame), mel decoder on the T_gen generated frames (4 blocks + mel
+        projection 20 480 + Gaussian upsampling 256 L per frame), phoneme side and per-utterance heads as in f_fwd;
+        f_synth(T, T, L) == f_fwd(T, L) '''
+    return T_ref * (14386688 + 2048 * T_ref) + T_gen * (6836224 + 2048 * T_gen + 256 * L) + L * (7409664 + 2048 * L) + 723712
+
+
+def csrc_sha16():
+    ''' fingerprint of the kernel sources: recorded PMC figures are only quoted for the build they were measured on '''
+    import hashlib
+    d = os.path.join(ROOT, 'ubisoft-laforge-daft-exprt_amd', 'csrc')
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h', '.cpp')):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def recorded_counters(tag):
+    ''' newest committed PMC summary profiles/rNN_<tag>.json recorded for THIS kernel build (tools/pmc_counters.py stores the
+        csrc fingerprint), or (None, reason) '''
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_{tag}.json')), reverse=True)
+    for path in paths:
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get('csrc_sha16') == csrc_sha16():
+            return rec, os.path.relpath(path, ROOT)
+        return None, f'{os.path.relpath(path, ROOT)} was recorded for kernel build {rec.get("csrc_sha16")}, this build is {csrc_sha16()}: not quoted'
+    return None, 'no PMC summary committed'
+
+
 def make_hparams(batch, dtype):
     from daft_exprt.hparams import HyperParams
     return HyperParams(verbose=False, training_files='none', validation_files='none', output_directory='/nonexistent_out',
@@ -88,50 +124,170 @@ def cpu_baseline(hp, batch, n_utt=4, warmup=2, steps=5):
             's_per_step_median': med, 's_per_step_min': timed[0], 's_per_step_max': timed[-1], 'cpu_model': _cpu_model()}
 
 
-def measured_traffic(kernel_family):
+def measured_traffic(kernel_family, tag='counters'):
     ''' HBM-side bytes per launch of the roofline kernel family from the committed PMC summary (rocprofv3 --pmc
         FETCH_SIZE / --pmc WRITE_SIZE in separate passes, gfx950 x2 fetch correction applied; written by
         tools/pmc_counters.py from the same bench command).  PMC counters cannot be read from inside this process, so
-        the number is the recorded one for this kernel build; None when no summary is committed. '''
-    path = os.path.join(ROOT, 'profiles', 'r02_counters.json')
-    try:
-        rec = json.load(open(path))['families'][kernel_family]
-        return {'bytes_per_launch': rec['fetch_x2_bytes'] + rec['write_bytes'], 'fetch_x2_bytes': rec['fetch_x2_bytes'],
-                'write_bytes': rec['write_bytes'], 'launches': rec['launches'], 'mfma_util': rec.get('mfma_util'),
-                'source': 'profiles/r02_counters.json (rocprofv3 --pmc, recorded run of this bench command)'}
-    except (OSError, KeyError, ValueError):
-        return None
+        this is a RECORDED figure: it is quoted only when the summary carries the fingerprint of the kernel sources that
+        are running now (otherwise null + the reason). '''
+    rec, src = recorded_counters(tag)
+    if rec is None:
+        return {'bytes_per_launch': None, 'note': src}
+    fam = rec.get('families', {}).get(kernel_family)
+    if not fam or 'fetch_x2_bytes' not in fam:
+        return {'bytes_per_launch': None, 'note': f'{src}: no entry for {kernel_family}'}
+    return {'bytes_per_launch': fam['fetch_x2_bytes'] + fam['write_bytes'], 'fetch_x2_bytes': fam['fetch_x2_bytes'],
+            'write_bytes': fam['write_bytes'], 'launches': fam['launches'], 'mfma_util': fam.get('mfma_util'),
+            'source': f'{src} (rocprofv3 --pmc, recorded run of this bench command on this kernel build {rec["csrc_sha16"]})'}
+
+
+def hbm_line(ms_per_step, tag='counters'):
+    ''' whole-step HBM traffic (sum over every kernel of FETCH_SIZE x 2 + WRITE_SIZE per step, recorded PMC passes) over the
+        LIVE step time, against the 8 TB/s HBM3E peak of MI355X_MICROARCH.md '''
+    rec, src = recorded_counters(tag)
+    if rec is None or 'whole_step' not in rec:
+        return {'gbps': None, 'note': src}
+    b = rec['whole_step']['fetch_x2_bytes'] + rec['whole_step']['write_bytes']
+    return {'gbps': b / (ms_per_step * 1e-3) / 1e9, 'peak_gbps': 8000., 'frac': b / (ms_per_step * 1e-3) / 8e12, 'bytes_per_step': b,
+            'fetch_x2_bytes_per_step': rec['whole_step']['fetch_x2_bytes'], 'write_bytes_per_step': rec['whole_step']['write_bytes'],
+            'source': f'{src}: bytes per step from the recorded --pmc passes (kernel build {rec["csrc_sha16"]}), time from this run'}
+
+
+def family_tables(fam, nprobe, valid_frac, peak):
+    ''' per-family {ms, launches, achieved TFLOP/s, fraction of peak}; algorithmic FLOPs = padded-dense FLOPs of each launch
+        scaled by the valid fraction of its time / phoneme axis (valid_frac(k, n_axis)) '''
+    out = {}
+    for fname, (fms, frecs) in fam.items():
+        falg, per_step = 0., len(frecs) // nprobe
+        for k in range(nprobe):
+            for s_, e_, fl, n_axis in frecs[k * per_step: (k + 1) * per_step]:
+                falg += fl * valid_frac(k, n_axis)
+        out[fname] = {'ms_per_step': fms / nprobe, 'launches_per_step': per_step, 'achieved_tflops': falg / (fms * 1e-3) / 1e12,
+                      'frac_of_peak': falg / (fms * 1e-3) / peak, 'algorithmic_gflop_per_step': falg / nprobe / 1e9,
+                      'stream': 'side (overlapped with the main stream)' if fname == 'conv_wgrad' else 'main'}
+    return out
+
+
+def cpu_baseline_synth(hp, cpu_inputs, n_utt=8, warmup=2, steps=5):
+    ''' the CPU oracle's `inference` (oracle/daft_exprt_cpu.py, a port of model.py:866-923) timed on this host on every
+        (B / n_utt)-th sentence of the bench batch (bounded sample), `warmup` + `steps` calls, median '''
+    from oracle import daft_exprt_cpu as O
+    P = O.random_params(hp, seed=0)
+    with torch.no_grad():   # same centring of the duration head as the GPU run (random-init weights predict arbitrary durations)
+        P['prosody_predictor.projection.linear_layer.weight'][0].mul_(0.05)
+        P['prosody_predictor.projection.linear_layer.bias'].copy_(torch.tensor([0.08, 0., 0.]))
+    B = cpu_inputs[0].shape[0]
+    idx = torch.arange(0, B, max(1, B // n_utt))[:n_utt]
+    cin = [t[idx].clone() for t in cpu_inputs]
+    L, T = int(cin[4].max()), int(cin[8].max())
+    for i in (0, 1, 2, 3):
+        cin[i] = cin[i][:, :L]
+    cin[5], cin[6], cin[7] = cin[5][:, :T], cin[6][:, :T], cin[7][:, :, :T]
+    times, frames = [], 0
+    for s in range(warmup + steps):
+        t0 = time.time()
+        enc, dec, _ = O.inference(P, hp, tuple(t.clone() for t in cin), 'add')
+        times.append(time.time() - t0)
+        frames = int(dec[1].sum())
+    timed = sorted(times[warmup:])
+    med = timed[len(timed) // 2]
+    return {'value': len(idx) / med, 'unit': 'utterances/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{warmup} warm-up + {steps} timed calls of the CPU oracle inference (fp32) on {len(idx)} sentences of the bench batch '
+                      f'(every {max(1, B // n_utt)}-th; L_max={L}, T_ref_max={T}, {frames} generated frames), median; '
+                      f'host os.cpu_count()={os.cpu_count()}, torch threads={torch.get_num_threads()}, CPU "{_cpu_model()}"',
+            'generated_frames_per_s': frames / med, 's_per_call_median': med, 's_per_call_min': timed[0], 's_per_call_max': timed[-1],
+            'cpu_model': _cpu_model()}
 
 
 def synth_bench(args, hp, dev, rank, world):
     ''' BASELINE configs[3]: batched prosody-transfer synthesis, forward only (prosody encoder on the reference mels ->
-        phoneme encoder -> predictor -> integer durations -> Gaussian upsampling -> mel decoder), B sentences per call '''
+        phoneme encoder -> predictor -> integer durations -> Gaussian upsampling -> mel decoder), B sentences per call.
+        Accounting follows the reference's own (generate.py:413-435, scripts/synthesize.py:117-135): sentences and generated
+        frames per second of wall time of the batched call, RTF = generated audio seconds per second. '''
+    from daft_exprt import ops
     from daft_exprt.data_loader import centre_duration_head, synthetic_inference_batch
     from daft_exprt.model import DaftExprt
     model = DaftExprt(hp).to(dev).eval()
     centre_duration_head(model)   # duration head centred on ~80 ms so that random-init weights give utterances of realistic length
     hp.stats = {f'spk {i}': {'pitch': {'mean': 5.0, 'std': 0.3}} for i in range(hp.n_speakers)}
     B = args.batch
-    inputs = tuple(t.to(dev) for t in synthetic_inference_batch(hp, B, seed=1234 + rank))
-    frames = 0
+    cpu_inputs = synthetic_inference_batch(hp, B, seed=1234 + rank)
+    inputs = tuple(t.to(dev) for t in cpu_inputs)
+    frames, flops = 0, 0.
     for w in range(args.warmup):
         out = model.inference(tuple(t.clone() for t in inputs), 'add', hp)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
+    lens = []
     for k in range(args.steps):
         enc, dec, _ = model.inference(tuple(t.clone() for t in inputs), 'add', hp)
-        frames += int(dec[1].sum())
+        lens.append(dec[1])
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     elapsed = time.perf_counter() - t0
+    L_list, Tr_list = cpu_inputs[4].tolist(), cpu_inputs[8].tolist()
+    for ol in lens:
+        ol = ol.tolist()
+        frames += sum(ol)
+        flops += sum(f_synth(int(tr), int(tg), int(l)) for tr, tg, l in zip(Tr_list, ol, L_list))
+    stats = torch.tensor([elapsed, float(B * args.steps), float(frames), flops], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tot = stats[1:].clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        stats = torch.cat([tmax, tot])
+    elapsed, utts, frames, flops = [float(v) for v in stats]
+    peak = PEAK_MFMA_BF16 if args.dtype == 'bf16' else 157.3e12
+    roofline = None
+    if not args.no_probe:
+        ops.PROBE = {}
+        nprobe = min(args.steps, 3)
+        outl = []
+        for k in range(nprobe):
+            enc, dec, _ = model.inference(tuple(t.clone() for t in inputs), 'add', hp)
+            outl.append(dec[1])
+        torch.cuda.synchronize()
+        fam = {name: (sum(s_.elapsed_time(e_) for s_, e_, _, _ in recs), recs) for name, recs in ops.PROBE.items()}
+        ops.PROBE = None
+        Lm, Trm = int(inputs[0].shape[1]), int(inputs[7].shape[2])
+        fL, fTr = float(inputs[4].sum()) / (B * Lm), float(inputs[8].sum()) / (B * Trm)
+
+        def valid_frac(k, n_axis):   # launches are identified by the length of their position axis
+            if n_axis == Trm:
+                return fTr
+            if n_axis == Lm:
+                return fL
+            return float(outl[k].sum()) / (B * n_axis)   # decoder: generated frames of this call
+        families = family_tables(fam, nprobe, valid_frac, peak)
+        name = max(families, key=lambda n: families[n]['ms_per_step'])
+        f = families[name]
+        roofline = {'kernel': f'{name} (conv / linear as implicit GEMM, all call sites of the synthesis path)', 'bound': 'mfma',
+                    'achieved': f['achieved_tflops'], 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': f['frac_of_peak'],
+                    'traffic': measured_traffic(name, 'synth_counters') if (B == 256 and args.dtype == 'bf16') else None,
+                    'launches_per_step': f['launches_per_step'], 'avg_launch_us': f['ms_per_step'] * 1e3 / max(1, f['launches_per_step']),
+                    'algorithmic_gflop_per_launch': f['algorithmic_gflop_per_step'] / max(1, f['launches_per_step']),
+                    'share_of_step_time': f['ms_per_step'] / (elapsed / args.steps * 1e3), 'families': families,
+                    'whole_step': {'achieved': flops / elapsed / world / 1e12, 'unit': 'TFLOP/s per GPU (algorithmic, sum of f_synth over the generated utterances)',
+                                   'frac': flops / elapsed / world / peak},
+                    'hbm': hbm_line(elapsed / args.steps * 1e3, 'synth_counters') if (B == 256 and args.dtype == 'bf16') else None}
     if rank == 0:
-        print(json.dumps({'metric': 'synth-path mels/sec', 'value': B * args.steps / elapsed, 'unit': 'utterances/s', 'n_gpus': world,
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline_synth(hp, cpu_inputs)
+        print(json.dumps({'metric': 'synth-path mels/sec', 'value': utts / elapsed, 'unit': 'utterances/s', 'n_gpus': world,
                           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
                           'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
                           'config': {'workload': f'BASELINE configs[3]: batched prosody-transfer synthesis, {B} sentences per call, '
                                                  'L~U{40..160}, reference mels T~U{250..1000}, forward only', 'global_batch': B * world,
-                                     'generated_frames_per_s': frames / elapsed, 'mean_generated_frames': frames / args.steps / B,
-                                     'audio_seconds_per_s (RTF)': frames / elapsed * hp.hop_length / hp.sampling_rate},
-                          'roofline': None, 'cpu_baseline': None}))
+                                     'generated_frames_per_s': frames / elapsed, 'mean_generated_frames': frames / utts,
+                                     'audio_seconds_per_s (RTF^-1 of generate.py:422-435)': frames / elapsed * hp.hop_length / hp.sampling_rate},
+                          'roofline': roofline, 'cpu_baseline': cpu}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def spawn_ranks(n):
@@ -246,40 +402,26 @@ def main():
         main_fams = {n: v for n, v in fam.items() if n != 'conv_wgrad'} or fam
         name = max(main_fams, key=lambda n: main_fams[n][0])
         ms, recs = fam[name]
-        # algorithmic FLOPs: padded-dense FLOPs of each launch scaled by the valid fraction of its time/phoneme axis
-        alg = 0.
-        for k in range(nprobe):
+        peak = PEAK_MFMA_BF16 if args.dtype == 'bf16' else 157.3e12
+
+        def valid_frac(k, n_axis):   # padded-dense FLOPs of a launch x the valid fraction of its time / phoneme axis
             inp = batches[k % args.pool][0]
             Tm, Lm = int(inp[8].shape[2]), int(inp[0].shape[1])
-            fT, fL = float(inp[9].sum()) / (inp[9].numel() * Tm), float(inp[5].sum()) / (inp[5].numel() * Lm)
-            per_step = len(recs) // nprobe
-            for s, e, fl, n_axis in recs[k * per_step: (k + 1) * per_step]:
-                alg += fl * (fT if n_axis == Tm else fL)
+            return float(inp[9].sum()) / (inp[9].numel() * Tm) if n_axis == Tm else float(inp[5].sum()) / (inp[5].numel() * Lm)
+        families = family_tables(fam, nprobe, valid_frac, peak)
+        f = families[name]
         n_launch = len(recs)
-        achieved = alg / (ms * 1e-3) / 1e12
-        families = {}
-        for fname, (fms, frecs) in fam.items():
-            falg = 0.
-            per_step = len(frecs) // nprobe
-            for k in range(nprobe):
-                inp = batches[k % args.pool][0]
-                Tm, Lm = int(inp[8].shape[2]), int(inp[0].shape[1])
-                fT, fL = float(inp[9].sum()) / (inp[9].numel() * Tm), float(inp[5].sum()) / (inp[5].numel() * Lm)
-                for s_, e_, fl, n_axis in frecs[k * per_step: (k + 1) * per_step]:
-                    falg += fl * (fT if n_axis == Tm else fL)
-            families[fname] = {'ms_per_step': fms / nprobe, 'launches_per_step': per_step, 'achieved_tflops': falg / (fms * 1e-3) / 1e12,
-                               'frac_of_peak': falg / (fms * 1e-3) / (PEAK_MFMA_BF16 if args.dtype == 'bf16' else 157.3e12),
-                               'stream': 'side (overlapped with the main stream)' if fname == 'conv_wgrad' else 'main'}
+        c2 = args.batch == 48 and args.tmin == 1 and args.dtype == 'bf16'
         roofline = {'kernel': f'{name} (conv / linear as implicit GEMM on the main stream, all call sites)', 'bound': 'mfma',
-                    'achieved': achieved, 'peak': PEAK_MFMA_BF16 / 1e12 if args.dtype == 'bf16' else 157.3, 'unit': 'TFLOP/s',
-                    'frac': achieved / (PEAK_MFMA_BF16 / 1e12 if args.dtype == 'bf16' else 157.3),
-                    'traffic': measured_traffic(name) if (args.batch == 48 and args.tmin == 1 and args.dtype == 'bf16') else None,
+                    'achieved': f['achieved_tflops'], 'peak': peak / 1e12, 'unit': 'TFLOP/s', 'frac': f['frac_of_peak'],
+                    'traffic': measured_traffic(name) if c2 else None,
                     'launches_per_step': n_launch // nprobe, 'avg_launch_us': ms * 1e3 / n_launch,
-                    'algorithmic_gflop_per_launch': alg / n_launch / 1e9,
+                    'algorithmic_gflop_per_launch': f['algorithmic_gflop_per_step'] * nprobe / n_launch,
                     'share_of_step_time': (ms / nprobe) / (elapsed / args.steps * 1e3),
                     'families_ms_per_step': {k: v[0] / nprobe for k, v in fam.items()}, 'families': families,
                     'whole_step': {'achieved': done_flops / elapsed / world / 1e12, 'unit': 'TFLOP/s per GPU (algorithmic 3*F_fwd)',
-                                   'frac': done_flops / elapsed / world / (PEAK_MFMA_BF16 if args.dtype == 'bf16' else 157.3e12)}}
+                                   'frac': done_flops / elapsed / world / peak},
+                    'hbm': hbm_line(elapsed / args.steps * 1e3) if c2 else None}
 
     if rank == 0:
         cpu = None

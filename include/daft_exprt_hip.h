@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DX_ABI_VERSION 7
+#define DX_ABI_VERSION 8
 
 enum { DX_F32 = 0, DX_BF16 = 1, DX_I64 = 2 };
 enum { DX_OK = 0, DX_ERR_ARG = -1, DX_ERR_SHAPE = -2, DX_ERR_DTYPE = -3, DX_ERR_LAUNCH = -4, DX_ERR_UNSUPPORTED = -5 };
@@ -96,27 +96,6 @@ int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void* w_packed, 
 int dx_conv_tile_plan_size(int B, int N);
 int dx_conv_tile_plan(const int64_t* lengths, int B, int N, int n_tiles, int* table, void* stream);
 
-/* K2 of SURVEY 2c -- the position-wise feed-forward half of an FFT block in ONE launch, replaces PositionWiseConvFF.forward
- * (src/daft_exprt/model.py:220-237) + the masked_fill that follows it (model.py:262):
- *   h = ReLU(conv_k3(x; W1, b1))   128 -> C;   z = conv_k3(h; W2, b2)   C -> 128;
- *   y = [film_gamma * ] LayerNorm(dropout(z; p_pre, seed_pre) + residual) [+ film_beta], rows >= lengths[b] zero.
- * bf16 operands only.  x_lp (B, N, 128) bf16 is the GEMM-operand copy of `residual` (B, N, 128) fp32; w1_packed
- * [3][C][128] and w2_packed [3][128][C] are the forward packings of dx_pack_conv_weight; C a multiple of 64.
- * The hidden tensor never makes the HBM round trip of the two-kernel path: a workgroup recomputes the chunk of h it needs
- * (its tile + 1 halo row per side) from an activation tile resident in LDS and feeds conv 2 from LDS; h_out (B, N, C) bf16
- * is written once for the backward pass (rows 0 .. lengths[b] of every utterance -- row lengths[b] is the first padding
- * row, which the reference does NOT mask between the two convolutions, SURVEY App. B item 1 -- plus zeros in the next 130
- * rows; anything further is left untouched and is never multiplied by a non-zero gradient).
- * y, y_lp (optional bf16 copy), s_out / mean / rstd (optional, saved LayerNorm input and statistics) as in dx_conv1d_ln,
- * same dropout counters, so both paths draw the same mask for a given seed.
- * plan: table of dx_ff_plan (n_tiles = dx_ff_plan_size(B, N) entries {b, n0, rows <= 126, fill}, one per workgroup). */
-int dx_ff_plan_size(int B, int N);
-int dx_ff_plan(const int64_t* lengths, int B, int N, int n_tiles, int* table, void* stream);
-int dx_ff_fused_fwd(const void* x_lp, const void* w1_packed, const float* b1, const void* w2_packed, const float* b2,
-                    const float* residual, const float* gamma, const float* beta, const float* film, long ldf,
-                    const int64_t* lengths, void* h_out, float* y, void* y_lp, float* s_out, float* mean, float* rstd,
-                    int B, int N, int C, float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, void* stream);
-
 /* Pack an fp32 (Cout, Cin, taps) PyTorch conv / (Cout, Cin) linear weight for dx_conv1d.
  *   transpose_flip = 0: out[tap][co][ci] = w[co][ci][tap]                (forward operand)
  *   transpose_flip = 1: out[tap][ci][co] = w[co][ci][taps-1-tap]         (data-gradient operand) */
@@ -183,10 +162,14 @@ long dx_layernorm_bwd_ws_floats(int B, int N, int C);
 int dx_attention_fwd(const void* qkv, int dtype, const int64_t* lengths, const int* order, void* o, float* lse, int B, int N,
                      int H, int E, float p_drop, uint64_t seed, void* stream);
 
-/* Backward of dx_attention_fwd: dqkv (B, N, 3E) <- d_o (B, N, E).  delta_ws: (B, H, N) fp32 workspace. */
+/* Backward of dx_attention_fwd (autograd of model.py:182-186): dqkv (B, N, 3E) <- d_o (B, N, E).  delta_ws: (B, H, N) fp32 workspace.
+ * algo: DX_ATTN_AUTO picks the fused kernel where it exists (bf16, d_head 16, N <= 1024: one workgroup per (utterance, head)
+ * recomputes S / dP once for dQ, dK and dV) and the two-pass pair (dQ kernel, dK/dV kernel) elsewhere; DX_ATTN_TWO_PASS forces the
+ * pair; DX_ATTN_FUSED returns DX_ERR_UNSUPPORTED where the fused kernel does not apply.  Both draw the forward's dropout mask. */
+enum { DX_ATTN_AUTO = 0, DX_ATTN_TWO_PASS = 1, DX_ATTN_FUSED = 2 };
 int dx_attention_bwd(const void* qkv, const void* o, const void* d_o, int dtype, const float* lse,
                      const int64_t* lengths, const int* order, void* dqkv, float* delta_ws, int B, int N, int H, int E,
-                     float p_drop, uint64_t seed, void* stream);
+                     float p_drop, uint64_t seed, int algo, void* stream);
 
 /* order[r] = index of the utterance with the r-th largest length (ties: lower index first), B <= 65536.  Host-side
  * analogue: the reference's collate sorts a batch by decreasing phoneme count (data_loader.py:246-250); the attention

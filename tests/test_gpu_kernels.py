@@ -82,6 +82,60 @@ def test_attention_dropout_keep_rate():
     assert float(per_q.std()) > 1e-3      # dropout really happened
 
 
+def _attn_ref_grads(qkv, d_o, lens, H):
+    ''' fp32 torch autograd of the attention core (no dropout), pad keys masked, pad queries excluded '''
+    B, N, E3 = qkv.shape
+    E, dh = E3 // 3, E3 // 3 // H
+    x = qkv.float().clone().requires_grad_(True)
+    q, k, v = [t.reshape(B, N, H, dh).transpose(1, 2) for t in x.split(E, dim=2)]
+    s = (q @ k.transpose(2, 3)) / dh ** 0.5
+    pad = torch.arange(N, device=qkv.device)[None, :] >= lens[:, None]
+    s = s.masked_fill(pad[:, None, None, :], float('-inf'))
+    s = s.masked_fill((lens == 0)[:, None, None, None], 0.)          # a zero-length utterance: keep its (unused) softmax finite
+    o = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, N, E)
+    (o * d_o.float() * (~pad).unsqueeze(2)).sum().backward()
+    return x.grad * (~pad).unsqueeze(2)
+
+
+@pytest.mark.parametrize('N,lens', [(150, [150, 97, 33]), (1000, [1000, 624, 31, 257]), (1024, [1024, 1, 512]), (70, [0, 70, 64])])
+def test_attention_fused_backward_matches_two_pass_and_fp32_reference(N, lens):
+    ''' the fused d_head = 16 backward kernel (one recomputation of S / dP for dQ, dK, dV; keys split over the waves, queries
+        streamed, dQ partials summed in wave order) against (a) the two-pass kernels on the same dropout mask: same bf16 rounding
+        points, so only fp32 summation order differs; (b) torch fp32 autograd without dropout '''
+    from daft_exprt import ops
+    B, H, E = len(lens), 8, 128
+    g = torch.Generator().manual_seed(N)
+    qkv = (torch.randn(B, N, 3 * E, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    lens_t = torch.tensor(lens, device=DEV)
+    valid = (torch.arange(N, device=DEV)[None, :] < lens_t[:, None]).unsqueeze(2)
+    d_o = (torch.randn(B, N, E, generator=g).to(DEV) * valid).to(torch.bfloat16)
+    for p, seed in ((0.1, 4242), (0., 0)):
+        o, lse = ops.attention_fwd(qkv, lens_t, H, p, seed)
+        two = ops.attention_bwd(qkv, o, d_o, lse, lens_t, H, p, seed, algo=ops.ATTN_TWO_PASS).float()
+        fus = ops.attention_bwd(qkv, o, d_o, lse, lens_t, H, p, seed, algo=ops.ATTN_FUSED).float()
+        assert torch.isfinite(fus).all()
+        assert float((fus * ~valid).abs().max()) == 0.          # pad rows are exact zeros
+        scale = float(two.abs().max())
+        err = float((fus - two).abs().max())
+        assert err <= 1.5e-2 * scale, (p, err, scale)            # a handful of 1-ulp bf16 flips of the stored gradients
+        assert float((fus - two).abs().mean()) <= 2e-4 * scale
+        again = ops.attention_bwd(qkv, o, d_o, lse, lens_t, H, p, seed, algo=ops.ATTN_FUSED).float()
+        assert torch.equal(again, fus)                           # no atomics: bit-reproducible
+        order = ops.length_order(lens_t)
+        assert torch.equal(ops.attention_bwd(qkv, o, d_o, lse, lens_t, H, p, seed, order=order, algo=ops.ATTN_FUSED).float(), fus)
+    ref = _attn_ref_grads(qkv, d_o, lens_t, H)
+    scale = float(ref.abs().max())
+    assert float((fus - ref).abs().max()) <= 3e-2 * scale and float((fus - ref).abs().mean()) <= 2e-3 * scale
+
+
+def test_attention_fused_backward_is_refused_where_it_does_not_apply():
+    from daft_exprt import ops
+    qkv, lens = _attn_inputs(2, 64, 2, 128, 1, torch.bfloat16)
+    o, lse = ops.attention_fwd(qkv, lens, 2, 0., 0)
+    with pytest.raises(RuntimeError, match='fused kernel'):
+        ops.attention_bwd(qkv, o, torch.zeros_like(o), lse, lens, 2, algo=ops.ATTN_FUSED)
+
+
 @pytest.mark.parametrize('C', [128, 256, 1024])
 def test_layernorm_dropout_forward_backward_consistency(C):
     from daft_exprt import ops

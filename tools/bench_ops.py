@@ -132,9 +132,11 @@ def bench_attn():
             d_o = torch.randn(B, N, E, device=dev).to(torch.bfloat16)
             t_f = timeit(lambda: ops.attention_fwd(qkv, lens, H, 0.1, 7))
             t_f0 = timeit(lambda: ops.attention_fwd(qkv, lens, H, 0., 7))
-            t_b = timeit(lambda: ops.attention_bwd(qkv, o, d_o, lse, lens, H, 0.1, 7))
+            order = ops.length_order(lens)
+            t_b = timeit(lambda: ops.attention_bwd(qkv, o, d_o, lse, lens, H, 0.1, 7, order=order))
+            t_b2 = timeit(lambda: ops.attention_bwd(qkv, o, d_o, lse, lens, H, 0.1, 7, order=order, algo=ops.ATTN_TWO_PASS))
             el = float((lens.double() ** 2).sum()) * H
-            print(f'attn[{tag}] d_h={E // H}: fwd {t_f * 1e3:6.1f} us (no dropout {t_f0 * 1e3:6.1f}) bwd {t_b * 1e3:6.1f} us | '
+            print(f'attn[{tag}] d_h={E // H}: fwd {t_f * 1e3:6.1f} us (no dropout {t_f0 * 1e3:6.1f}) bwd {t_b * 1e3:6.1f} us (two-pass {t_b2 * 1e3:6.1f}) | '
                   f'{el / 1e6:.0f} M (q,k) pairs -> fwd {t_f * 1e-3 / el * 1e12:.2f} ps/pair bwd {t_b * 1e-3 / el * 1e12:.2f} ps/pair')
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'attn':
@@ -188,34 +190,3 @@ def bench_lnbwd():
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'lnbwd':
     bench_lnbwd()
 
-
-def bench_ff():
-    ''' feed-forward half of an FFT block, frame level (B = 48, T <= 1000 ragged): fused kernel vs conv1 + conv2/LN launches '''
-    dev = torch.device('cuda:0')
-    B, N, C = int(os.environ.get('FF_B', 48)), 1000, 1024
-    g = torch.Generator().manual_seed(0)
-    lens = torch.randint(250, 1001, (B,), generator=g)
-    lens[0] = N
-    lens = lens.to(dev)
-    a = torch.randn(B, N, 128, device=dev)
-    a_lp = a.to(torch.bfloat16)
-    w1 = ops.pack_conv_weight(torch.randn(C, 128, 3, device=dev) / 20, torch.bfloat16)
-    w2 = ops.pack_conv_weight(torch.randn(128, C, 3, device=dev) / 55, torch.bfloat16)
-    b1, b2 = torch.randn(C, device=dev) * .1, torch.randn(128, device=dev) * .1
-    gm, bt = torch.ones(128, device=dev), torch.zeros(128, device=dev)
-    film = torch.randn(B, 256, device=dev)
-    plan, fplan = ops.conv_tile_plan(lens, N), ops.ff_plan(lens, N)
-
-    def pair():
-        h = ops.conv1d(a_lp, w1, b1, out_dtype=torch.bfloat16, relu=True, skip_lengths=lens)
-        return ops.conv1d_ln(h, w2, b2, a, gm, bt, lens, film=film, save=True, p_pre=0.1, seed_pre=3, lp_copy=True, plan=plan)
-    t_pair = timeit(pair)
-    t_fused = timeit(lambda: ops.ff_fused_fwd(a_lp, w1, b1, w2, b2, a, gm, bt, lens, fplan, film=film, save=True, p_pre=0.1, seed_pre=3))
-    rows = int(lens.sum())
-    fl = 2. * rows * 128 * C * 3 * 2
-    print(f'FF forward, {rows} valid rows: two launches {t_pair * 1e3:6.1f} us ({fl / t_pair / 1e9:.0f} TFLOP/s) | fused {t_fused * 1e3:6.1f} us '
-          f'({fl / t_fused / 1e9:.0f} TFLOP/s)')
-
-
-if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'ff':
-    bench_ff()

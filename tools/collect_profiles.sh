@@ -4,7 +4,7 @@
 # kernel trace + step timeline, three separate PMC passes (FETCH_SIZE / WRITE_SIZE / MFMA busy: they do not fit the TCC
 # slots together, and gpurun refuses --pmc combined with the other trace domains), bench lines of C2 / C5 / C4.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -20,8 +20,19 @@ rm -rf $OUT/kt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -- $CMD > /dev/null 2> $OUT/pmc1.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -- $CMD > /dev/null 2> $OUT/pmc2.err
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES -d $OUT/pmc_mfma -- $CMD > /dev/null 2> $OUT/pmc3.err
-python tools/pmc_counters.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma --out $OUT/${TAG}_counters.json --command "$CMD" > $OUT/counters_summary.txt
+python tools/pmc_counters.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma --out $OUT/${TAG}_counters.json --command "$CMD" --steps-total 5 > $OUT/counters_summary.txt
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma
+# synthesis path (BASELINE configs[3]): kernel trace + the same three PMC passes
+SCMD="python bench.py --workload synth --batch 256 --steps 3 --warmup 2 --no-cpu-baseline --no-probe"
+rocprofv3 --kernel-trace -d $OUT/skt -- python bench.py --workload synth --batch 256 --steps 10 --warmup 3 --no-cpu-baseline --no-probe > /dev/null 2> $OUT/skt.err
+SDB=$(ls $OUT/skt/*/*.db | head -1)
+python tools/rocprof_stats.py $SDB > $OUT/${TAG}_synth_kernel_trace.md
+rm -rf $OUT/skt
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/spmc_fetch -- $SCMD > /dev/null 2> $OUT/spmc1.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/spmc_write -- $SCMD > /dev/null 2> $OUT/spmc2.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES -d $OUT/spmc_mfma -- $SCMD > /dev/null 2> $OUT/spmc3.err
+python tools/pmc_counters.py $OUT/spmc_fetch $OUT/spmc_write $OUT/spmc_mfma --out $OUT/${TAG}_synth_counters.json --command "$SCMD" --steps-total 5 > $OUT/synth_counters_summary.txt
+rm -rf $OUT/spmc_fetch $OUT/spmc_write $OUT/spmc_mfma
 P1="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
 P2="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_INSTS_SALU"
 rocprofv3 --kernel-trace --pmc $P1 -d $OUT/pa1 -- python tools/bench_ops.py attn > /dev/null 2>&1

@@ -11,8 +11,7 @@
 Per kernel (template instance): launches, average duration, FETCH_SIZE bytes (raw and with the gfx950 x2 correction for wide
 coalesced reads, MI355X_MICROARCH.md "HBM"), WRITE_SIZE bytes, and MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8 XCDs)
 * 256 CUs * 4 SIMDs) (the gfx94x `MfmaUtil` formula; the counter counts cycles in which a SIMD's matrix pipe is busy).
-`families` groups the kernels the way bench.py's roofline does (conv_gemm = conv_gemm_kernel + conv_wreg_kernel + the fused
-FF kernels; conv_wgrad = the weight-gradient kernels) and averages per launch, weighted by launches."""
+`families` groups the kernels the way bench.py's roofline does (conv_gemm = conv_gemm_kernel + conv_wreg_kernel; conv_wgrad = the weight-gradient kernels) and averages per launch, weighted by launches."""
 import argparse
 import glob
 import json
@@ -23,7 +22,7 @@ from collections import defaultdict
 
 N_SIMD = 256 * 4
 N_XCD = 8       # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (a 72 us kernel at 2.4 GHz reads 1.38 M), SQ_* summed over all SIMDs
-FAMILIES = {'conv_gemm': ('conv_gemm_kernel', 'conv_wreg_kernel', 'ff_fused'), 'conv_wgrad': ('conv_wgrad', 'wgrad_reduce'),
+FAMILIES = {'conv_gemm': ('conv_gemm_kernel', 'conv_wreg_kernel'), 'conv_wgrad': ('conv_wgrad', 'wgrad_reduce'),
             'attention': ('attn_',), 'layernorm': ('ln_fwd_kernel', 'ln_bwd_kernel')}
 
 
@@ -62,6 +61,7 @@ def main():
     ap.add_argument('runs', nargs='+', help='rocprofv3 output directories (or .db files), one per --pmc pass')
     ap.add_argument('--out', required=True)
     ap.add_argument('--command', default='python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-probe')
+    ap.add_argument('--steps-total', type=int, default=0, help='steps (warm-up + timed) the profiled command ran: adds whole_step = bytes per step over ALL kernels')
     args = ap.parse_args()
     kernels = defaultdict(dict)
     for run in args.runs:
@@ -97,11 +97,21 @@ def main():
             agg['mfma_util'] = sum(r['SQ_VALU_MFMA_BUSY_CYCLES'] * r['launches'] for r in members.values()) / \
                 (sum(r['GRBM_GUI_ACTIVE'] * r['launches'] for r in members.values()) / N_XCD * N_SIMD)
         fams[fam] = agg
-    out = {'command': args.command, 'notes': 'per-launch averages; FETCH_SIZE x2-corrected for gfx950 (MI355X_MICROARCH.md, HBM); '
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    from bench import csrc_sha16
+    whole = None
+    if args.steps_total > 0:
+        tot = lambda field: sum(r.get(field, 0.) * r['launches'] for r in kernels.values()) / args.steps_total
+        whole = {'steps': args.steps_total, 'fetch_x2_bytes': tot('fetch_x2_bytes'), 'write_bytes': tot('write_bytes'),
+                 'kernel_launches_per_step': sum(r['launches'] for r in kernels.values()) / args.steps_total}
+    out = {'command': args.command, 'csrc_sha16': csrc_sha16(), 'whole_step': whole, 'notes': 'per-launch averages; FETCH_SIZE x2-corrected for gfx950 (MI355X_MICROARCH.md, HBM); '
            'mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); valu_util likewise from SQ_ACTIVE_INST_VALU * 4', 'families': fams,
            'kernels': dict(sorted(kernels.items(), key=lambda kv: -kv[1].get('avg_us', 0.) * kv[1].get('launches', 0)))}
     with open(args.out, 'w') as f:
         json.dump(out, f, indent=1)
+    if whole:
+        print('whole step', {k: round(v) for k, v in whole.items()})
     for fam, a in fams.items():
         print(fam, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items() if k != 'kernels'})
 

@@ -16,6 +16,10 @@
 // LDS transpose read ds_read_b64_tr_b16 (bf16) -- two reads give a lane its 8 k-values -- or eight
 // ds_read_b32 in the exact-fp32 mode.
 // Dropout on P: counter-based hash of (seed, (b, h, query, key)), regenerated in the backward kernels.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "dx_common.h"
 
 namespace {
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : 2) void attn_bwd_dkv_kernel(Att
   const float* lse = a.lse + ((long)b * a.H + h) * N;
   const float* delta = a.delta + ((long)b * a.H + h) * N;
   const bool key_valid = key < len;
-  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;   // dV: applied once at the end
+  const float inv_keep = dx_drop_inv_keep8(dx_drop_th8(a.p_drop));   // dV: applied once at the end (the forward's quantised keep rate)
 
   f32x16 dvT[MT], dkT[MT];
 #pragma unroll
@@ -659,6 +663,279 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : 2) void attn_bwd_dkv_kernel(Att
   }
 }
 
+
+// =============================================================================== backward, fused (bf16, d_head = 16)
+// ONE recomputation of S and dP for dQ, dK and dV (the two kernels above recompute them once each, and the d_head = 16 kernels
+// are bound by that VALU work, not by their MFMAs).  A workgroup owns one (utterance, head) completely:
+//   * its 8 waves split the KEYS: wave w keeps the K / V fragments of its <= 4 key blocks (32 keys each) in registers for the
+//     whole kernel together with their dK^T / dV^T accumulators (16x16x32 MFMAs: 16 d x 16 keys per accumulator, no padding);
+//   * the QUERIES stream through LDS in stages of 256 rows (Q and dO, next stage prefetched in registers); per 32-query block
+//     every wave computes S^T = K Q^T and dP^T = V dO^T for its key blocks (lane = query, keys in registers: log-sum-exp and
+//     delta are per-lane scalars, the cheap form of the dropout hash applies), P, the dropout mask and dS once;
+//   * dQ^T += K^T dS^T takes dS^T straight from the registers (B operand) and K^T from the utterance's K rows in LDS;
+//   * dV^T += dO^T P_drop and dK^T += Q^T dS contract over the QUERIES, which sit in the lanes: P_drop and dS pass through a
+//     wave-private 32 x 32 bf16 LDS tile and come back key-major with ds_read_b64_tr_b16 (8 b64 writes + 8 transposed reads
+//     per tile instead of a second softmax recomputation);
+//   * the 8 partial dQ^T of a query block (one per wave) meet in LDS and are summed in wave order: deterministic, no atomics.
+// N <= 1024 (8 waves x 4 key blocks); longer batches take the two-kernel path.
+constexpr int FB_W = 8, FB_T = FB_W * 64, FB_KB = 4, FB_QT = 256, FB_MAXN = FB_W * FB_KB * 32;
+constexpr int FB_LDK = 24, FB_LDT = 40;
+
+__device__ __forceinline__ f32x4 dx_mma16(f32x4 acc, const bf16x8& a, const bf16x8& b) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+// operand of a 16x16x32 MFMA read k-major from a row-major bf16 tile: lane (i = lane & 15, G = lane >> 4) gets column col0 + i,
+// rows row0 + 8 G .. + 7 (two 4 x 16 transposed reads per 16-lane group)
+__device__ __forceinline__ bf16x8 tr8(const bf16_t* tile, int ld, int row0, int col0, int lane) {
+  const int i = lane & 15, G = lane >> 4;
+  const bf16_t* p = tile + (row0 + 8 * G + (i >> 2)) * ld + col0 + 4 * (i & 3);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * ld));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+// a[i], b[i] = byte i of w >= th8 ? a[i], b[i] : 0 (one compare per decision, two selects; see dx_drop4)
+__device__ __forceinline__ void dx_drop4x2(float* a, float* b, uint32_t w, uint32_t th8) {
+  uint64_t m0, m1, m2, m3;
+  asm("v_cmp_ge_u32_sdwa %8, %12, %13 src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %9, %12, %13 src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %10, %12, %13 src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %11, %12, %13 src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+      "v_cndmask_b32_e64 %0, 0, %0, %8\n\t"
+      "v_cndmask_b32_e64 %1, 0, %1, %9\n\t"
+      "v_cndmask_b32_e64 %2, 0, %2, %10\n\t"
+      "v_cndmask_b32_e64 %3, 0, %3, %11\n\t"
+      "v_cndmask_b32_e64 %4, 0, %4, %8\n\t"
+      "v_cndmask_b32_e64 %5, 0, %5, %9\n\t"
+      "v_cndmask_b32_e64 %6, 0, %6, %10\n\t"
+      "v_cndmask_b32_e64 %7, 0, %7, %11"
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+        "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+      : "v"(w), "v"(th8));
+}
+
+__global__ __launch_bounds__(FB_T, 1) void attn_bwd_fused16_kernel(AttnArgs a) {
+  constexpr int DH = 16;
+  typedef bf16_t TC;
+  typedef bf16x8 frag_t;
+  __shared__ __attribute__((aligned(16))) TC Kall[FB_MAXN * FB_LDK];     // the utterance's K rows (this head): K^T operand of dQ^T
+  __shared__ __attribute__((aligned(16))) TC Qs[FB_QT * FB_LDK];
+  __shared__ __attribute__((aligned(16))) TC dOs[FB_QT * FB_LDK];
+  __shared__ float lse_all[FB_MAXN], delta_all[FB_MAXN];
+  __shared__ __attribute__((aligned(16))) TC Tp[FB_W][32 * FB_LDT];      // wave-private transposition tiles [query][key]
+  __shared__ __attribute__((aligned(16))) TC Td[FB_W][32 * FB_LDT];
+  __shared__ float red[2][FB_W][8][64];                                   // partial dQ^T of a query block, one slot per wave
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5, i16 = lane & 15, G = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, N = a.N, E = a.E;
+  const int bi = blockIdx.x / H, h = blockIdx.x - bi * H;
+  const int b = a.order ? a.order[bi] : bi;
+  int len = (int)a.lengths[b];
+  len = len < 0 ? 0 : (len > N ? N : len);
+  const long ld_g = 3L * E;
+  const TC* base = reinterpret_cast<const TC*>(a.qkv) + (long)b * N * ld_g + h * DH;
+  const TC* dO = reinterpret_cast<const TC*>(a.d_o) + (long)b * N * E + h * DH;
+  const TC* Og = reinterpret_cast<const TC*>(a.o) + (long)b * N * E + h * DH;
+  TC* dQ = reinterpret_cast<TC*>(a.dqkv) + (long)b * N * ld_g + h * DH;
+  const float* lse = a.lse + ((long)b * H + h) * N;
+  const int nkb = (len + 31) >> 5, rows_live = nkb * 32;
+  {   // rows past the last live block: dQ | dK | dV are zero (this head's 16 columns of each)
+    const frag_t z = zero8<TC>();
+    const int nz = (N - rows_live) * 6;
+    for (int c = tid; c < nz; c += FB_T) {
+      const int row = rows_live + c / 6, part = c % 6;
+      *reinterpret_cast<frag_t*>(dQ + (long)row * ld_g + (part >> 1) * E + (part & 1) * 8) = z;
+    }
+  }
+  if (len == 0) return;
+  for (int c = tid; c < rows_live * 2; c += FB_T) {
+    const int r = c >> 1, hf = (c & 1) * 8;
+    frag_t v = zero8<TC>();
+    if (r < len) v = *reinterpret_cast<const frag_t*>(base + E + (long)r * ld_g + hf);
+    *reinterpret_cast<frag_t*>(&Kall[r * FB_LDK + hf]) = v;
+  }
+  for (int q = tid; q < rows_live; q += FB_T) {   // delta_q = sum_d dO[q][d] O[q][d]; log-sum-exp in the log2 domain
+    float dl = 0.f, ls = 0.f;
+    if (q < len) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const frag_t x = *reinterpret_cast<const frag_t*>(dO + (long)q * E + hf * 8);
+        const frag_t y = *reinterpret_cast<const frag_t*>(Og + (long)q * E + hf * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)x[e] * (float)y[e];
+      }
+      ls = lse[q] * LOG2E;
+    }
+    delta_all[q] = dl;
+    lse_all[q] = ls;
+  }
+  // key blocks of this wave: [kb0, kb0 + cnt), spread evenly over the waves that get any
+  const int nwa = nkb < FB_W ? nkb : FB_W;
+  int kb0 = 0, cnt = 0;
+  if (w < nwa) { kb0 = (w * nkb) / nwa; cnt = ((w + 1) * nkb) / nwa - kb0; }
+  frag_t kf[FB_KB], vf[FB_KB];
+  f32x4 dk[FB_KB][2], dv[FB_KB][2];
+#pragma unroll
+  for (int j = 0; j < FB_KB; ++j) {
+    const int key = (kb0 + j) * 32 + l31;
+    const bool ok = j < cnt && key < len;
+    kf[j] = ok ? *reinterpret_cast<const frag_t*>(base + E + (long)key * ld_g + g * 8) : zero8<TC>();
+    vf[j] = ok ? *reinterpret_cast<const frag_t*>(base + 2 * E + (long)key * ld_g + g * 8) : zero8<TC>();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { dk[j][t][r] = 0.f; dv[j][t][r] = 0.f; }
+  }
+  const float c2 = a.scale * LOG2E;
+  const uint32_t th8 = dx_drop_th8(a.p_drop);
+  const float inv_keep = dx_drop_inv_keep8(th8);
+  const uint32_t NB = (uint32_t)(N + 3) >> 2;
+  const uint32_t skey = dx_key32(a.seed, (uint32_t)(b * H + h));
+
+  const int srow = tid >> 1, shf = (tid & 1) * 8;   // this thread's 16-byte piece of a 256-row stage
+  frag_t qreg, doreg;
+  auto fetch = [&](int qs0) {                         // branch-free: rows past the tensor re-read its last row (masked later)
+    const int r = min(qs0 + srow, N - 1);
+    qreg = *reinterpret_cast<const frag_t*>(base + (long)r * ld_g + shf);
+    doreg = *reinterpret_cast<const frag_t*>(dO + (long)r * E + shf);
+  };
+  fetch(0);
+  int buf = 0;
+  for (int qs0 = 0; qs0 < len; qs0 += FB_QT) {
+    *reinterpret_cast<frag_t*>(&Qs[srow * FB_LDK + shf]) = qreg;
+    *reinterpret_cast<frag_t*>(&dOs[srow * FB_LDK + shf]) = doreg;
+    __syncthreads();
+    if (qs0 + FB_QT < len) fetch(qs0 + FB_QT);
+    const int left = (len - qs0 + 31) >> 5, nsub = left < FB_QT / 32 ? left : FB_QT / 32;
+    for (int sub = 0; sub < nsub; ++sub) {
+      const int qb = qs0 + sub * 32, q = qb + l31;
+      f32x16 dqT;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dqT[r] = 0.f;
+      if (cnt > 0) {
+        const bool q_valid = q < len;
+        const frag_t qf = *reinterpret_cast<const frag_t*>(&Qs[(sub * 32 + l31) * FB_LDK + g * 8]);
+        const frag_t dof = *reinterpret_cast<const frag_t*>(&dOs[(sub * 32 + l31) * FB_LDK + g * 8]);
+        const float lse2 = lse_all[q], delta_q = delta_all[q];
+        const frag_t doA = tr8(dOs, FB_LDK, sub * 32, 0, lane);   // dO^T / Q^T: 16 d x 32 queries of this block
+        const frag_t qA = tr8(Qs, FB_LDK, sub * 32, 0, lane);
+        const uint32_t ctr_lane = dx_opaque(((uint32_t)(q >> 2) * NB + g) * DX_CTR_MUL + skey);
+        const uint32_t rot_lane = 8u * (q & 3), mult_lane = dx_blk_mult(q & 3);
+        const f32x2 c22 = {c2, c2}, nl2 = {-lse2, -lse2}, ik2 = {inv_keep, inv_keep}, nd2 = {-delta_q, -delta_q};
+#pragma unroll
+        for (int j = 0; j < FB_KB; ++j) {
+          if (j < cnt) {
+            const int k0 = (kb0 + j) * 32;
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            dx_mma(s, kf[j], qf);      // S^T[key][q]: lane = query, registers = keys
+            dx_mma(dp, vf[j], dof);    // dP^T[key][q]
+            if (!(qb + 32 <= len && k0 + 32 <= len)) {   // wave-uniform, boundary tiles only: pad keys / pad queries -> P = 2^-inf = 0
+              asm volatile("; boundary tile" ::: "memory");   // keeps this a branch (if-converted, the 32 compare / select pairs ran on every tile)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) s[r] = (q_valid && k0 + dx_acc_row(r, g) < len) ? s[r] : -INFINITY;
+            }
+            const uint32_t ctr_tile = (uint32_t)(k0 >> 2) * DX_CTR_MUL;
+            uint32_t hw[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) hw[jj] = ctr_lane + (ctr_tile + (uint32_t)(2 * jj) * DX_CTR_MUL);
+            dx_drop_prefix4(hw);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) hw[jj] = __builtin_amdgcn_alignbit(hw[jj], hw[jj], rot_lane);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) hw[jj] = __umul24(hw[jj], mult_lane);
+            float pd[16], ds[16];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {   // registers 4jj .. 4jj + 3 = keys k0 + 8jj + 4g + {0..3}: one row word
+              float x[4] = {dp[4 * jj], dp[4 * jj + 1], dp[4 * jj + 2], dp[4 * jj + 3]};
+              float pr[4], pm[4];
+#pragma unroll
+              for (int i = 0; i < 4; i += 2) {
+                const int r = 4 * jj + i;
+                const f32x2 t = pk_fma(f32x2{s[r], s[r + 1]}, c22, nl2);
+                pr[i] = fast_exp2<TC>(t[0]);
+                pr[i + 1] = fast_exp2<TC>(t[1]);
+                pm[i] = pr[i]; pm[i + 1] = pr[i + 1];
+              }
+              dx_drop4x2(pm, x, hw[jj], th8);
+#pragma unroll
+              for (int i = 0; i < 4; i += 2) {
+                const int r = 4 * jj + i;
+                const f32x2 d2 = f32x2{pr[i], pr[i + 1]} * pk_fma(f32x2{x[i], x[i + 1]}, ik2, nd2);
+                ds[r] = d2[0]; ds[r + 1] = d2[1];
+                pd[r] = pm[i]; pd[r + 1] = pm[i + 1];
+              }
+            }
+            const frag_t pdf[2] = {pack8<TC>(pd), pack8<TC>(pd + 8)};
+            const frag_t dsf[2] = {pack8<TC>(ds), pack8<TC>(ds + 8)};
+            // [query][key] tiles for the contractions over the queries: fragment element e of k-step ks = key 16 ks + 8 (e >> 2) + 4 g + (e & 3)
+            TC* tp = &Tp[w][l31 * FB_LDT + 4 * g];
+            TC* td = &Td[w][l31 * FB_LDT + 4 * g];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              *reinterpret_cast<bf16x4*>(tp + 16 * ks) = __builtin_shufflevector(pdf[ks], pdf[ks], 0, 1, 2, 3);
+              *reinterpret_cast<bf16x4*>(tp + 16 * ks + 8) = __builtin_shufflevector(pdf[ks], pdf[ks], 4, 5, 6, 7);
+              *reinterpret_cast<bf16x4*>(td + 16 * ks) = __builtin_shufflevector(dsf[ks], dsf[ks], 0, 1, 2, 3);
+              *reinterpret_cast<bf16x4*>(td + 16 * ks + 8) = __builtin_shufflevector(dsf[ks], dsf[ks], 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {   // dQ^T += K^T dS^T
+              const frag_t kT = gather8<TC, 16>(Kall + k0 * FB_LDK, FB_LDK, ks * 16 + 4 * g, ks * 16 + 4 * g + 8, 0, lane);
+              dx_mma(dqT, kT, dsf[ks]);
+            }
+            asm volatile("" ::: "memory");      // the transposed reads below follow this wave's own tile writes (LDS is in order per wave)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {      // key halves of the block: dV^T += dO^T P_drop, dK^T += Q^T dS
+              const frag_t pB = tr8(Tp[w], FB_LDT, 0, 16 * t, lane);
+              const frag_t dB = tr8(Td[w], FB_LDT, 0, 16 * t, lane);
+              dv[j][t] = dx_mma16(dv[j][t], doA, pB);
+              dk[j][t] = dx_mma16(dk[j][t], qA, dB);
+            }
+            asm volatile("" ::: "memory");
+          }
+        }
+      }
+      if (w < nwa) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) red[buf][w][r][lane] = dqT[r];   // rows d < 16 of the 32 x 32 accumulator
+      }
+      __syncthreads();
+      if (tid < 128) {   // thread = (query, 4 consecutive d): sums the waves' partials in wave order, one 8-byte store
+        const int qq = tid & 31, dg = tid >> 5, rhi = dg >> 1, gg = dg & 1;
+        float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ww = 0; ww < nwa; ++ww)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc4[e] += red[buf][ww][rhi * 4 + e][gg * 32 + qq];
+        if (qb + qq < N) {
+          bf16x4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o4[e] = (TC)(acc4[e] * a.scale);
+          *reinterpret_cast<bf16x4*>(dQ + (long)(qb + qq) * ld_g + 4 * dg) = o4;
+        }
+      }
+      buf ^= 1;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < FB_KB; ++j) {
+    if (j < cnt) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {   // accumulator (16 d x 16 keys): lane = key, registers = d 4 G .. 4 G + 3
+        const int key = (kb0 + j) * 32 + 16 * t + i16;
+        if (key < N) {
+          bf16x4 k4, v4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { k4[r] = (TC)(dk[j][t][r] * a.scale); v4[r] = (TC)(dv[j][t][r] * inv_keep); }
+          *reinterpret_cast<bf16x4*>(dQ + E + (long)key * ld_g + 4 * G) = k4;
+          *reinterpret_cast<bf16x4*>(dQ + 2 * E + (long)key * ld_g + 4 * G) = v4;
+        }
+      }
+    }
+  }
+}
+
 template <typename TC>
 int launch_fwd(const AttnArgs& a, int B, int dh, hipStream_t s) {
   dim3 grid(dx_cdiv(a.N, dh == 64 ? 128 / Split<64>::value : 128), a.H, B), block(256);
@@ -668,8 +945,23 @@ int launch_fwd(const AttnArgs& a, int B, int dh, hipStream_t s) {
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
+// DX_ATTN_FUSED_BWD (default 1): the fused backward kernel for bf16 / d_head = 16 / N <= 1024
+static int fused_bwd_enabled() {
+  static const int on = [] { const char* e = getenv("DX_ATTN_FUSED_BWD"); return e ? atoi(e) : 1; }();
+  return on;
+}
 template <typename TC>
-int launch_bwd(const AttnArgs& a, int B, int dh, float* delta, hipStream_t s) {
+int launch_bwd(const AttnArgs& a, int B, int dh, float* delta, int algo, hipStream_t s) {
+  const bool can_fuse = std::is_same<TC, bf16_t>::value && dh == 16 && a.N <= FB_MAXN;
+  if (algo == DX_ATTN_FUSED && !can_fuse) {
+    dx_set_error("dx_attention_bwd: the fused kernel needs bf16, d_head 16, N <= %d (got d_head %d, N %d)", FB_MAXN, dh, a.N);
+    return DX_ERR_UNSUPPORTED;
+  }
+  if (can_fuse && (algo == DX_ATTN_FUSED || (algo == DX_ATTN_AUTO && fused_bwd_enabled()))) {
+    hipLaunchKernelGGL(attn_bwd_fused16_kernel, dim3(B * a.H), dim3(FB_T), 0, s, a);
+    DX_LAUNCH_CHECK();
+    return DX_OK;
+  }
   dim3 grid(dx_cdiv(a.N, dh == 64 ? 128 / Split<64>::value : 128), a.H, B), block(256);
   if (dh == 16) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, 16>), grid, block, 0, s, a);
@@ -719,14 +1011,15 @@ extern "C" int dx_attention_fwd(const void* qkv, int dtype, const int64_t* lengt
 
 extern "C" int dx_attention_bwd(const void* qkv, const void* o, const void* d_o, int dtype, const float* lse,
                                 const int64_t* lengths, const int* order, void* dqkv, float* delta_ws, int B, int N, int H, int E,
-                                float p_drop, uint64_t seed, void* stream) {
+                                float p_drop, uint64_t seed, int algo, void* stream) {
   DX_REQUIRE(qkv && o && d_o && lse && lengths && dqkv && delta_ws, DX_ERR_ARG, "dx_attention_bwd: null pointer");
   DX_REQUIRE(B > 0 && N > 0 && H > 0 && E % H == 0, DX_ERR_SHAPE, "dx_attention_bwd: bad shape");
+  DX_REQUIRE(algo >= DX_ATTN_AUTO && algo <= DX_ATTN_FUSED, DX_ERR_ARG, "dx_attention_bwd: algo %d", algo);
   const int dh = E / H;
   AttnArgs a{qkv, const_cast<void*>(o), const_cast<float*>(lse), d_o, delta_ws, dqkv, lengths, N, H, E,
              1.f / sqrtf((float)dh), p_drop, seed, order};
-  if (dtype == DX_BF16) return launch_bwd<bf16_t>(a, B, dh, delta_ws, (hipStream_t)stream);
-  if (dtype == DX_F32) return launch_bwd<float>(a, B, dh, delta_ws, (hipStream_t)stream);
+  if (dtype == DX_BF16) return launch_bwd<bf16_t>(a, B, dh, delta_ws, algo, (hipStream_t)stream);
+  if (dtype == DX_F32) return launch_bwd<float>(a, B, dh, delta_ws, algo, (hipStream_t)stream);
   dx_set_error("dx_attention_bwd: bad dtype %d", dtype);
   return DX_ERR_DTYPE;
 }

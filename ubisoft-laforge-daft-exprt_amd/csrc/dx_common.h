@@ -196,7 +196,12 @@ __host__ __device__ __forceinline__ uint32_t dx_key32(uint64_t seed, uint32_t sa
 // per degree of freedom.  Without the rotation the low bytes of the four row words share the low bits of `base` (|corr| 0.07).
 constexpr uint32_t DX_CTR_MUL = 0x9E3779B1u, DX_M24_PRE = 0x9E3779u;
 constexpr uint32_t DX_BLK_M0 = 0xC2B2AFu, DX_BLK_M1 = 0x85EBCBu, DX_BLK_M2 = 0xA54FF5u, DX_BLK_M3 = 0x6C8E95u;
-__host__ __device__ __forceinline__ uint32_t dx_drop_th8(float p) { return p <= 0.f ? 0u : (uint32_t)(p * 256.f + 0.5f); }
+// p > 0 always drops something and never everything: the threshold is clamped to [1, 255] (p < 1/512 -> 1/256, p > 255/256 -> 255/256)
+__host__ __device__ __forceinline__ uint32_t dx_drop_th8(float p) {
+  if (p <= 0.f) return 0u;
+  const uint32_t t = (uint32_t)(p * 256.f + 0.5f);
+  return t < 1u ? 1u : (t > 255u ? 255u : t);
+}
 __host__ __device__ __forceinline__ float dx_drop_inv_keep8(uint32_t th8) { return 256.f / (float)(256u - th8); }
 __device__ __forceinline__ uint32_t dx_drop_prefix(uint32_t ctr) {
   ctr ^= ctr >> 16;                    // both xor-shifts are by 16: one v_xor_b32_sdwa (src1_sel:WORD_1) each

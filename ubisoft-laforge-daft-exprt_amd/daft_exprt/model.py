@@ -182,10 +182,12 @@ class DaftExprt(nn.Module):
         assert [n for n, _ in self.named_parameters()] == [n for n, _, _ in self._table]
         self._flat = self._gflat = None
         self._packed, self._packed_version, self._param_version = {}, -1, 0
-        # True: re-pack the bf16 weight copies on every call.  Not needed for anything that goes through torch: `_weights` watches
-        # the version counters of the GEMM weights, so load_state_dict, torch.optim steps and in-place ops under no_grad are all
-        # seen; only writes through `.data` (or a foreign kernel) are invisible -- those callers use `mark_updated()`
-        self.always_repack = False
+        # True (default, always safe): re-pack the bf16 weight copies on every call (one batched kernel, ~40 us).  False: re-pack only
+        # when the parameters changed through torch -- `_weights` watches the version counters of the GEMM weights, so
+        # load_state_dict, torch.optim steps and in-place ops under no_grad are all seen; writes through `.data`, `model._P[...]`
+        # or the flat buffer are NOT (EMA swaps, weight clipping): those callers use `mark_updated()`.  `Trainer`, which owns every
+        # parameter update, switches it off.
+        self.always_repack = True
         self._anchor = None
         self._side = self._side_stream = None
         self._wgrad_keep = []
@@ -199,7 +201,6 @@ class DaftExprt(nn.Module):
         self.balanced_tiles = bool(int(__import__('os').environ.get('DX_BALANCED_TILES', '1')))   # see _plan
         self._plans = {}
         self.attn_lpt = bool(int(__import__('os').environ.get('DX_ATTN_LPT', '1')))   # see _order
-        self.ff_fused = bool(int(__import__('os').environ.get('DX_FF_FUSED', '0')))   # K2: both FF convs + LayerNorm in one launch (bf16); opt-in, see DESIGN
         self._plan_min_rows = int(__import__('os').environ.get('DX_PLAN_MIN_ROWS', '0'))
         self._plan_k1 = bool(int(__import__('os').environ.get('DX_PLAN_K1', '0')))   # balanced tiles also for the k = 1 QKV data gradient + LayerNorm backward (measured: 8.78 vs 8.74 ms)
         self._step_id, self._site, self._rank = 0, 0, 0
@@ -292,7 +293,11 @@ class DaftExprt(nn.Module):
                     bwd.append((w, self._packed['T:' + name], True))
             self._pack_fwd, self._pack_bwd = ops.pack_table(fwd, dev), ops.pack_table(bwd, dev)
             self._packed_version = self._dgrad_version = -1
-        version = (self._param_version, tuple(self._params[n]._version for n in self._gemm_weights))
+        try:
+            version = (self._param_version, tuple(self._params[n]._version for n in self._gemm_weights))
+        except RuntimeError:      # inference tensors (model built or moved under torch.inference_mode()) carry no version counter
+            version = (self._param_version, None)
+            self._packed_version = -1 if self._packed_version == version else self._packed_version   # always re-pack
         if self._packed_version != version or self.always_repack:
             ops.pack_weights_batched(*self._pack_fwd, self.cd)
             self._packed_version = version
@@ -322,14 +327,6 @@ class DaftExprt(nn.Module):
         hit = self._plans.get(key)
         if hit is None or hit[0] is not lengths:
             hit = self._plans[key] = (lengths, ops.length_order(lengths))
-        return hit[1]
-
-    def _ff_plan(self, lengths, N):
-        ''' tile table of the fused feed-forward kernel (`ops.ff_plan`), one per distinct lengths tensor per step '''
-        key = ('ff', lengths.data_ptr(), N)
-        hit = self._plans.get(key)
-        if hit is None or hit[0] is not lengths:
-            hit = self._plans[key] = (lengths, ops.ff_plan(lengths, N))
         return hit[1]
 
     def set_rank(self, rank):
@@ -412,20 +409,12 @@ class DaftExprt(nn.Module):
                                                   P[f'{a_pre}.layer_norm.bias'], lengths, save=save, p_pre=p_attn, seed_pre=seeds[1],
                                                   lp_copy=lp)
         ain = a_lp if lp else a
-        if lp and self.ff_fused and lengths is not None and cfg['conv_channels'] % 64 == 0 and cfg['conv_kernel'] == 3:
-            # K2: conv1 -> ReLU -> conv2 -> Dropout -> residual -> LayerNorm -> FiLM -> mask in ONE launch; the hidden
-            # tensor is written once for the backward pass and never read back in the forward pass
-            u, u_lp, s2, mean2, rstd2, h = ops.ff_fused_fwd(
-                ain, W[f'{f_pre}.convs.0.conv.weight'], P[f'{f_pre}.convs.0.conv.bias'], W[f'{f_pre}.convs.2.conv.weight'],
-                P[f'{f_pre}.convs.2.conv.bias'], a, P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'], lengths,
-                self._ff_plan(lengths, x.shape[1]), film=film, save=save, p_pre=p_conv, seed_pre=seeds[2], lp_copy=True)
-        else:
-            h = ops.conv1d(ain, W[f'{f_pre}.convs.0.conv.weight'], P[f'{f_pre}.convs.0.conv.bias'], out_dtype=cd, relu=True,
-                           skip_lengths=lengths)
-            # second FF conv + Dropout + residual + LayerNorm + FiLM + mask in ONE launch
-            u, u_lp, s2, mean2, rstd2 = ops.conv1d_ln(h, W[f'{f_pre}.convs.2.conv.weight'], P[f'{f_pre}.convs.2.conv.bias'], a,
-                                                      P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'], lengths, film=film,
-                                                      save=save, p_pre=p_conv, seed_pre=seeds[2], lp_copy=lp, plan=self._plan(lengths, x.shape[1]))
+        h = ops.conv1d(ain, W[f'{f_pre}.convs.0.conv.weight'], P[f'{f_pre}.convs.0.conv.bias'], out_dtype=cd, relu=True,
+                       skip_lengths=lengths)
+        # second FF conv + Dropout + residual + LayerNorm + FiLM + mask in ONE launch
+        u, u_lp, s2, mean2, rstd2 = ops.conv1d_ln(h, W[f'{f_pre}.convs.2.conv.weight'], P[f'{f_pre}.convs.2.conv.bias'], a,
+                                                  P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'], lengths, film=film,
+                                                  save=save, p_pre=p_conv, seed_pre=seeds[2], lp_copy=lp, plan=self._plan(lengths, x.shape[1]))
         if save:
             s.pre, s.cfg, s.x, s.film, s.lengths = pre, cfg, xin, film, lengths
             s.qkv, s.o, s.lse, s.s1, s.mean1, s.rstd1, s.a, s.h, s.s2, s.mean2, s.rstd2 = qkv, o, lse, s1, mean1, rstd1, ain, h, s2, mean2, rstd2
@@ -457,7 +446,7 @@ class DaftExprt(nn.Module):
         P, hp, cfg, pre = self._P, self.hp, self.hp.prosody_encoder, 'prosody_encoder'
         p_conv = cfg['conv_dropout'] if train else 0.
         s = _Saved()
-        x = ops.transpose_last2(mel_specs)   # (B, T, n_mel) channel-last rows of the input batch
+        x = ops.transpose_last2(mel_specs.float().contiguous())   # (B, T, n_mel) channel-last rows (no-op casts on the step path: parse_batch normalises)
         wide = self.cd
         l1, s.c1 = self._conv_ln_fwd(W, f'{pre}.convs.0', f'{pre}.convs.2', x, p_conv, wide, save, skip=output_lengths)
         l2, s.c2 = self._conv_ln_fwd(W, f'{pre}.convs.4', f'{pre}.convs.6', l1, p_conv, wide, save, skip=output_lengths)
@@ -765,7 +754,7 @@ class DaftExprt(nn.Module):
         # ---- local prosody predictor
         saved_pp, pp_x, pp_y = S.pp
         if d_dur is not None:
-            dy = ops.stack([d_dur.contiguous(), d_energy.contiguous(), d_pitch.contiguous()])
+            dy = ops.stack([d_dur.float().contiguous(), d_energy.float().contiguous(), d_pitch.float().contiguous()])
             ppn = 'prosody_predictor'
             dx = ops.linear_small_bwd(dy, None, pp_x, P[f'{ppn}.projection.linear_layer.weight'],
                                       G[f'{ppn}.projection.linear_layer.weight'], G[f'{ppn}.projection.linear_layer.bias'],

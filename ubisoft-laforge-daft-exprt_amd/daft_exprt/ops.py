@@ -144,41 +144,6 @@ def conv_tile_plan(lengths, N):
     return table, B, N
 
 
-def ff_plan(lengths, N):
-    ''' tile table of the fused feed-forward kernel (dx_ff_plan): (int32 table (n_tiles, 4) on the device, B, N) '''
-    B = lengths.shape[0]
-    n = H.lib().dx_ff_plan_size(B, N)
-    table = torch.empty((n, 4), dtype=torch.int32, device=lengths.device)
-    H.check(H.lib().dx_ff_plan(H.ptr(lengths), B, N, n, H.ptr(table), H.stream()))
-    return table, B, N
-
-
-def ff_fused_fwd(x_lp, w1_packed, b1, w2_packed, b2, residual, gamma, beta, lengths, plan, film=None, save=False, p_pre=0.,
-                 seed_pre=0, lp_copy=True):
-    ''' conv k3 -> ReLU -> conv k3 -> Dropout -> + residual -> LayerNorm [-> FiLM] -> mask in one launch (dx_ff_fused_fwd).
-        Returns (y, y_lp, s_out, mean, rstd, h) -- h (B, N, C) bf16 is the hidden tensor the backward pass needs. '''
-    B, N, D = x_lp.shape
-    C = w1_packed.shape[1]
-    assert x_lp.dtype == torch.bfloat16 and w1_packed.dtype == torch.bfloat16 and w2_packed.dtype == torch.bfloat16
-    assert D == 128 and x_lp.is_contiguous() and residual.is_contiguous() and residual.dtype == torch.float32
-    assert tuple(w1_packed.shape) == (3, C, 128) and tuple(w2_packed.shape) == (3, 128, C)
-    table, pb, pn = plan
-    assert (pb, pn) == (B, N), 'tile plan built for another batch geometry'
-    dev = x_lp.device
-    h = torch.empty((B, N, C), dtype=torch.bfloat16, device=dev)
-    y = torch.empty((B, N, 128), dtype=torch.float32, device=dev)
-    y_lp = torch.empty((B, N, 128), dtype=torch.bfloat16, device=dev) if lp_copy else None
-    s_out = torch.empty((B, N, 128), dtype=torch.float32, device=dev) if save else None
-    mean = torch.empty(B * N, dtype=torch.float32, device=dev) if save else None
-    rstd = torch.empty(B * N, dtype=torch.float32, device=dev) if save else None
-    with _probe('conv_gemm', lambda: 2. * B * N * 128 * C * 3 * 2, N):
-        H.check(H.lib().dx_ff_fused_fwd(H.ptr(x_lp), H.ptr(w1_packed), H.ptr(b1), H.ptr(w2_packed), H.ptr(b2), H.ptr(residual),
-                                        H.ptr(gamma), H.ptr(beta), H.ptr(film), film.stride(0) if film is not None else 0,
-                                        H.ptr(lengths), H.ptr(h), H.ptr(y), H.ptr(y_lp), H.ptr(s_out), H.ptr(mean), H.ptr(rstd),
-                                        B, N, C, float(p_pre), int(seed_pre), H.ptr(table), table.shape[0], H.stream()))
-    return y, y_lp, s_out, mean, rstd, h
-
-
 def _plan_args(plan, x, w_packed, B, N, k1_ok=False):
     ''' (table pointer, n_tiles) when the plan applies to this GEMM (bf16 operands, k = 3, same batch geometry) '''
     taps = w_packed.shape[0]
@@ -299,14 +264,17 @@ def attention_fwd(qkv, lengths, nb_heads, p_drop=0., seed=0, need_lse=True, orde
     return o, lse
 
 
-def attention_bwd(qkv, o, d_o, lse, lengths, nb_heads, p_drop=0., seed=0, order=None):
+ATTN_AUTO, ATTN_TWO_PASS, ATTN_FUSED = 0, 1, 2
+
+
+def attention_bwd(qkv, o, d_o, lse, lengths, nb_heads, p_drop=0., seed=0, order=None, algo=ATTN_AUTO):
     B, N, E3 = qkv.shape
     E = E3 // 3
     assert d_o.is_contiguous() and d_o.dtype == qkv.dtype
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, nb_heads, N), dtype=torch.float32, device=qkv.device)
     H.check(H.lib().dx_attention_bwd(H.ptr(qkv), H.ptr(o), H.ptr(d_o), H.dt(qkv), H.ptr(lse), H.ptr(lengths), H.ptr(order), H.ptr(dqkv),
-                                     H.ptr(delta), B, N, nb_heads, E, float(p_drop), int(seed), H.stream()))
+                                     H.ptr(delta), B, N, nb_heads, E, float(p_drop), int(seed), int(algo), H.stream()))
     return dqkv
 
 
