@@ -165,7 +165,12 @@ int dx_attention_fwd(const void* qkv, int dtype, const int64_t* lengths, const i
 /* Backward of dx_attention_fwd (autograd of model.py:182-186): dqkv (B, N, 3E) <- d_o (B, N, E).  delta_ws: (B, H, N) fp32 workspace.
  * algo: DX_ATTN_AUTO picks the fused kernel where it exists (bf16, d_head 16, N <= 1024: one workgroup per (utterance, head)
  * recomputes S / dP once for dQ, dK and dV) and the two-pass pair (dQ kernel, dK/dV kernel) elsewhere; DX_ATTN_TWO_PASS forces the
- * pair; DX_ATTN_FUSED returns DX_ERR_UNSUPPORTED where the fused kernel does not apply.  Both draw the forward's dropout mask. */
+ * pair; DX_ATTN_FUSED returns DX_ERR_UNSUPPORTED where the fused kernel does not apply.  Both draw the forward's dropout mask.
+ * delta_ws: dx_attention_bwd_ws_floats(B, N, H) floats.  The LAST B * H of them are arrival counters of the fused kernel (an
+ * utterance of more than 512 keys is shared by two workgroups): they must be zero before the first call and are left in a valid
+ * state by every call, so the caller zeroes the workspace once and keeps it (one workspace per stream: calls that run
+ * concurrently must not share it). */
+long dx_attention_bwd_ws_floats(int B, int N, int H);
 enum { DX_ATTN_AUTO = 0, DX_ATTN_TWO_PASS = 1, DX_ATTN_FUSED = 2 };
 int dx_attention_bwd(const void* qkv, const void* o, const void* d_o, int dtype, const float* lse,
                      const int64_t* lengths, const int* order, void* dqkv, float* delta_ws, int B, int N, int H, int E,

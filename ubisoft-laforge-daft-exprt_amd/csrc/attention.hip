@@ -666,19 +666,24 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : 2) void attn_bwd_dkv_kernel(Att
 
 // =============================================================================== backward, fused (bf16, d_head = 16)
 // ONE recomputation of S and dP for dQ, dK and dV (the two kernels above recompute them once each, and the d_head = 16 kernels
-// are bound by that VALU work, not by their MFMAs).  A workgroup owns one (utterance, head) completely:
-//   * its 8 waves split the KEYS: wave w keeps the K / V fragments of its <= 4 key blocks (32 keys each) in registers for the
-//     whole kernel together with their dK^T / dV^T accumulators (16x16x32 MFMAs: 16 d x 16 keys per accumulator, no padding);
-//   * the QUERIES stream through LDS in stages of 256 rows (Q and dO, next stage prefetched in registers); per 32-query block
-//     every wave computes S^T = K Q^T and dP^T = V dO^T for its key blocks (lane = query, keys in registers: log-sum-exp and
-//     delta are per-lane scalars, the cheap form of the dropout hash applies), P, the dropout mask and dS once;
-//   * dQ^T += K^T dS^T takes dS^T straight from the registers (B operand) and K^T from the utterance's K rows in LDS;
+// are bound by that VALU work, not by their MFMAs).  A workgroup (4 waves, two resident per CU) owns the KEYS of one (utterance,
+// head) -- all of them up to 512, one half each of a longer utterance -- and walks ALL of its queries:
+//   * wave w keeps the K / V fragments of its <= 4 key blocks (32 keys each) in registers for the whole kernel together with
+//     their dK^T / dV^T accumulators (16x16x32 MFMAs: 16 d x 16 keys per accumulator, no padding);
+//   * the queries stream through LDS in stages of 128 rows (Q and dO, next stage prefetched in registers; delta = rowsum(dO * O)
+//     and the log-sum-exp are staged with them); per 32-query block every wave computes S^T = K Q^T and dP^T = V dO^T for its key
+//     blocks (lane = query, keys in registers: log-sum-exp and delta are per-lane scalars, the cheap form of the dropout hash
+//     applies), P, the dropout mask and dS once;
+//   * dQ^T += K^T dS^T takes dS^T straight from the registers (B operand) and K^T from the workgroup's K rows in LDS;
 //   * dV^T += dO^T P_drop and dK^T += Q^T dS contract over the QUERIES, which sit in the lanes: P_drop and dS pass through a
 //     wave-private 32 x 32 bf16 LDS tile and come back key-major with ds_read_b64_tr_b16 (8 b64 writes + 8 transposed reads
 //     per tile instead of a second softmax recomputation);
-//   * the 8 partial dQ^T of a query block (one per wave) meet in LDS and are summed in wave order: deterministic, no atomics.
-// N <= 1024 (8 waves x 4 key blocks); longer batches take the two-kernel path.
-constexpr int FB_W = 8, FB_T = FB_W * 64, FB_KB = 4, FB_QT = 256, FB_MAXN = FB_W * FB_KB * 32;
+//   * the 4 partial dQ^T of a query block (one per wave) meet in LDS and are summed in wave order: deterministic, no atomics;
+//   * an utterance of more than 512 keys has two workgroups: each leaves its fp32 dQ partial in the workspace, and the one that
+//     arrives second (an arrival counter per (utterance, head), release / acquire fences at agent scope) adds the two in key order
+//     and writes dQ -- two terms, so the sum does not depend on who arrives first.
+// N <= 1024; longer batches take the two-pass kernels.
+constexpr int FB_W = 4, FB_T = FB_W * 64, FB_KB = 4, FB_QT = 128, FB_KEYS = FB_W * FB_KB * 32, FB_MAXN = 2 * FB_KEYS;
 constexpr int FB_LDK = 24, FB_LDT = 40;
 
 __device__ __forceinline__ f32x4 dx_mma16(f32x4 acc, const bf16x8& a, const bf16x8& b) {
@@ -695,85 +700,86 @@ __device__ __forceinline__ bf16x8 tr8(const bf16_t* tile, int ld, int row0, int 
   s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, r);
 }
-// a[i], b[i] = byte i of w >= th8 ? a[i], b[i] : 0 (one compare per decision, two selects; see dx_drop4)
-__device__ __forceinline__ void dx_drop4x2(float* a, float* b, uint32_t w, uint32_t th8) {
+// pm[i] = byte i of w >= th8 ? pr[i] : 0 and x[i] likewise in place (one compare per decision, two selects; see dx_drop4)
+__device__ __forceinline__ void dx_drop4x2(float* pm, const float* pr, float* x, uint32_t w, uint32_t th8) {
   uint64_t m0, m1, m2, m3;
-  asm("v_cmp_ge_u32_sdwa %8, %12, %13 src0_sel:BYTE_0 src1_sel:DWORD\n\t"
-      "v_cmp_ge_u32_sdwa %9, %12, %13 src0_sel:BYTE_1 src1_sel:DWORD\n\t"
-      "v_cmp_ge_u32_sdwa %10, %12, %13 src0_sel:BYTE_2 src1_sel:DWORD\n\t"
-      "v_cmp_ge_u32_sdwa %11, %12, %13 src0_sel:BYTE_3 src1_sel:DWORD\n\t"
-      "v_cndmask_b32_e64 %0, 0, %0, %8\n\t"
-      "v_cndmask_b32_e64 %1, 0, %1, %9\n\t"
-      "v_cndmask_b32_e64 %2, 0, %2, %10\n\t"
-      "v_cndmask_b32_e64 %3, 0, %3, %11\n\t"
+  asm("v_cmp_ge_u32_sdwa %8, %16, %17 src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %9, %16, %17 src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %10, %16, %17 src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+      "v_cmp_ge_u32_sdwa %11, %16, %17 src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+      "v_cndmask_b32_e64 %0, 0, %12, %8\n\t"
+      "v_cndmask_b32_e64 %1, 0, %13, %9\n\t"
+      "v_cndmask_b32_e64 %2, 0, %14, %10\n\t"
+      "v_cndmask_b32_e64 %3, 0, %15, %11\n\t"
       "v_cndmask_b32_e64 %4, 0, %4, %8\n\t"
       "v_cndmask_b32_e64 %5, 0, %5, %9\n\t"
       "v_cndmask_b32_e64 %6, 0, %6, %10\n\t"
       "v_cndmask_b32_e64 %7, 0, %7, %11"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+      : "=&v"(pm[0]), "=&v"(pm[1]), "=&v"(pm[2]), "=&v"(pm[3]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]),
         "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
-      : "v"(w), "v"(th8));
+      : "v"(pr[0]), "v"(pr[1]), "v"(pr[2]), "v"(pr[3]), "v"(w), "v"(th8));
 }
 
-__global__ __launch_bounds__(FB_T, 1) void attn_bwd_fused16_kernel(AttnArgs a) {
+// workspace of the fused kernel behind the (B, H, N) floats of delta: B * H * 2 fp32 dQ partials of (N_pad x 16) + B * H arrival
+// counters (int, zero before the first call; every pair of arrivals leaves the parity it found)
+__host__ __device__ static inline long fb_ws_floats(int B, int N, int H) {
+  const long npad = (N + 31) & ~31;
+  return (long)B * H * 2 * npad * 16 + (long)B * H;
+}
+
+__global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, float* ws) {
   constexpr int DH = 16;
   typedef bf16_t TC;
   typedef bf16x8 frag_t;
-  __shared__ __attribute__((aligned(16))) TC Kall[FB_MAXN * FB_LDK];     // the utterance's K rows (this head): K^T operand of dQ^T
+  __shared__ __attribute__((aligned(16))) TC Kall[FB_KEYS * FB_LDK];     // this workgroup's K rows (one head): K^T operand of dQ^T
   __shared__ __attribute__((aligned(16))) TC Qs[FB_QT * FB_LDK];
   __shared__ __attribute__((aligned(16))) TC dOs[FB_QT * FB_LDK];
-  __shared__ float lse_all[FB_MAXN], delta_all[FB_MAXN];
+  __shared__ float lse_s[FB_QT], delta_s[FB_QT];
   __shared__ __attribute__((aligned(16))) TC Tp[FB_W][32 * FB_LDT];      // wave-private transposition tiles [query][key]
   __shared__ __attribute__((aligned(16))) TC Td[FB_W][32 * FB_LDT];
   __shared__ float red[2][FB_W][8][64];                                   // partial dQ^T of a query block, one slot per wave
+  __shared__ int arrived;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5, i16 = lane & 15, G = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = a.H, N = a.N, E = a.E;
-  const int bi = blockIdx.x / H, h = blockIdx.x - bi * H;
+  const int half = blockIdx.x & 1, bh = blockIdx.x >> 1;
+  const int bi = bh / H, h = bh - bi * H;
   const int b = a.order ? a.order[bi] : bi;
   int len = (int)a.lengths[b];
   len = len < 0 ? 0 : (len > N ? N : len);
+  const int nkb_all = (len + 31) >> 5, rows_live = nkb_all * 32;
+  const bool split = nkb_all > FB_KEYS / 32;                             // two workgroups share this (utterance, head)
+  if (half && !split) return;
   const long ld_g = 3L * E;
   const TC* base = reinterpret_cast<const TC*>(a.qkv) + (long)b * N * ld_g + h * DH;
   const TC* dO = reinterpret_cast<const TC*>(a.d_o) + (long)b * N * E + h * DH;
   const TC* Og = reinterpret_cast<const TC*>(a.o) + (long)b * N * E + h * DH;
   TC* dQ = reinterpret_cast<TC*>(a.dqkv) + (long)b * N * ld_g + h * DH;
   const float* lse = a.lse + ((long)b * H + h) * N;
-  const int nkb = (len + 31) >> 5, rows_live = nkb * 32;
-  {   // rows past the last live block: dQ | dK | dV are zero (this head's 16 columns of each)
+  const long npad = (N + 31) & ~31;
+  float* part = ws + (((long)b * H + h) * 2 + half) * npad * 16;        // split utterances: this workgroup's dQ partial [query][d]
+  int* counter = reinterpret_cast<int*>(ws + (long)gridDim.x * npad * 16) + (b * H + h);
+  if (!half) {   // rows past the last live block: dQ | dK | dV are zero (this head's 16 columns of each)
     const frag_t z = zero8<TC>();
     const int nz = (N - rows_live) * 6;
     for (int c = tid; c < nz; c += FB_T) {
-      const int row = rows_live + c / 6, part = c % 6;
-      *reinterpret_cast<frag_t*>(dQ + (long)row * ld_g + (part >> 1) * E + (part & 1) * 8) = z;
+      const int row = rows_live + c / 6, pt = c % 6;
+      *reinterpret_cast<frag_t*>(dQ + (long)row * ld_g + (pt >> 1) * E + (pt & 1) * 8) = z;
     }
   }
   if (len == 0) return;
-  for (int c = tid; c < rows_live * 2; c += FB_T) {
-    const int r = c >> 1, hf = (c & 1) * 8;
+  // key blocks of this workgroup [kbA, kbB) and of this wave [kb0, kb0 + cnt): spread evenly over the waves that get any
+  const int kbA = split ? (half ? (nkb_all + 1) >> 1 : 0) : 0, kbB = split ? (half ? nkb_all : (nkb_all + 1) >> 1) : nkb_all;
+  const int nkb = kbB - kbA;
+  for (int c = tid; c < nkb * 64; c += FB_T) {
+    const int r = c >> 1, hf = (c & 1) * 8, key = kbA * 32 + r;
     frag_t v = zero8<TC>();
-    if (r < len) v = *reinterpret_cast<const frag_t*>(base + E + (long)r * ld_g + hf);
+    if (key < len) v = *reinterpret_cast<const frag_t*>(base + E + (long)key * ld_g + hf);
     *reinterpret_cast<frag_t*>(&Kall[r * FB_LDK + hf]) = v;
   }
-  for (int q = tid; q < rows_live; q += FB_T) {   // delta_q = sum_d dO[q][d] O[q][d]; log-sum-exp in the log2 domain
-    float dl = 0.f, ls = 0.f;
-    if (q < len) {
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const frag_t x = *reinterpret_cast<const frag_t*>(dO + (long)q * E + hf * 8);
-        const frag_t y = *reinterpret_cast<const frag_t*>(Og + (long)q * E + hf * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dl += (float)x[e] * (float)y[e];
-      }
-      ls = lse[q] * LOG2E;
-    }
-    delta_all[q] = dl;
-    lse_all[q] = ls;
-  }
-  // key blocks of this wave: [kb0, kb0 + cnt), spread evenly over the waves that get any
   const int nwa = nkb < FB_W ? nkb : FB_W;
-  int kb0 = 0, cnt = 0;
-  if (w < nwa) { kb0 = (w * nkb) / nwa; cnt = ((w + 1) * nkb) / nwa - kb0; }
+  int kb0 = kbA, cnt = 0;
+  if (w < nwa) { kb0 = kbA + (w * nkb) / nwa; cnt = kbA + ((w + 1) * nkb) / nwa - kb0; }
   frag_t kf[FB_KB], vf[FB_KB];
   f32x4 dk[FB_KB][2], dv[FB_KB][2];
 #pragma unroll
@@ -793,18 +799,29 @@ __global__ __launch_bounds__(FB_T, 1) void attn_bwd_fused16_kernel(AttnArgs a) {
   const uint32_t NB = (uint32_t)(N + 3) >> 2;
   const uint32_t skey = dx_key32(a.seed, (uint32_t)(b * H + h));
 
-  const int srow = tid >> 1, shf = (tid & 1) * 8;   // this thread's 16-byte piece of a 256-row stage
+  const int srow = tid >> 1, shf = (tid & 1) * 8;   // this thread's 16-byte piece of a 128-row stage
   frag_t qreg, doreg;
+  float dreg, lreg;
   auto fetch = [&](int qs0) {                         // branch-free: rows past the tensor re-read its last row (masked later)
     const int r = min(qs0 + srow, N - 1);
     qreg = *reinterpret_cast<const frag_t*>(base + (long)r * ld_g + shf);
     doreg = *reinterpret_cast<const frag_t*>(dO + (long)r * E + shf);
+    const frag_t og = *reinterpret_cast<const frag_t*>(Og + (long)r * E + shf);
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d += (float)doreg[e] * (float)og[e];
+    dreg = d;                                         // half of delta_q = sum_d dO[q][d] O[q][d]; the lane pair adds up at commit
+    lreg = lse[r] * LOG2E;                            // log2 domain, see fast_exp2
   };
   fetch(0);
   int buf = 0;
   for (int qs0 = 0; qs0 < len; qs0 += FB_QT) {
     *reinterpret_cast<frag_t*>(&Qs[srow * FB_LDK + shf]) = qreg;
     *reinterpret_cast<frag_t*>(&dOs[srow * FB_LDK + shf]) = doreg;
+    {
+      const float d = dreg + __shfl_xor(dreg, 1, 64);
+      if (!(tid & 1)) { const bool ok = qs0 + srow < len; delta_s[srow] = ok ? d : 0.f; lse_s[srow] = ok ? lreg : 0.f; }
+    }
     __syncthreads();
     if (qs0 + FB_QT < len) fetch(qs0 + FB_QT);
     const int left = (len - qs0 + 31) >> 5, nsub = left < FB_QT / 32 ? left : FB_QT / 32;
@@ -817,7 +834,7 @@ __global__ __launch_bounds__(FB_T, 1) void attn_bwd_fused16_kernel(AttnArgs a) {
         const bool q_valid = q < len;
         const frag_t qf = *reinterpret_cast<const frag_t*>(&Qs[(sub * 32 + l31) * FB_LDK + g * 8]);
         const frag_t dof = *reinterpret_cast<const frag_t*>(&dOs[(sub * 32 + l31) * FB_LDK + g * 8]);
-        const float lse2 = lse_all[q], delta_q = delta_all[q];
+        const float lse2 = lse_s[sub * 32 + l31], delta_q = delta_s[sub * 32 + l31];
         const frag_t doA = tr8(dOs, FB_LDK, sub * 32, 0, lane);   // dO^T / Q^T: 16 d x 32 queries of this block
         const frag_t qA = tr8(Qs, FB_LDK, sub * 32, 0, lane);
         const uint32_t ctr_lane = dx_opaque(((uint32_t)(q >> 2) * NB + g) * DX_CTR_MUL + skey);
@@ -850,22 +867,20 @@ __global__ __launch_bounds__(FB_T, 1) void attn_bwd_fused16_kernel(AttnArgs a) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {   // registers 4jj .. 4jj + 3 = keys k0 + 8jj + 4g + {0..3}: one row word
               float x[4] = {dp[4 * jj], dp[4 * jj + 1], dp[4 * jj + 2], dp[4 * jj + 3]};
-              float pr[4], pm[4];
+              float pr[4];
 #pragma unroll
               for (int i = 0; i < 4; i += 2) {
                 const int r = 4 * jj + i;
                 const f32x2 t = pk_fma(f32x2{s[r], s[r + 1]}, c22, nl2);
                 pr[i] = fast_exp2<TC>(t[0]);
                 pr[i + 1] = fast_exp2<TC>(t[1]);
-                pm[i] = pr[i]; pm[i + 1] = pr[i + 1];
               }
-              dx_drop4x2(pm, x, hw[jj], th8);
+              dx_drop4x2(pd + 4 * jj, pr, x, hw[jj], th8);
 #pragma unroll
               for (int i = 0; i < 4; i += 2) {
                 const int r = 4 * jj + i;
                 const f32x2 d2 = f32x2{pr[i], pr[i + 1]} * pk_fma(f32x2{x[i], x[i + 1]}, ik2, nd2);
                 ds[r] = d2[0]; ds[r + 1] = d2[1];
-                pd[r] = pm[i]; pd[r + 1] = pm[i + 1];
               }
             }
             const frag_t pdf[2] = {pack8<TC>(pd), pack8<TC>(pd + 8)};
@@ -882,7 +897,7 @@ __global__ __launch_bounds__(FB_T, 1) void attn_bwd_fused16_kernel(AttnArgs a) {
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {   // dQ^T += K^T dS^T
-              const frag_t kT = gather8<TC, 16>(Kall + k0 * FB_LDK, FB_LDK, ks * 16 + 4 * g, ks * 16 + 4 * g + 8, 0, lane);
+              const frag_t kT = gather8<TC, 16>(Kall + (k0 - kbA * 32) * FB_LDK, FB_LDK, ks * 16 + 4 * g, ks * 16 + 4 * g + 8, 0, lane);
               dx_mma(dqT, kT, dsf[ks]);
             }
             asm volatile("" ::: "memory");      // the transposed reads below follow this wave's own tile writes (LDS is in order per wave)
@@ -902,13 +917,15 @@ __global__ __launch_bounds__(FB_T, 1) void attn_bwd_fused16_kernel(AttnArgs a) {
         for (int r = 0; r < 8; ++r) red[buf][w][r][lane] = dqT[r];   // rows d < 16 of the 32 x 32 accumulator
       }
       __syncthreads();
-      if (tid < 128) {   // thread = (query, 4 consecutive d): sums the waves' partials in wave order, one 8-byte store
+      if (tid < 128) {   // thread = (query, 4 consecutive d): sums the waves' partials in wave order, one store
         const int qq = tid & 31, dg = tid >> 5, rhi = dg >> 1, gg = dg & 1;
         float acc4[4] = {0.f, 0.f, 0.f, 0.f};
         for (int ww = 0; ww < nwa; ++ww)
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc4[e] += red[buf][ww][rhi * 4 + e][gg * 32 + qq];
-        if (qb + qq < N) {
+        if (split) {
+          *reinterpret_cast<f32x4*>(part + (long)(qb + qq) * 16 + 4 * dg) = f32x4{acc4[0], acc4[1], acc4[2], acc4[3]};
+        } else if (qb + qq < N) {
           bf16x4 o4;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o4[e] = (TC)(acc4[e] * a.scale);
@@ -932,6 +949,33 @@ __global__ __launch_bounds__(FB_T, 1) void attn_bwd_fused16_kernel(AttnArgs a) {
           *reinterpret_cast<bf16x4*>(dQ + 2 * E + (long)key * ld_g + 4 * G) = v4;
         }
       }
+    }
+  }
+  if (!split) return;
+  // second arrival of the pair adds the two partials (keys 0.. first, then the upper half) and writes dQ
+  // (hand-off recipe of the CDNA guide, section 6 G16: drain every wave's stores, ONE lane releases at agent scope, then the
+  // ticket; the second arrival acquires once -- a __threadfence() per thread made this kernel 1.8x slower)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int second = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1;
+    if (second) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    arrived = second;
+  }
+  __syncthreads();
+  if (!arrived) return;
+  const float* p0 = ws + (((long)b * H + h) * 2) * npad * 16;
+  const float* p1 = p0 + npad * 16;
+  for (int c = tid; c < rows_live * 4; c += FB_T) {
+    const int qq = c >> 2, dg = c & 3;
+    if (qq < N) {
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(p0 + (long)qq * 16 + 4 * dg), x1 = *reinterpret_cast<const f32x4*>(p1 + (long)qq * 16 + 4 * dg);
+      bf16x4 o4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o4[e] = (TC)((x0[e] + x1[e]) * a.scale);
+      *reinterpret_cast<bf16x4*>(dQ + (long)qq * ld_g + 4 * dg) = o4;
     }
   }
 }
@@ -958,7 +1002,7 @@ int launch_bwd(const AttnArgs& a, int B, int dh, float* delta, int algo, hipStre
     return DX_ERR_UNSUPPORTED;
   }
   if (can_fuse && (algo == DX_ATTN_FUSED || (algo == DX_ATTN_AUTO && fused_bwd_enabled()))) {
-    hipLaunchKernelGGL(attn_bwd_fused16_kernel, dim3(B * a.H), dim3(FB_T), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_fused16_kernel, dim3(B * a.H * 2), dim3(FB_T), 0, s, a, delta + (long)B * a.H * a.N);
     DX_LAUNCH_CHECK();
     return DX_OK;
   }
@@ -1007,6 +1051,11 @@ extern "C" int dx_attention_fwd(const void* qkv, int dtype, const int64_t* lengt
   if (dtype == DX_F32) return launch_fwd<float>(a, B, dh, (hipStream_t)stream);
   dx_set_error("dx_attention_fwd: bad dtype %d", dtype);
   return DX_ERR_DTYPE;
+}
+
+extern "C" long dx_attention_bwd_ws_floats(int B, int N, int H) {
+  if (B <= 0 || N <= 0 || H <= 0) return 0;
+  return (long)B * H * N + fb_ws_floats(B, N, H);
 }
 
 extern "C" int dx_attention_bwd(const void* qkv, const void* o, const void* d_o, int dtype, const float* lse,

@@ -265,6 +265,19 @@ def attention_fwd(qkv, lengths, nb_heads, p_drop=0., seed=0, need_lse=True, orde
 
 
 ATTN_AUTO, ATTN_TWO_PASS, ATTN_FUSED = 0, 1, 2
+_ATTN_WS = {}
+
+
+def _attn_workspace(B, N, nb_heads, device):
+    ''' backward workspace (dx_attention_bwd_ws_floats), kept per (device, stream, shape): its arrival counters are zeroed once and
+        left valid by every call.  Calls on one stream run in order, so they can share it. '''
+    key = (device, torch.cuda.current_stream(device).cuda_stream, B, N, nb_heads)
+    ws = _ATTN_WS.get(key)
+    if ws is None:
+        if len(_ATTN_WS) > 16:
+            _ATTN_WS.clear()
+        ws = _ATTN_WS[key] = torch.zeros((H.lib().dx_attention_bwd_ws_floats(B, N, nb_heads),), dtype=torch.float32, device=device)
+    return ws
 
 
 def attention_bwd(qkv, o, d_o, lse, lengths, nb_heads, p_drop=0., seed=0, order=None, algo=ATTN_AUTO):
@@ -272,7 +285,7 @@ def attention_bwd(qkv, o, d_o, lse, lengths, nb_heads, p_drop=0., seed=0, order=
     E = E3 // 3
     assert d_o.is_contiguous() and d_o.dtype == qkv.dtype
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty((B, nb_heads, N), dtype=torch.float32, device=qkv.device)
+    delta = _attn_workspace(B, N, nb_heads, qkv.device)
     H.check(H.lib().dx_attention_bwd(H.ptr(qkv), H.ptr(o), H.ptr(d_o), H.dt(qkv), H.ptr(lse), H.ptr(lengths), H.ptr(order), H.ptr(dqkv),
                                      H.ptr(delta), B, N, nb_heads, E, float(p_drop), int(seed), int(algo), H.stream()))
     return dqkv
