@@ -290,6 +290,35 @@ def synth_bench(args, hp, dev, rank, world):
         dist.destroy_process_group()
 
 
+def train_loop_bench(args, hp):
+    ''' the loop users run (`daft_exprt.train.train`, the reference's train.py:236-494): DataLoader workers synthesising and
+        collating utterances, `parse_batch` H2D copies, `Trainer.step`, a log line + metrics record per iteration.  Timed from its
+        own per-iteration durations (metrics.jsonl), the first `--warmup` iterations dropped. '''
+    import tempfile
+    from daft_exprt import train as T
+    out = tempfile.mkdtemp(prefix='dx_train_loop_')
+    hp.output_directory = out
+    hp.nb_iterations = args.warmup + args.steps
+    hp.iters_per_checkpoint = 10 ** 9
+    hp.iters_check_for_model_improvement = 10 ** 9
+    hp.checkpoint = ''
+    hp.multiprocessing_distributed = False
+    hp.synthetic_items = args.batch * (args.warmup + args.steps + 4)
+    hp.synthetic_workers = 24
+    T.train(0, hp, os.path.join(out, 'train.log'))
+    recs = [json.loads(l) for l in open(os.path.join(out, 'metrics.jsonl')) if 'DaftExprt.training/loss' in l]
+    recs = recs[args.warmup:]
+    secs = sum(r['DaftExprt.optimization/duration'] for r in recs)
+    frames = sum(r['valid_frames'] for r in recs)
+    print(json.dumps({'metric': 'training mel-frames/sec (real train() loop)', 'value': frames / secs, 'unit': 'mel-frames/s', 'n_gpus': 1,
+                      'steps': len(recs), 'warmup': args.warmup, 'ms_per_step': secs / len(recs) * 1e3, 'higher_is_better': True,
+                      'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+                      'config': {'workload': f'daft_exprt.train.train(): synthetic utterances through the DataLoader (24 workers) + collate + H2D + '
+                                             f'Trainer.step + per-iteration log line, batch {args.batch}, T <= 1000, {args.dtype}',
+                                 'valid_frames_per_step': frames / len(recs)},
+                      'roofline': None, 'cpu_baseline': None}))
+
+
 def spawn_ranks(n):
     ''' re-execute this command line as n ranks (one per GPU) under torch.distributed.run; rank 0 prints the JSON line '''
     import socket
@@ -318,6 +347,9 @@ def main():
     ap.add_argument('--workload', default='train', choices=['train', 'synth'],
                     help='train = BASELINE configs[1] (default; configs[4] with --batch 256 --tmin 500); synth = configs[3]')
     ap.add_argument('--tmin', type=int, default=1, help='minimum frames per synthetic utterance (configs[4]: 500)')
+    ap.add_argument('--loop', default='step', choices=['step', 'train'],
+                    help='step = Trainer.step back to back on resident batches (the metric); train = the REAL daft_exprt.train.train() loop '
+                         '(DataLoader workers, collate, H2D, per-iteration logging) on synthetic utterances, 1 GPU')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -334,6 +366,7 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.setdefault('NCCL_DEBUG', 'VERSION')
         dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == world
 
@@ -346,9 +379,13 @@ def main():
     torch.manual_seed(hp.seed)
     if args.workload == 'synth':
         return synth_bench(args, hp, dev, rank, world)
+    if args.loop == 'train':
+        return train_loop_bench(args, hp)
     model = DaftExprt(hp).to(dev).train()
     model.set_rank(rank)
     trainer = Trainer(model, hp, world)
+    if rank == 0:      # stderr: the JSON line stays alone on stdout
+        print(f'[bench] torch.distributed world {dist.get_world_size() if world > 1 else 1}; {trainer.reducer.describe()}', file=sys.stderr)
     batches, cpu_batches = [], []
     for i in range(args.pool):
         cb = synthetic_batch(hp, args.batch, seed=1234 + rank + 1000 * i, t_min=args.tmin, t_max=1000, force_first_full=True)

@@ -66,7 +66,8 @@ int dx_conv1d(const void* x, int x_dtype, long ldx, const void* w_packed, int w_
 int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const float* bias,
                  const float* residual, const float* gamma, const float* beta, const float* film, long ldf,
                  const int64_t* lengths, float* y, void* y_lp, float* s_out, float* mean, float* rstd, int B, int N,
-                 int Cin, int taps, float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, void* stream);
+                 int Cin, int taps, float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, const void* w_frag,
+                 void* stream);
 
 /* Data gradient of a conv / linear INTO a 128-channel residual stream, fused with the BACKWARD of the LayerNorm that
  * consumed that stream in the forward pass (autograd of model.py:189-191 resp. 226-235 + 259/262, i.e. what
@@ -81,7 +82,30 @@ int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void* w_packed, 
                     const float* s_in, const float* mean, const float* rstd, const float* gamma, const float* beta,
                     const float* film, long ldf, const int64_t* lengths, void* dx_pre_lp, float* dgamma, float* dbeta,
                     float* dfilm, long lddf, int B, int N, int Cin, int taps, float p_pre, uint64_t seed_pre,
-                    const int* plan, int plan_tiles, void* stream);
+                    const int* plan, int plan_tiles, const void* w_frag, void* stream);
+
+/* The weights of a k = 3 conv in MFMA-fragment order: out[chunk][tap][half][block][lane][8] = w_packed[tap][32 block + (lane & 31)]
+ * [32 chunk + 16 half + 8 (lane >> 5) + 0..7], block < Cout / 32; w_packed = the [3][Cout][Cin] bf16 packing of dx_pack_conv_weight
+ * (either orientation), Cin and Cout multiples of 32.  A fragment (the B operand of one v_mfma_f32_32x32x16_bf16) is one contiguous
+ * KiB, so a wave reads it from L2 straight into registers with one fully coalesced load and the weights never pass through LDS.
+ * Users: the optional `w_frag` of dx_conv1d_ln / dx_conv1d_lnbwd (Cout = 128, with a tile plan, Cin >= 256, Cin % 128 == 0: split-K
+ * workgroups of 4 waves with 512 registers each -- all rows x 64 channels x half of the contraction per wave, accumulators in AGPRs,
+ * four K chunks of fragments in flight per wave, LDS carries the activation tile only, the two K halves added through LDS in a
+ * fixed order; results differ from the w_frag = NULL path by fp32 summation order only) and dx_conv1d_wide. */
+int dx_pack_frag_major(const void* w_packed, void* out, int Cin, int Cout, void* stream);
+/* The same for n weights in one launch.  descs_dev: DEVICE array of n records {const void* src; void* dst; int Cin; int Cout;}
+ * (dx_frag_desc_size() bytes each); max_elems = the largest Cin * Cout * 3 in the table. */
+int dx_frag_desc_size(void);
+int dx_pack_frag_major_batched(const void* descs_dev, int n, long max_elems, void* stream);
+
+/* dx_conv1d for the WIDE k = 3 GEMMs (ConvNorm1D with 1024 -> 1024 channels in the prosody encoder's pre-net, model.py:341-363, and its
+ * data gradient): bf16 x (B, N, Cin) and y (B, N, Cout), weights in fragment order, Cin % 128 == 0, Cout % 256 == 0, flags = 0 or
+ * DX_CONV_RELU, bias fp32 or NULL.  256 rows x 256 channels per 4-wave workgroup (one wave per SIMD, 128 x 128 per wave = 256
+ * accumulator registers), activation tile through an LDS-DMA ring, weight fragments from L2 into registers one chunk ahead:
+ * 0.25 KB of LDS traffic per MFMA and half the L2 -> CU bytes of 256 x 128 tiles.  Rows n >= skip_lengths[b] + 2 are written as zeros
+ * (they never reach a valid output); skip_lengths may be NULL. */
+int dx_conv1d_wide(const void* x, long ldx, const void* w_frag, const float* bias, void* y, long ldy, const int64_t* skip_lengths,
+                   int B, int N, int Cin, int Cout, int flags, void* stream);
 
 /* Balanced position tiles for dx_conv1d_ln / dx_conv1d_lnbwd (optional `plan`; bf16 operands, Cin % 32 == 0, taps = 3 --
  * dx_conv1d_lnbwd also taps = 1).
@@ -281,6 +305,8 @@ int dx_loss_fwd_bwd(const float* dur, const float* energy, const float* pitch, c
 int dx_sumsq(const float* x, long n, float* out, void* stream);
 int dx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, const float* grad_norm_sq, float clip_thresh,
+                 float* grad_norm_sq_accum /* NULL, or a device scalar that receives += sum(g^2) of this slice: the norm the
+                 trainer logs (train.py:399 with an infinite threshold) without a pass of its own; per-section calls add up */,
                  void* stream);
 
 /* ---- K16: float -> integer frame durations on the device (DaftExprt.get_int_durations model.py:789-812 +

@@ -375,6 +375,62 @@ def test_planned_conv_ln_and_lnbwd_match_unplanned(film):
         assert float((r[0][k] - r[1][k]).abs().max()) <= 1e-4 * float(r[0][k].abs().max()) + 1e-5, k
 
 
+@pytest.mark.parametrize('film', [False, True])
+@pytest.mark.parametrize('lens_list,N', [([700, 433, 257, 256, 130, 5], 700), ([1000, 999, 31, 1, 0, 640, 512, 300], 1000), ([40, 17], 40)])
+def test_splitk_conv_ln_and_lnbwd_match_ring_kernel_and_fp32_reference(film, lens_list, N):
+    ''' the split-K kernel (fragment-order weights from L2 into registers, the two K halves of a workgroup added through LDS)
+        on the balanced tiles of the ring kernel: same inputs, same dropout counters -> results equal up to the fp32 summation order
+        of the contraction (two halves instead of one chain); padding rows exact zeros; bit-reproducible; and the conv itself
+        against a torch fp32 reference on the same bf16-rounded operands '''
+    from daft_exprt import ops
+    g = torch.Generator().manual_seed(N + len(lens_list))
+    B, cin = len(lens_list), 1024
+    lens = torch.tensor(lens_list).to(DEV)
+    n_idx = torch.arange(N, device=DEV)[None, :, None]
+    valid = n_idx < lens[:, None, None]
+    x = (torch.randn(B, N, cin, generator=g).to(DEV) * (n_idx < lens[:, None, None] + 2)).to(torch.bfloat16)
+    w = (torch.randn(128, cin, 3, generator=g) / (cin * 3) ** 0.5).to(DEV)
+    wp = ops.pack_conv_weight(w, torch.bfloat16)
+    wf = ops.pack_frag_major(wp)
+    bias, gamma, beta = (torch.randn(128, generator=g).to(DEV) for _ in range(3))
+    res = torch.randn(B, N, 128, generator=g).to(DEV) * valid
+    fl = torch.randn(B, 256, generator=g).to(DEV) if film else None
+    plan = ops.conv_tile_plan(lens, N)
+    ring = ops.conv1d_ln(x, wp, bias, res, gamma, beta, lens, film=fl, save=True, p_pre=0.1, seed_pre=9, lp_copy=True, plan=plan)
+    sk = ops.conv1d_ln(x, wp, bias, res, gamma, beta, lens, film=fl, save=True, p_pre=0.1, seed_pre=9, lp_copy=True, plan=plan, w_frag=wf)
+    sk2 = ops.conv1d_ln(x, wp, bias, res, gamma, beta, lens, film=fl, save=True, p_pre=0.1, seed_pre=9, lp_copy=True, plan=plan, w_frag=wf)
+    for a, b_, c_, name in zip(ring, sk, sk2, ('y', 'y_lp', 's', 'mean', 'rstd')):
+        m = valid if a.dim() == 3 else valid.reshape(-1)
+        a, b_, c_ = a.float(), b_.float(), c_.float()
+        assert torch.isfinite(b_).all(), name
+        assert torch.equal(b_, c_), name                                    # fixed summation order: reproducible
+        assert float((b_ * ~m).abs().max()) == 0., name                     # padding rows are zeros
+        tol = 2e-2 if name == 'y_lp' else 2e-4
+        assert float(((a - b_) * m).abs().max()) <= tol * max(1., float((a * m).abs().max())), (name, float(((a - b_) * m).abs().max()))
+    # s = dropout(conv) + residual with p = 0: the plain conv against torch on the bf16-rounded operands
+    s0 = ops.conv1d_ln(x, wp, bias, res, gamma, beta, lens, film=fl, save=True, lp_copy=True, plan=plan, w_frag=wf)[2]
+    ref = torch.nn.functional.conv1d(x.float().transpose(1, 2), w.to(torch.bfloat16).float(), bias, padding=1).transpose(1, 2) + res
+    assert float(((s0 - ref) * valid).abs().max()) <= 2e-3 * float(ref.abs().max())
+    # backward variant
+    _, _, s_in, mean, rstd = ring
+    wpt = ops.pack_conv_weight((torch.randn(cin, 128, 3, generator=g) / (cin * 3) ** 0.5).to(DEV), torch.bfloat16, transpose_flip=True)
+    wft = ops.pack_frag_major(wpt)
+    gin = torch.randn(B, N, 128, generator=g).to(DEV) * (n_idx < lens[:, None, None] + 2)
+    r = []
+    for frag in (None, wft, wft):
+        y = gin.clone()
+        dg, db = torch.zeros(128, device=DEV), torch.zeros(128, device=DEV)
+        df = torch.zeros(B, 256, device=DEV) if film else None
+        dx = ops.conv1d_lnbwd(x, wpt, y, s_in, mean, rstd, gamma, beta, lens, dg, db, film=fl, dfilm=df, p_pre=0.1, seed_pre=4, plan=plan, w_frag=frag)
+        r.append((y, dx.float(), dg, db, df))
+    assert torch.equal(r[1][0], r[2][0]) and torch.equal(r[1][1], r[2][1])
+    assert float((r[1][0] * ~valid).abs().max()) == 0. and float((r[1][1] * ~valid).abs().max()) == 0.
+    for k, tol in ((0, 2e-4), (1, 2e-2)):
+        assert float(((r[0][k] - r[1][k]) * valid).abs().max()) <= tol * max(1., float((r[0][k] * valid).abs().max())), k
+    for k in (2, 3) + ((4,) if film else ()):
+        assert float((r[0][k] - r[1][k]).abs().max()) <= 1e-3 * float(r[0][k].abs().max()) + 1e-4, k
+
+
 @pytest.mark.parametrize('B,N,cin', [(1, 5, 256), (300, 40, 128), (70, 130, 1024)])
 def test_planned_conv_ln_edge_batches(B, N, cin):
     ''' balanced-tile launches on batches far from the training shape: a single 5-row utterance, more utterances than

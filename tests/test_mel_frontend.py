@@ -48,6 +48,38 @@ def test_filterbank_properties_and_product_copy():
     assert fe.nb_frames(22050, hp) == 87 and fe.nb_frames(1024, make_hparams(centered=False)) == 1
 
 
+def test_mel_scale_known_answers_from_librosa_documentation():
+    ''' `librosa` is absent from the build image, so `librosa.filters.mel` (extract_features.py:346) cannot be run here.  What CAN be
+        pinned independently of this repository are the worked examples in librosa's public documentation of the functions the
+        filterbank is built from (Slaney scale, htk=False): hz_to_mel(60) = 0.9, hz_to_mel([110, 220, 440]) = [1.65, 3.3, 6.6],
+        mel_to_hz(3) = 200, mel_to_hz([1..5]) = [66.667, 133.333, 200, 266.667, 333.333], and the head of
+        mel_frequencies(n_mels=40) = [0, 85.317, 170.635, 255.952, 341.269, 426.586, 511.904, 597.221, 682.538, 767.855, 853.173,
+        938.49, 1024.856, ...] up to fmax = 11025 -- the entry 1024.856 is the first one above the 1 kHz break and fixes both the
+        break point and the logarithmic step ln(6.4) / 27 (it moves to 1024.1 / 1025.6 for a step 3 % off).  The remaining freedom
+        of `filters.mel` -- triangles between consecutive centre frequencies, `norm='slaney'` = 2 / (f[i+2] - f[i]) -- is checked
+        by construction below (peak position, linear flanks, area). '''
+    from oracle import mel_frontend_cpu as M
+    import importlib
+    fe = importlib.import_module('daft_exprt.extract_features')
+    assert abs(float(M._hz_to_mel(60.)) - 0.9) < 1e-12
+    assert np.allclose(M._hz_to_mel([110., 220., 440.]), [1.65, 3.3, 6.6], atol=1e-12)
+    assert abs(float(M._mel_to_hz(3.)) - 200.) < 1e-9
+    assert np.allclose(M._mel_to_hz([1., 2., 3., 4., 5.]), [66.667, 133.333, 200., 266.667, 333.333], atol=5e-4)
+    head = [0., 85.317, 170.635, 255.952, 341.269, 426.586, 511.904, 597.221, 682.538, 767.855, 853.173, 938.49, 1024.856]
+    f40 = M._mel_to_hz(np.linspace(M._hz_to_mel(0.), M._hz_to_mel(11025.), 40))
+    assert np.abs(f40[:13] - np.array(head)).max() < 6e-4 and abs(f40[-1] - 11025.) < 1e-6
+    # the filterbank of the model's configuration, both implementations: triangle i peaks at centre i + 1 of the 82 mel-spaced
+    # frequencies with height 2 / (f[i+2] - f[i]) and falls linearly to zero at centres i and i + 2
+    ctr = M._mel_to_hz(np.linspace(M._hz_to_mel(0.), M._hz_to_mel(8000.), 82))
+    hz = np.linspace(0., 11025., 513)
+    for fb in (M.mel_filterbank(22050, 1024, 80, 0, 8000), fe.mel_filter_bank(22050, 1024, 80, 0, 8000)):
+        for i in (0, 1, 17, 40, 63, 79):
+            lo, mid, hi = ctr[i], ctr[i + 1], ctr[i + 2]
+            peak = 2. / (hi - lo)
+            want = np.where(hz <= mid, (hz - lo) / (mid - lo), (hi - hz) / (hi - mid)).clip(min=0.) * peak
+            assert np.abs(fb[i] - want).max() <= 1e-6 * max(1., peak), i
+
+
 @pytest.mark.gpu
 def test_gpu_front_end_matches_reference_fixture():
     from daft_exprt import extract_features as fe

@@ -53,6 +53,7 @@ struct ConvArgs {
   int N, Cin, Cout, flags, B;
   LNEpi ln;
   const int* plan; int plan_tiles;     // balanced position tiles {b, n0, rows, 0} (dx_conv_tile_plan), ring kernels only
+  const void* w_frag;                  // the same weights in MFMA-fragment order (dx_pack_frag_major): split-K kernel, or NULL
 };
 
 template <typename T, int V> struct VecN;
@@ -1053,16 +1054,598 @@ extern "C" int dx_debug_cg_wg(unsigned long long* host_out) {
 }
 namespace {
 #endif
-#ifdef WR_TIMING
-}  // namespace
-extern "C" int dx_debug_wreg_timing(unsigned long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dx_wreg_ts), sizeof(unsigned long long) * 8 * 64);
-}
-extern "C" int dx_debug_wreg_wg(unsigned long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dx_wreg_wg), sizeof(unsigned long long) * 1024 * 4);
-}
-namespace {
+
+// ---- narrow-output k = 3 GEMM with the LayerNorm epilogues, split-K INSIDE the workgroup (conv_sk_kernel) ------------------------
+// The balanced-tile ring kernel above gives every CU one pass over the 786 KB weight slice of a 1024 -> 128 k = 3 GEMM, but its
+// main loop runs at a third of the matrix rate: weights (24 KB per K chunk) and activations (8 KB) share one LDS ring filled by
+// LDS-DMA, whose issue -> landed latency is ~1 us under load, so the bytes a CU can have in flight (two ring stages) cap the
+// stream at ~30 GB/s per CU; 4 x 2 register blocking needs 0.75 KB of LDS fragments per MFMA on top.  Here
+//   * the workgroup is 4 waves, ONE per SIMD, with the full 512-register file each: wave (wk, wc) owns ALL rows of the tile
+//     (<= 8 blocks of 32) x the channel half wc (2 blocks of 32) for the K half wk (the 16-channel half wk of every 32-channel
+//     chunk, all taps): <= 8 x 2 MFMA tiles = 256 accumulator registers;
+//   * its weight fragments come straight from L2 into registers: the weights are stored in fragment order
+//     (dx_pack_frag_major: [chunk][tap][half][channel block][lane][8], a fragment is one contiguous KiB), every fragment is read by
+//     exactly ONE wave of the workgroup -- 786 KB per CU per launch (with the waves split rows x K instead, the two row halves
+//     fetched every fragment twice and the kernel sat on the ~13 TB/s L2 -> register ceiling of the chip) -- and a wave keeps
+//     4 chunks (24 KiB) in flight in 96 registers: the register file is the weight ring, LDS holds activations only;
+//   * the haloed activation tile (<= 258 rows x 32 channels per chunk, 17 KB) runs through a 4-stage LDS-DMA ring issued by the
+//     same waves (inline asm: hipcc would drain every counted load before the first LDS read that follows a DMA it knows of);
+//     the two channel halves read the same activation fragments: 0.5 KB of LDS per MFMA;
+//   * after the last chunk the two K halves swap one channel block per row block through LDS and add, which leaves wave
+//     (wk, wc) with the complete rows of channel block 2 wc + wk for the LayerNorm epilogues (forward LayerNorm: dx_conv1d_ln;
+//     backward: dx_conv1d_lnbwd), the row-wise code of conv_gemm_kernel run by one 256-thread team.
+// The padding rows of the batch (an equal share per workgroup, as in the ring kernel) are zero-filled after the epilogue.
+constexpr int SK_THREADS = 256, SK_S = 4, SK_NB = 4, SK_MAXP = 5;
+#ifdef SK_TIMING   // development: per-workgroup stamps of the launches with LNM == SK_TIMING (tools/sk_timing.py), s_memrealtime ticks (10 ns)
+__device__ unsigned long long dx_sk_ts[1024 * 8];
+#define SK_STAMP(i) do { if (LNM == SK_TIMING && threadIdx.x == 0) dx_sk_ts[(blockIdx.x & 1023) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long dx_sk_chunk[4 * 64 * 8];   // workgroup 40, wave w: per chunk {start, after the DMA wait, after the barrier, after the DMA issue, end} (s_memtime)
+#define SK_CHUNK(k, i) do { if (LNM == SK_TIMING && blockIdx.x == 40 && lane == 0 && (k) < 64) dx_sk_chunk[(wave * 64 + (k)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SK_STAMP(i)
+#define SK_CHUNK(k, i)
 #endif
+
+__device__ __forceinline__ void sk_dma16(const void* gsrc, unsigned lds_dst) {   // one 1-KiB LDS-DMA piece (16 B per lane)
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void sk_wait_vmcnt(int n) {   // s_waitcnt vmcnt(n), n wave-uniform
+  switch (n) {
+#define DX_VMW(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+    DX_VMW(18) DX_VMW(19) DX_VMW(20) DX_VMW(21) DX_VMW(22) DX_VMW(23) DX_VMW(24) DX_VMW(25) DX_VMW(26) DX_VMW(27) DX_VMW(28)
+#undef DX_VMW
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
+template <int LNM>
+__global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
+  typedef bf16_t TC;
+  typedef bf16x8 frag_t;
+  constexpr int LN = LNM == 3 ? 2 : LNM;
+  constexpr bool LNFILM = LNM == 2;
+  constexpr int TAPS = 3, HALO = 1, MAXBLK = 8, AROWS = 32 * MAXBLK + TAPS - 1, AR16 = (AROWS + 15) & ~15, STAGE_EL = AR16 * 32;
+  constexpr int STG_LD = BN + 4;
+  constexpr int RING_BYTES = SK_S * STAGE_EL * 2, XCH_BYTES = 4 * MAXBLK * 16 * 64 * 4, STG_BYTES = 64 * STG_LD * 4;
+  constexpr int SMEM_BYTES = RING_BYTES > XCH_BYTES ? (RING_BYTES > STG_BYTES ? RING_BYTES : STG_BYTES) : (XCH_BYTES > STG_BYTES ? XCH_BYTES : STG_BYTES);
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+  TC* ring = reinterpret_cast<TC*>(smem);
+  float* stage = reinterpret_cast<float*>(smem);
+  float* xch = reinterpret_cast<float*>(smem);
+  auto lds_at = [](int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3); };
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wk = wave & 1, wc = wave >> 1;
+  const int4 e = reinterpret_cast<const int4*>(p.plan)[blockIdx.x];
+  const int b = e.x, n0 = e.y, h = e.z, fill_per = e.w;
+  const int N = p.N, Cin = p.Cin;
+  const int len = p.mask_len ? (int)p.mask_len[b] : N;
+  SK_STAMP(0);
+
+  if (h > 0) {
+    f32x16 acc[MAXBLK][2];
+#pragma unroll
+    for (int i = 0; i < MAXBLK; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const TC* X = reinterpret_cast<const TC*>(p.x) + (size_t)b * N * p.ldx;
+    const int nk = Cin >> 5;
+    const int nA = (h + TAPS - 1 + 15) >> 4;                       // 16-row pieces of the haloed activation tile
+    const int mine = __builtin_amdgcn_readfirstlane(nA > wave ? (nA - wave + 3) >> 2 : 0);   // pieces wave, wave + 4, ... are this wave's
+    const TC* src[SK_MAXP];
+    unsigned dst[SK_MAXP];
+#pragma unroll
+    for (int t = 0; t < SK_MAXP; ++t) {
+      const int q = wave + 4 * t;
+      const int r = q * 16 + (lane >> 2);                          // row of the tile image this lane fills
+      const int c = (lane & 3) ^ ((r >> 2) & 3);                   // source chunk that belongs at position lane & 3 (lds_at)
+      const int n = n0 + r - HALO;
+      const TC* sp = reinterpret_cast<const TC*>(dx_zero_page) + c * 8;
+      if (q < nA && r < h + TAPS - 1 && n >= 0 && n < N) sp = X + (long)n * p.ldx + c * 8;
+      src[t] = sp;
+      dst[t] = (unsigned)(q * 512 * 2);
+    }
+    const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+    auto issue_dma = [&](int kc, int buf) {
+#pragma unroll
+      for (int t = 0; t < SK_MAXP; ++t)
+        if (t < mine) sk_dma16(src[t] + kc * 32, __builtin_amdgcn_readfirstlane(ring_base + (unsigned)(buf * STAGE_EL * 2) + dst[t]));
+    };
+    // weight fragments of this wave: K half wk, channel blocks 2 wc + (j ^ wk) for the LOCAL index j -- local 0 is the block the
+    // wave keeps after the exchange (2 wc + wk), local 1 the one it hands to its partner: static register indices either way.
+    // Fragment (chunk kc, tap, half, block c) sits at ((kc * 3 + tap) * 2 + half) * 2048 + c * 512 elements.
+    const TC* wp = reinterpret_cast<const TC*>(p.w_frag) + (size_t)wk * 2048 + (size_t)(2 * wc) * 512 + lane * 8;
+    const int jflip = wk * 512;
+    frag_t bq[SK_NB][TAPS][2];
+    auto load_b = [&](int kc, int tap, frag_t* d) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) d[j] = *reinterpret_cast<const frag_t*>(wp + (size_t)(kc * 3 + tap) * 4096 + ((j * 512) ^ jflip));
+    };
+    const int nblk = __builtin_amdgcn_readfirstlane((h + 31) >> 5);   // live 32-row blocks
+    // Every workgroup walks the K chunks in its own rotation: workgroup L runs on XCD L % 8, and the 32 workgroups of an XCD
+    // start within a microsecond of each other -- in the same order they would all ask the XCD's L2 for the same weight lines
+    // at the same time (one channel serves them one after the other: measured 30 GB/s per CU of L2 hits, a quarter of what the
+    // L2 delivers to CUs that read different lines).  The fp32 sums of different tiles then run in different chunk orders
+    // (each still fixed, so results stay reproducible).
+    const int koff = (int)((blockIdx.x >> 3) % (unsigned)nk);
+    auto kc_of = [&](int it) { const int k = it + koff; return k >= nk ? k - nk : k; };
+    const bool counted = nk >= 8;                                      // the vmcnt arithmetic below holds (else: drain)
+#pragma unroll
+    for (int st = 0; st < SK_S - 1; ++st)
+      if (st < nk) issue_dma(kc_of(st), st);
+#pragma unroll
+    for (int nb = 0; nb < SK_NB; ++nb)
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) load_b(kc_of(nb < nk ? nb : nk - 1), tap, bq[nb][tap]);
+    // one K chunk.  Memory operations of a wave in program order: [DMA pieces of chunk it + S - 1] [6 fragment loads of chunk
+    // it + NB] per iteration, so when the pieces of chunk `it` must have landed, 6 (S - 1) fragment loads and the DMA pieces of
+    // the (up to S - 2) iterations in between may still be in flight: 18 + mine * min(2, nk - 1 - it) (S = 4; prologue-issued
+    // chunks have more behind them: the count stays a lower bound).  The fragment loads are UNCONDITIONAL (past the last chunk they
+    // re-read it): hipcc counts them itself, and a load that may not execute makes it assume the worst at every use -- with
+    // `if (it + NB < nk)` around them it drained the whole queue (vmcnt(0)) in front of the first MFMA of every chunk.  It does
+    // not see the DMA pieces: its waits are early, never late.
+    auto chunk = [&](int it, auto slot_tag, auto na_tag) {
+      constexpr int U = decltype(slot_tag)::value, NA = decltype(na_tag)::value;
+      const int behind = nk - 1 - it;
+      SK_CHUNK(it, 0);
+      if (counted) sk_wait_vmcnt(18 + mine * (behind > 2 ? 2 : behind));
+      else sk_wait_vmcnt(0);
+      SK_CHUNK(it, 1);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      SK_CHUNK(it, 2);
+      if (it + SK_S - 1 < nk) issue_dma(kc_of(it + SK_S - 1), (it + SK_S - 1) % SK_S);
+      SK_CHUNK(it, 3);
+      const TC* Ar = ring + (it % SK_S) * STAGE_EL;
+      const int knext = kc_of(it + SK_NB < nk ? it + SK_NB : nk - 1);
+      frag_t a[2][NA];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(&Ar[lds_at(i * 32 + l31, wk * 2 + g)]);
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        if (tap + 1 < TAPS) {                        // the next tap's activation fragments are requested before this tap's MFMAs
+#pragma unroll
+          for (int i = 0; i < NA; ++i) a[(tap + 1) & 1][i] = *reinterpret_cast<const frag_t*>(&Ar[lds_at(i * 32 + l31 + tap + 1, wk * 2 + g)]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) dx_mma(acc[i][j], a[tap & 1][i], bq[U][tap][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(knext, tap, bq[U][tap]);              // refill the slots just read: chunk it + NB
+      }
+      SK_CHUNK(it, 4);
+    };
+    auto mainloop = [&](auto na_tag) {               // nk % 4 == 0 (launcher): four chunks per trip, the fragment ring bq[] is indexed statically
+      for (int it = 0; it < nk; it += SK_NB) {
+        chunk(it, std::integral_constant<int, 0>{}, na_tag);
+        chunk(it + 1, std::integral_constant<int, 1>{}, na_tag);
+        chunk(it + 2, std::integral_constant<int, 2>{}, na_tag);
+        chunk(it + 3, std::integral_constant<int, 3>{}, na_tag);
+      }
+    };
+    SK_STAMP(1);
+    if (nblk > 4) mainloop(std::integral_constant<int, 8>{});
+    else if (nblk > 2) mainloop(std::integral_constant<int, 4>{});
+    else if (nblk == 2) mainloop(std::integral_constant<int, 2>{});
+    else mainloop(std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // the ring is dead: exchange / epilogue staging reuse it
+    SK_STAMP(2);
+
+    // ---- the two K halves meet: wave (wk, wc) hands its partner (wk ^ 1, wc) the local-1 tiles and adds what it receives to its
+    // local-0 tiles: channel block cb = 2 wc + wk, complete (a + b == b + a: the order of the two halves does not matter)
+    {
+      float* mine_x = xch + (size_t)wave * (MAXBLK * 16 * 64) + lane;
+      const float* part_x = xch + (size_t)(wave ^ 1) * (MAXBLK * 16 * 64) + lane;
+#pragma unroll
+      for (int i = 0; i < MAXBLK; ++i)
+        if (i < nblk) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mine_x[(i * 16 + r) * 64] = acc[i][1][r];
+        }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < MAXBLK; ++i)
+        if (i < nblk) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][0][r] += part_x[(i * 16 + r) * 64];
+        }
+      __syncthreads();
+    }
+    SK_STAMP(3);
+    // ---- LayerNorm epilogue (the PLAN epilogue of conv_gemm_kernel with one 256-thread team)
+    constexpr int NCS = LNM == 2 ? 4 : (LNM == 3 ? 2 : 1);
+    float csum[NCS][8];
+#pragma unroll
+    for (int q = 0; q < NCS; ++q)
+#pragma unroll
+      for (int e2 = 0; e2 < 8; ++e2) csum[q][e2] = 0.f;
+    const int cb = 2 * wc + wk;
+    const float bv = p.bias ? p.bias[cb * 32 + l31] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXBLK / 2; ++i) {
+      if (i * 64 >= h) break;                          // workgroup-uniform: the barriers below stay matched
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[(rb * 32 + dx_acc_row(r, g)) * STG_LD + cb * 32 + l31] = acc[2 * i + rb][0][r] + bv;
+      f32x8 pf_a[4], pf_b[4];
+      float pf_m[4], pf_r[4];
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {           // the global inputs of all four passes are requested before the barrier
+        const int sr = (tid >> 4) + pass * 16, trow = i * 64 + sr;
+        const int n = n0 + trow, cl = (tid & 15) * 8;
+        if (n < N && trow < h) {
+          const size_t rowg = (size_t)b * N + n, offl = rowg * BN + cl;
+          if (LN == 2) {
+            pf_a[pass] = raw_load8<float>(p.ln.y + offl);
+            pf_b[pass] = raw_load8<float>(p.ln.s_out + offl);
+            pf_m[pass] = p.ln.mean[rowg];
+            pf_r[pass] = p.ln.rstd[rowg];
+          } else {
+            pf_a[pass] = raw_load8<float>(p.ln.residual + offl);
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int sr = (tid >> 4) + pass * 16, trow = i * 64 + sr;
+        const int n = n0 + trow, cl = (tid & 15) * 8;
+        if (n < N && trow < h) {
+          float v[8];
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(&stage[sr * STG_LD + cl]);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(&stage[sr * STG_LD + cl + 4]);
+          v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+          const size_t rowg = (size_t)b * N + n, offl = rowg * BN + cl;
+          if (LN == 2) {        // fused LayerNorm BACKWARD: v + residual gradient = dL/d(LN output) of this row
+            {
+              const f32x8 r = pf_a[pass];
+#pragma unroll
+              for (int e2 = 0; e2 < 8; ++e2) v[e2] = n < len ? v[e2] + r[e2] : 0.f;     // masked_fill rows carry no gradient
+            }
+            const f32x8 sv = pf_b[pass];
+            const float mean = pf_m[pass], rstd = pf_r[pass];
+            const f32x8 gm = raw_load8<float>(p.ln.gamma + cl);
+            float xh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e2 = 0; e2 < 8; ++e2) xh[e2] = (sv[e2] - mean) * rstd;
+            if (LNFILM) {                                         // y = fg * LN + fb
+              const f32x8 fg = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + cl), bt = raw_load8<float>(p.ln.beta + cl);
+#pragma unroll
+              for (int e2 = 0; e2 < 8; ++e2) {
+                csum[LNFILM ? 2 : 0][e2] += v[e2] * (xh[e2] * gm[e2] + bt[e2]);
+                csum[LNFILM ? 3 : 0][e2] += v[e2];
+                v[e2] *= fg[e2];
+              }
+            }
+#pragma unroll
+            for (int e2 = 0; e2 < 8; ++e2) {
+              csum[0][e2] += v[e2] * xh[e2];
+              csum[NCS > 1 ? 1 : 0][e2] += v[e2];
+              v[e2] *= gm[e2];
+              s1 += v[e2];
+              s2 += v[e2] * xh[e2];
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            s1 *= 1.f / BN; s2 *= 1.f / BN;
+#pragma unroll
+            for (int e2 = 0; e2 < 8; ++e2) v[e2] = rstd * (v[e2] - s1 - xh[e2] * s2);
+            store8<float>(p.ln.y + offl, v);                      // ds, in place of the residual gradient
+            if (p.ln.p_pre > 0.f) {
+              const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(p.ln.seed_pre, 0);
+              const float sc = 1.f / (1.f - p.ln.p_pre);
+#pragma unroll
+              for (int e2 = 0; e2 < 8; ++e2) v[e2] = dx_keep(key, (uint32_t)rowg * BN + cl + e2, th) ? v[e2] * sc : 0.f;
+            }
+            store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + offl, v);
+          } else {              // fused LayerNorm: 16 lanes hold one complete 128-channel row
+            if (p.ln.p_pre > 0.f) {
+              const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(p.ln.seed_pre, 0);
+              const float sc = 1.f / (1.f - p.ln.p_pre);
+#pragma unroll
+              for (int e2 = 0; e2 < 8; ++e2) v[e2] = dx_keep(key, (uint32_t)rowg * BN + cl + e2, th) ? v[e2] * sc : 0.f;
+            }
+            {
+              const f32x8 r = pf_a[pass];
+#pragma unroll
+              for (int e2 = 0; e2 < 8; ++e2) v[e2] += r[e2];
+            }
+            if (p.ln.s_out) store8<float>(p.ln.s_out + offl, v);
+            float sum = 0.f;
+#pragma unroll
+            for (int e2 = 0; e2 < 8; ++e2) sum += v[e2];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            const float mean = sum * (1.f / BN);
+            float sq = 0.f;
+#pragma unroll
+            for (int e2 = 0; e2 < 8; ++e2) { const float d = v[e2] - mean; sq += d * d; }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sq += __shfl_xor(sq, o, 64);
+            const float rstd = rsqrtf(sq * (1.f / BN) + 1e-5f);
+            if (p.ln.mean && cl == 0) { p.ln.mean[rowg] = mean; p.ln.rstd[rowg] = rstd; }
+            const f32x8 gm = raw_load8<float>(p.ln.gamma + cl), bt = raw_load8<float>(p.ln.beta + cl);
+#pragma unroll
+            for (int e2 = 0; e2 < 8; ++e2) v[e2] = (v[e2] - mean) * rstd * gm[e2] + bt[e2];
+            if (p.ln.film) {
+              const f32x8 fg = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + cl), fb = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + BN + cl);
+#pragma unroll
+              for (int e2 = 0; e2 < 8; ++e2) v[e2] = fg[e2] * v[e2] + fb[e2];
+            }
+            if (n >= len) {
+#pragma unroll
+              for (int e2 = 0; e2 < 8; ++e2) v[e2] = 0.f;
+            }
+            store8<float>(p.ln.y + offl, v);
+            if (p.ln.y_lp) store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + offl, v);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (LN == 2) {   // column sums: 16 row-threads per channel segment -> LDS -> one atomic per channel per workgroup
+      for (int q = 0; q < NCS; ++q)
+#pragma unroll
+        for (int e2 = 0; e2 < 8; ++e2) stage[(q * 16 + (tid >> 4)) * BN + (tid & 15) * 8 + e2] = csum[q][e2];
+      __syncthreads();
+      for (int idx = tid; idx < NCS * BN; idx += SK_THREADS) {
+        const int q = idx / BN, c = idx - q * BN;
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += stage[(q * 16 + r) * BN + c];
+        if (q == 0) atomicAdd(p.ln.dgamma + c, t);
+        else if (q == 1) atomicAdd(p.ln.dbeta + c, t);
+        else atomicAdd(p.ln.dfilm + (size_t)b * p.ln.lddf + (q == 3 ? BN : 0) + c, t);
+      }
+    }
+  }
+  SK_STAMP(4);
+  // ---- padding fill: the batch's padding rows, flattened utterance by utterance, are split evenly over the workgroups; this one
+  // owns [lo, hi).  Each wave finds the utterances its range touches with a wave scan over the lengths, and the 256 threads share
+  // the 16-byte segments of those rows.
+  {
+    const long lo = (long)blockIdx.x * fill_per, hi = lo + fill_per;
+    long carry = 0;
+    for (int base = 0; base < p.B && carry < hi; base += 64) {
+      const int ub = base + lane;
+      const int ulen = ub < p.B ? (int)p.skip_len[ub] : N;
+      const int dead = ub < p.B ? N - (ulen < 0 ? 0 : (ulen > N ? N : ulen)) : 0;
+      int incl = dead;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+      const long ustart = carry + incl - dead, uend = carry + incl;
+      const long fs = ustart > lo ? ustart : lo, fe = uend < hi ? uend : hi;
+      unsigned long long todo = __ballot(fs < fe);
+      while (todo) {
+        const int src_lane = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int fb = base + src_lane;
+        const int first = __shfl(N - dead + (int)(fs - ustart), src_lane, 64), cntr = __shfl((int)(fe - fs), src_lane, 64);
+        float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c = tid; c < cntr * (BN / 8); c += SK_THREADS) {
+          const int n = first + (c >> 4), cl = (c & 15) * 8;
+          const size_t off = ((size_t)fb * N + n) * BN + cl;
+          store8<float>(p.ln.y + off, z);
+          if (LN == 2 || p.ln.y_lp) store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + off, z);
+          if (LN == 1) {
+            if (p.ln.s_out) store8<float>(p.ln.s_out + off, z);
+            if (p.ln.mean && cl == 0) { p.ln.mean[(size_t)fb * N + n] = 0.f; p.ln.rstd[(size_t)fb * N + n] = 0.f; }
+          }
+        }
+      }
+      carry += __shfl(incl, 63, 64);
+    }
+  }
+  SK_STAMP(5);
+}
+
+
+// ---- wide k = 3 GEMM (Cout a multiple of 256, long contraction: the pre-net's 1024 -> 1024 conv and its data gradient) on the
+// full register file: 256 rows x 256 channels per 4-wave workgroup, ONE wave per SIMD, wave (wr, wc) = 128 rows x 128 channels =
+// 4 x 4 MFMA tiles = 256 accumulator registers.  Same ingredients as conv_sk_kernel: the haloed activation tile (258 rows x 32
+// channels per chunk) through a 3-stage LDS-DMA ring issued by the waves themselves, the weights in fragment order
+// (dx_pack_frag_major) from L2 straight into registers -- a ring of 6 k-steps = one chunk (4 fragments each, 96 registers): the
+// slot a k-step has just read is refilled with the same k-step of the next chunk -- and the per-workgroup rotation of the chunk order.  Per k-step a wave
+// reads 4 activation fragments from LDS for 16 MFMAs (0.25 KB of LDS per MFMA; the 128-channel tiles of conv_gemm_kernel need 0.75).
+// L2 -> CU traffic per launch = 2 bytes x M N K x (1 / 256 + 1 / 256): half of what 256 x 128 tiles fetch.
+// Epilogue: bias, ReLU, rows past length + 2 zeroed; a wave stages one 32-row x 128-channel slab at a time through its own LDS
+// region and stores whole 256-byte row segments in bf16.
+constexpr int WD_THREADS = 256, WD_S = 3, WD_RING = 6, WD_MAXP = 5;
+__device__ __forceinline__ void wd_wait_vmcnt(int n) {
+  switch (n) {
+#define DX_VMW(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+    DX_VMW(48) DX_VMW(49) DX_VMW(50) DX_VMW(51) DX_VMW(52) DX_VMW(53)
+#undef DX_VMW
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
+__global__ __launch_bounds__(WD_THREADS, 1) void conv_wide_kernel(ConvArgs p) {
+  typedef bf16_t TC;
+  typedef bf16x8 frag_t;
+  constexpr int TAPS = 3, HALO = 1, BMW = 256, AROWS = BMW + TAPS - 1, AR16 = (AROWS + 15) & ~15, STAGE_EL = AR16 * 32;
+  constexpr int SLAB_LD = 128 + 4;
+  constexpr int RING_BYTES = WD_S * STAGE_EL * 2, SLAB_BYTES = 4 * 32 * SLAB_LD * 4;
+  __shared__ __attribute__((aligned(16))) char smem[RING_BYTES > SLAB_BYTES ? RING_BYTES : SLAB_BYTES];
+  TC* ring = reinterpret_cast<TC*>(smem);
+  auto lds_at = [](int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3); };
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 1, wc = wave & 1;
+  const int N = p.N, Cin = p.Cin, Cout = p.Cout;
+  // XCD-aware, weight-stationary order (see conv_gemm_kernel): an XCD walks all of its position tiles for channel tile 0, then 1, ..
+  const int ptiles = dx_cdiv(N, BMW);
+  const int Lid = blockIdx.x, jj = Lid >> 3;
+  const int per_xcd = (ptiles * p.B + 7) >> 3;
+  const int pt = (Lid & 7) + 8 * (jj % per_xcd);
+  if (pt >= ptiles * p.B) return;
+  const int n0 = (pt % ptiles) * BMW, b = pt / ptiles, ct = jj / per_xcd;
+  const int co_w = ct * 256 + wc * 128;                              // first channel of this wave
+  TC* Y = reinterpret_cast<TC*>(p.y);
+  const int h = N - n0 < BMW ? N - n0 : BMW;                         // rows of this tile inside the tensor
+  const int lim = p.skip_len ? (int)p.skip_len[b] + 2 : N;           // rows >= lim never reach a valid output: zeros
+  if (n0 >= lim) {                                                   // padding early-out
+    const bf16x8 z = zero8<TC>();
+    for (int c = tid; c < h * 32; c += WD_THREADS) {
+      const int n = n0 + (c >> 5), co = ct * 256 + (c & 31) * 8;
+      *reinterpret_cast<bf16x8*>(Y + ((size_t)b * N + n) * p.ldy + co) = z;
+    }
+    return;
+  }
+  const int hv = lim - n0 < h ? lim - n0 : h;                        // rows that carry work
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+  const TC* X = reinterpret_cast<const TC*>(p.x) + (size_t)b * N * p.ldx;
+  const int nk = Cin >> 5;
+  const int nA = (hv + TAPS - 1 + 15) >> 4;
+  const int mine = __builtin_amdgcn_readfirstlane(nA > wave ? (nA - wave + 3) >> 2 : 0);
+  const TC* src[WD_MAXP];
+  unsigned dst[WD_MAXP];
+#pragma unroll
+  for (int t = 0; t < WD_MAXP; ++t) {
+    const int q = wave + 4 * t;
+    const int r = q * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((r >> 2) & 3);
+    const int n = n0 + r - HALO;
+    const TC* sp = reinterpret_cast<const TC*>(dx_zero_page) + c * 8;
+    if (q < nA && r < hv + TAPS - 1 && n >= 0 && n < N) sp = X + (long)n * p.ldx + c * 8;
+    src[t] = sp;
+    dst[t] = (unsigned)(q * 512 * 2);
+  }
+  const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+  auto issue_dma = [&](int kc, int buf) {
+#pragma unroll
+    for (int t = 0; t < WD_MAXP; ++t)
+      if (t < mine) sk_dma16(src[t] + kc * 32, __builtin_amdgcn_readfirstlane(ring_base + (unsigned)(buf * STAGE_EL * 2) + dst[t]));
+  };
+  const int koff = (int)((blockIdx.x >> 3) % (unsigned)nk);         // per-workgroup rotation of the chunk order (see conv_sk_kernel)
+  auto kc_of = [&](int it) { const int k = it + koff; return k >= nk ? k - nk : k; };
+  // fragment (k-step q = chunk * 6 + tap * 2 + half, channel block c) at q * (Cout / 32) * 512 + c * 512 elements
+  const size_t qstride = (size_t)(Cout >> 5) * 512;
+  const TC* wp = reinterpret_cast<const TC*>(p.w_frag) + (size_t)(co_w >> 5) * 512 + lane * 8;
+  frag_t bq[WD_RING][4];
+  auto load_b = [&](int it, int ks6, frag_t* d) {   // k-step ks6 of chunk `it` (in this workgroup's rotation; past the end: the last chunk again)
+    const TC* base = wp + (size_t)(kc_of(it < nk ? it : nk - 1) * 6 + ks6) * qstride;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) d[c] = *reinterpret_cast<const frag_t*>(base + c * 512);
+  };
+  const int nblk_w = __builtin_amdgcn_readfirstlane(hv > wr * 128 ? ((hv - wr * 128 + 31) >> 5 > 4 ? 4 : (hv - wr * 128 + 31) >> 5) : 0);   // live row blocks of this wave
+  const bool counted = nk >= 8;
+#pragma unroll
+  for (int st = 0; st < WD_S - 1; ++st)
+    if (st < nk) issue_dma(kc_of(st), st);
+#pragma unroll
+  for (int s0 = 0; s0 < WD_RING; ++s0) load_b(0, s0, bq[s0]);
+  // per chunk a wave issues [DMA pieces of chunk it + S - 1] [24 fragment loads]: when the pieces of chunk `it` must have landed,
+  // 24 (S - 1) fragment loads + the pieces of the iteration in between may be in flight: 48 + mine * min(1, nk - 1 - it) (S = 3)
+  auto chunk = [&](int it, auto na_tag) {
+    constexpr int NA = decltype(na_tag)::value;
+    const int behind = nk - 1 - it;
+    if (counted) wd_wait_vmcnt(48 + mine * (behind > 1 ? 1 : behind));
+    else wd_wait_vmcnt(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (it + WD_S - 1 < nk) issue_dma(kc_of(it + WD_S - 1), (it + WD_S - 1) % WD_S);
+    const TC* Ar = ring + (it % WD_S) * STAGE_EL;
+    frag_t a[2][NA > 0 ? NA : 1];
+    if constexpr (NA > 0) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(&Ar[lds_at(wr * 128 + i * 32 + l31, g)]);
+    }
+#pragma unroll
+    for (int ks6 = 0; ks6 < 6; ++ks6) {
+      if constexpr (NA > 0) {
+        if (ks6 + 1 < 6) {                           // the next k-step's activation fragments are requested before this one's MFMAs
+          const int tn = (ks6 + 1) >> 1, kn = (ks6 + 1) & 1;
+#pragma unroll
+          for (int i = 0; i < NA; ++i) a[(ks6 + 1) & 1][i] = *reinterpret_cast<const frag_t*>(&Ar[lds_at(wr * 128 + i * 32 + l31 + tn, kn * 2 + g)]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) dx_mma(acc[i][c], a[ks6 & 1][i], bq[ks6][c]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      load_b(it + 1, ks6, bq[ks6]);                  // the same k-step of the next chunk
+    }
+  };
+  auto mainloop = [&](auto na_tag) {
+    for (int it = 0; it < nk; ++it) chunk(it, na_tag);
+  };
+  if (nblk_w > 2) mainloop(std::integral_constant<int, 4>{});
+  else if (nblk_w == 2) mainloop(std::integral_constant<int, 2>{});
+  else if (nblk_w == 1) mainloop(std::integral_constant<int, 1>{});
+  else mainloop(std::integral_constant<int, 0>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                   // the ring is dead: every wave stages its slabs through its own region
+
+  const bool relu = p.flags & DX_CONV_RELU;
+  float* slab = reinterpret_cast<float*>(smem) + (size_t)wave * (32 * SLAB_LD);
+  float bv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) bv[c] = p.bias ? p.bias[co_w + c * 32 + l31] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r0 = wr * 128 + i * 32;                // first tile row of this 32-row block
+    if (r0 >= h) break;                              // wave-uniform; the staging region is wave-private: no workgroup barrier
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[i][c][r] + bv[c];
+        if (relu) v = fmaxf(v, 0.f);
+        slab[dx_acc_row(r, g) * SLAB_LD + c * 32 + l31] = v;
+      }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {           // 16 lanes x 16 bytes = one 256-byte row segment per store instruction
+      const int row = pass * 4 + (lane >> 4), cl = (lane & 15) * 8;
+      const int n = n0 + r0 + row;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(&slab[row * SLAB_LD + cl]);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(&slab[row * SLAB_LD + cl + 4]);
+      if (r0 + row < h) {
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (r0 + row >= hv) {
+#pragma unroll
+          for (int e2 = 0; e2 < 8; ++e2) v[e2] = 0.f;
+        }
+        store8<bf16_t>(Y + ((size_t)b * N + n) * p.ldy + co_w + cl, v);
+      }
+    }
+    asm volatile("" ::: "memory");
+  }
+}
+
+// fragment-order copy of a packed [3][Cout][Cin] bf16 weight (Cout a multiple of 32): out[chunk][tap][half][block][lane][8] =
+// w[tap][32 block + (lane & 31)][32 chunk + 16 half + 8 (lane >> 5) + 0..7], block < Cout / 32
+__device__ __forceinline__ void frag_major_copy(const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int Cin, int Cout, long i) {
+  const int nblk = Cout >> 5;
+  const int lane = i & 63;
+  const long r1 = i >> 6;
+  const int c = (int)(r1 % nblk);
+  const long r2 = r1 / nblk;
+  const int half = (int)(r2 & 1);
+  const long rest = r2 >> 1;
+  const int tap = (int)(rest % 3), kc = (int)(rest / 3);
+  const bf16_t* src = w + ((size_t)tap * Cout + c * 32 + (lane & 31)) * Cin + kc * 32 + half * 16 + (lane >> 5) * 8;
+  *reinterpret_cast<bf16x8*>(out + i * 8) = *reinterpret_cast<const bf16x8*>(src);
+}
+__global__ void pack_frag_major_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int Cin, int Cout) {
+  const long total = (long)(Cin >> 5) * 3 * 2 * (Cout >> 5) * 64;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) frag_major_copy(w, out, Cin, Cout, i);
+}
 // weight-stationary dispatch: bf16 operands, plain row-major vectorised output, no fused LayerNorm / accumulate
 template <typename TA, typename TC, typename TO, typename TG>
 bool try_weight_stationary(const ConvArgs& a, int B, int taps, hipStream_t s) {
@@ -1111,6 +1694,16 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
     constexpr int LNB = LN == 2 ? 3 : LN;             // backward without FiLM gradients: fewer registers
     const bool film = LN == 2 && a.ln.film != nullptr;
     if constexpr (sizeof(TA) == 2 && sizeof(TC) == 2) {
+      // split-K workgroups on the same balanced tiles, weights in fragment order -- while the batch is ONE round of tiles (B * N <= 256 CUs x
+      // 256 rows): measured 0.35 % of the B = 48 step faster than the ring kernel (frame level 46 vs 50 us, phoneme level 27 vs 33 us),
+      // 2.5 % of the B = 256 step slower (several rounds of 256-row tiles: the ring kernel's two epilogue teams win there)
+      if (a.plan && taps == 3 && a.w_frag && a.Cin >= 256 && a.Cin % 128 == 0 && (long)B * a.N <= 256L * 256) {
+        dim3 gridp((unsigned)a.plan_tiles);
+        if (film) hipLaunchKernelGGL((conv_sk_kernel<LN>), gridp, dim3(SK_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((conv_sk_kernel<LNB>), gridp, dim3(SK_THREADS), 0, s, a);
+        DX_LAUNCH_CHECK();
+        return DX_OK;
+      }
       if (a.plan && taps == 3) {   // balanced 256-row tiles + padding-fill workgroups (dx_conv_tile_plan)
         dim3 gridp((unsigned)a.plan_tiles);
         if (film) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 4, 32, LN, DX_PLAN_RING>), gridp, dim3(2 * NTHREADS), 0, s, a);
@@ -1927,8 +2520,10 @@ static int plan_check(const char* who, const int* plan, int plan_tiles, const in
 extern "C" int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const float* bias,
                             const float* residual, const float* gamma, const float* beta, const float* film, long ldf,
                             const int64_t* lengths, float* y, void* y_lp, float* s_out, float* mean, float* rstd, int B, int N,
-                            int Cin, int taps, float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, void* stream) {
+                            int Cin, int taps, float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, const void* w_frag,
+                            void* stream) {
   DX_REQUIRE(x && w_packed && residual && gamma && beta && y, DX_ERR_ARG, "dx_conv1d_ln: null pointer");
+  DX_REQUIRE(!w_frag || plan, DX_ERR_ARG, "dx_conv1d_ln: fragment-order weights go with a tile plan");
   if (int rc = plan_check("dx_conv1d_ln", plan, plan_tiles, lengths, x_dtype, w_dtype, ldx, Cin, taps, B, N)) return rc;
   DX_REQUIRE(B > 0 && N > 0 && Cin > 0, DX_ERR_SHAPE, "dx_conv1d_ln: empty shape");
   DX_REQUIRE(Cin % 8 == 0 && ldx % 8 == 0, DX_ERR_SHAPE, "dx_conv1d_ln: Cin (%d) and ldx (%ld) must be multiples of 8", Cin, ldx);
@@ -1937,7 +2532,7 @@ extern "C" int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_
   DX_REQUIRE(p_pre >= 0.f && p_pre < 1.f, DX_ERR_ARG, "dx_conv1d_ln: dropout p out of [0,1)");
   ConvArgs a{x, ldx, w_packed, bias, nullptr, BN, nullptr, lengths, lengths, N, Cin, BN, 0, B,
              LNEpi{gamma, beta, residual, film, ldf, y, y_lp, s_out, mean, rstd, p_pre, seed_pre, 1}};
-  a.plan = plan; a.plan_tiles = plan_tiles;
+  a.plan = plan; a.plan_tiles = plan_tiles; a.w_frag = w_frag;
   { static int dbg = getenv("DX_PLAN_DEBUG") ? atoi(getenv("DX_PLAN_DEBUG")) : 0; a.flags |= dbg; }
   hipStream_t s = (hipStream_t)stream;
   if (w_dtype == DX_BF16 && x_dtype == DX_BF16) return launch_taps<bf16_t, bf16_t, float, float, 1>(a, B, taps, s);
@@ -1951,8 +2546,9 @@ extern "C" int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void*
                                const float* s_in, const float* mean, const float* rstd, const float* gamma,
                                const float* beta, const float* film, long ldf, const int64_t* lengths, void* dx_pre_lp,
                                float* dgamma, float* dbeta, float* dfilm, long lddf, int B, int N, int Cin, int taps,
-                               float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, void* stream) {
+                               float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, const void* w_frag, void* stream) {
   if (int rc = plan_check("dx_conv1d_lnbwd", plan, plan_tiles, lengths, x_dtype, w_dtype, ldx, Cin, taps, B, N, true)) return rc;
+  DX_REQUIRE(!w_frag || plan, DX_ERR_ARG, "dx_conv1d_lnbwd: fragment-order weights go with a tile plan");
   DX_REQUIRE(x && w_packed && y_inout && s_in && mean && rstd && gamma && beta && lengths && dx_pre_lp && dgamma && dbeta,
              DX_ERR_ARG, "dx_conv1d_lnbwd: null pointer");
   DX_REQUIRE((film == nullptr) == (dfilm == nullptr), DX_ERR_ARG, "dx_conv1d_lnbwd: film and dfilm come together");
@@ -1963,7 +2559,7 @@ extern "C" int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void*
   ConvArgs a{x, ldx, w_packed, nullptr, y_inout, BN, nullptr, lengths, lengths, N, Cin, BN, 0, B,
              LNEpi{gamma, beta, nullptr, film, ldf, y_inout, dx_pre_lp, const_cast<float*>(s_in), const_cast<float*>(mean),
                    const_cast<float*>(rstd), p_pre, seed_pre, 2, dgamma, dbeta, dfilm, lddf}};
-  a.plan = plan; a.plan_tiles = plan_tiles;
+  a.plan = plan; a.plan_tiles = plan_tiles; a.w_frag = w_frag;
   { static int dbg = getenv("DX_PLAN_DEBUG") ? atoi(getenv("DX_PLAN_DEBUG")) : 0; a.flags |= dbg; }
   hipStream_t s = (hipStream_t)stream;
   if (w_dtype == DX_BF16 && x_dtype == DX_BF16) return launch_taps<bf16_t, bf16_t, float, float, 2>(a, B, taps, s);
@@ -1971,4 +2567,63 @@ extern "C" int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void*
   if (w_dtype == DX_F32 && x_dtype == DX_F32) return launch_taps<float, float, float, float, 2>(a, B, taps, s);
   dx_set_error("dx_conv1d_lnbwd: unsupported dtype combination x=%d w=%d", x_dtype, w_dtype);
   return DX_ERR_DTYPE;
+}
+
+struct FragDesc { const void* src; void* dst; int Cin; int Cout; };
+namespace {
+__global__ void pack_frag_major_batched_kernel(const FragDesc* __restrict__ descs) {
+  const FragDesc d = descs[blockIdx.y];
+  const long total = (long)(d.Cin >> 5) * 3 * 2 * (d.Cout >> 5) * 64;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    frag_major_copy(reinterpret_cast<const bf16_t*>(d.src), reinterpret_cast<bf16_t*>(d.dst), d.Cin, d.Cout, i);
+}
+}  // namespace
+
+#ifdef SK_TIMING
+extern "C" int dx_debug_sk_chunk(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dx_sk_chunk), sizeof(unsigned long long) * 4 * 64 * 8);
+}
+extern "C" int dx_debug_sk_ts(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dx_sk_ts), sizeof(unsigned long long) * 1024 * 8);
+}
+#endif
+extern "C" int dx_frag_desc_size(void) { return (int)sizeof(FragDesc); }
+
+extern "C" int dx_pack_frag_major_batched(const void* descs_dev, int n, long max_elems, void* stream) {
+  DX_REQUIRE(descs_dev && n > 0, DX_ERR_ARG, "dx_pack_frag_major_batched: empty table");
+  DX_REQUIRE(max_elems > 0 && max_elems % 8 == 0, DX_ERR_SHAPE, "dx_pack_frag_major_batched: max_elems=%ld", max_elems);
+  long blocks = (max_elems / 8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_frag_major_batched_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const FragDesc*>(descs_dev));
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_pack_frag_major(const void* w_packed, void* out, int Cin, int Cout, void* stream) {
+  DX_REQUIRE(w_packed && out, DX_ERR_ARG, "dx_pack_frag_major: null pointer");
+  DX_REQUIRE(Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 32 == 0, DX_ERR_SHAPE, "dx_pack_frag_major: Cin=%d, Cout=%d must be multiples of 32", Cin, Cout);
+  const long total = (long)(Cin >> 5) * 3 * 2 * (Cout >> 5) * 64;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_frag_major_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const bf16_t*>(w_packed), reinterpret_cast<bf16_t*>(out), Cin, Cout);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_conv1d_wide(const void* x, long ldx, const void* w_frag, const float* bias, void* y, long ldy, const int64_t* skip_lengths,
+                              int B, int N, int Cin, int Cout, int flags, void* stream) {
+  DX_REQUIRE(x && w_frag && y, DX_ERR_ARG, "dx_conv1d_wide: null pointer");
+  DX_REQUIRE(B > 0 && N > 0, DX_ERR_SHAPE, "dx_conv1d_wide: empty shape");
+  DX_REQUIRE(Cin % 128 == 0 && Cin >= 256 && Cin <= DX_ZERO_PAGE_EL && Cout % 256 == 0 && ldx % 8 == 0 && ldy % 8 == 0, DX_ERR_UNSUPPORTED,
+             "dx_conv1d_wide: Cin %% 128 == 0 (256..4096), Cout %% 256 == 0, row strides multiples of 8 (got Cin=%d Cout=%d)", Cin, Cout);
+  DX_REQUIRE((flags & ~DX_CONV_RELU) == 0, DX_ERR_UNSUPPORTED, "dx_conv1d_wide: only DX_CONV_RELU is supported (flags=%d)", flags);
+  ConvArgs a{x, ldx, nullptr, bias, y, ldy, nullptr, nullptr, skip_lengths, N, Cin, Cout, flags, B, LNEpi{}};
+  a.w_frag = w_frag;
+  const long ptiles = (long)dx_cdiv(N, 256) * B;
+  dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * (Cout / 256)));
+  hipLaunchKernelGGL(conv_wide_kernel, grid, dim3(WD_THREADS), 0, (hipStream_t)stream, a);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
 }

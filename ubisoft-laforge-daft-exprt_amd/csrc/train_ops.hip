@@ -162,17 +162,25 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 }
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                                   float wd, float bc1, float bc2_sqrt, const float* gnorm_sq, float clip) {
+                                                   float wd, float bc1, float bc2_sqrt, const float* gnorm_sq, float clip,
+                                                   float* gnorm_accum) {
+  __shared__ float red[4];
   float coef = 1.f;
   if (gnorm_sq && clip < INFINITY) coef = fminf(1.f, clip / (sqrtf(*gnorm_sq) + 1e-6f));  // clip_grad_norm_
   const float step = lr / bc1;
+  float gsq = 0.f;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
-    const float pi = p[i];
-    const float gi = g[i] * coef + wd * pi;
+    const float pi = p[i], graw = g[i];
+    gsq += graw * graw;
+    const float gi = graw * coef + wd * pi;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi; v[i] = vi;
     p[i] = pi - step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  }
+  if (gnorm_accum) {   // the gradient norm the trainer logs (clip_grad_norm_(inf), train.py:399), summed on the way: no separate pass over g
+    gsq = block_sum_256(gsq, red);
+    if (threadIdx.x == 0) atomicAdd(gnorm_accum, gsq);
   }
 }
 __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long n, float s) {
@@ -326,11 +334,11 @@ extern "C" int dx_sumsq(const float* x, long n, float* out, void* stream) {
 
 extern "C" int dx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                             float eps, float weight_decay, int step, const float* grad_norm_sq, float clip_thresh,
-                            void* stream) {
+                            float* grad_norm_sq_accum, void* stream) {
   DX_REQUIRE(p && g && m && v && n > 0 && step >= 1, DX_ERR_ARG, "dx_adam_step: bad arguments");
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, (float)bc1, (float)sqrt(bc2), grad_norm_sq, clip_thresh);
+                     weight_decay, (float)bc1, (float)sqrt(bc2), grad_norm_sq, clip_thresh, grad_norm_sq_accum);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }

@@ -205,6 +205,7 @@ class DaftExprt(nn.Module):
         self._plan_k1 = bool(int(__import__('os').environ.get('DX_PLAN_K1', '0')))   # balanced tiles also for the k = 1 QKV data gradient + LayerNorm backward (measured: 8.78 vs 8.74 ms)
         self._step_id, self._site, self._rank = 0, 0, 0
         self._trace = None    # tests set this to a list: every stage appends (kind, names, input, film, lengths, output)
+        self._trace_bwd = None   # likewise for the backward pass: (kind, saved, saved_below, gradient in, gradient out)
         self._pos = None
         self.n_params = sum(int(np.prod(s)) for _, s, _ in self._table)
         self._gemm_weights = [n for n, s, _ in self._table if
@@ -292,6 +293,30 @@ class DaftExprt(nn.Module):
                     self._packed['T:' + name] = torch.empty((taps, w.shape[1], w.shape[0]), dtype=self.cd, device=dev)
                     bwd.append((w, self._packed['T:' + name], True))
             self._pack_fwd, self._pack_bwd = ops.pack_table(fwd, dev), ops.pack_table(bwd, dev)
+            # fragment-order copies ('F:' / 'FT:' + name) of the k = 3 weights whose GEMM ends in a 128-channel LayerNorm epilogue
+            # on balanced tiles (second FF conv forward; first FF conv data gradient): the split-K kernel reads them from L2
+            # straight into registers, one contiguous KiB per MFMA fragment
+            self._frag_fwd = self._frag_bwd = None
+            if self.cd == torch.bfloat16:
+                ffwd, fbwd = [], []
+                for name in self._gemm_weights:
+                    w = self._P[name]
+                    if w.dim() != 3 or w.shape[2] != 3:
+                        continue
+                    if w.shape[0] % 256 == 0 and w.shape[1] % 128 == 0 and w.shape[1] >= 256:     # wide GEMMs (pre-net 1024 -> 1024): dx_conv1d_wide
+                        self._packed['F:' + name] = torch.empty(w.numel(), dtype=self.cd, device=dev)
+                        ffwd.append((self._packed[name], self._packed['F:' + name]))
+                        if w.shape[1] % 256 == 0 and w.shape[0] % 128 == 0:
+                            self._packed['FT:' + name] = torch.empty(w.numel(), dtype=self.cd, device=dev)
+                            fbwd.append((self._packed['T:' + name], self._packed['FT:' + name]))
+                    if name.endswith('feed_forward.convs.2.conv.weight') and w.shape[0] == 128 and w.shape[1] % 32 == 0 and w.shape[1] >= 256:
+                        self._packed['F:' + name] = torch.empty(w.numel(), dtype=self.cd, device=dev)
+                        ffwd.append((self._packed[name], self._packed['F:' + name]))
+                    if name.endswith('feed_forward.convs.0.conv.weight') and w.shape[1] == 128 and w.shape[0] % 32 == 0 and w.shape[0] >= 256:
+                        self._packed['FT:' + name] = torch.empty(w.numel(), dtype=self.cd, device=dev)
+                        fbwd.append((self._packed['T:' + name], self._packed['FT:' + name]))
+                self._frag_fwd = ops.frag_table(ffwd, dev) if ffwd else None
+                self._frag_bwd = ops.frag_table(fbwd, dev) if fbwd else None
             self._packed_version = self._dgrad_version = -1
         try:
             version = (self._param_version, tuple(self._params[n]._version for n in self._gemm_weights))
@@ -300,10 +325,14 @@ class DaftExprt(nn.Module):
             self._packed_version = -1 if self._packed_version == version else self._packed_version   # always re-pack
         if self._packed_version != version or self.always_repack:
             ops.pack_weights_batched(*self._pack_fwd, self.cd)
+            if self._frag_fwd is not None:
+                ops.pack_frag_major_batched(*self._frag_fwd)
             self._packed_version = version
             self._dgrad_version = -1
         if need_dgrad and self._dgrad_version != self._packed_version:
             ops.pack_weights_batched(*self._pack_bwd, self.cd)
+            if self._frag_bwd is not None:
+                ops.pack_frag_major_batched(*self._frag_bwd)
             self._dgrad_version = self._packed_version
         return self._packed
 
@@ -414,7 +443,8 @@ class DaftExprt(nn.Module):
         # second FF conv + Dropout + residual + LayerNorm + FiLM + mask in ONE launch
         u, u_lp, s2, mean2, rstd2 = ops.conv1d_ln(h, W[f'{f_pre}.convs.2.conv.weight'], P[f'{f_pre}.convs.2.conv.bias'], a,
                                                   P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'], lengths, film=film,
-                                                  save=save, p_pre=p_conv, seed_pre=seeds[2], lp_copy=lp, plan=self._plan(lengths, x.shape[1]))
+                                                  save=save, p_pre=p_conv, seed_pre=seeds[2], lp_copy=lp, plan=self._plan(lengths, x.shape[1]),
+                                                  w_frag=W.get(f'F:{f_pre}.convs.2.conv.weight'))
         if save:
             s.pre, s.cfg, s.x, s.film, s.lengths = pre, cfg, xin, film, lengths
             s.qkv, s.o, s.lse, s.s1, s.mean1, s.rstd1, s.a, s.h, s.s2, s.mean2, s.rstd2 = qkv, o, lse, s1, mean1, rstd1, ain, h, s2, mean2, rstd2
@@ -428,7 +458,8 @@ class DaftExprt(nn.Module):
         P = self._P
         cout = P[f'{conv_name}.conv.weight'].shape[0]
         c_dtype = torch.float32 if (self.cd == torch.float32 or cout == 128) else self.cd   # wide tensors in the MFMA operand type
-        c = ops.conv1d(x, W[f'{conv_name}.conv.weight'], P[f'{conv_name}.conv.bias'], relu=True, out_dtype=c_dtype, skip_lengths=skip)
+        c = ops.conv1d(x, W[f'{conv_name}.conv.weight'], P[f'{conv_name}.conv.bias'], relu=True, out_dtype=c_dtype, skip_lengths=skip,
+                       w_frag=W.get(f'F:{conv_name}.conv.weight'))
         seed = self._seed()
         y, _, mean, rstd = ops.layernorm_fwd(c, P[f'{ln_name}.weight'], P[f'{ln_name}.bias'], film=film, lengths=lengths,
                                              out_dtype=out_dtype, save=save, p_post=p_drop, seed_post=seed, skip_lengths=skip)
@@ -636,6 +667,7 @@ class DaftExprt(nn.Module):
                                         separate=True)   # dz is read by the side-stream wgrad while `da` is accumulated in place
         else:
             ds2, dz = pre                                # done in the epilogue of the block above's QKV data gradient
+        cap_in = ds2.clone() if self._trace_bwd is not None else None   # dL/d(s2 of this block): the residual gradient is updated in place below
         da = ds2
         self._wgrad(dz, s.h, G[f'{f_pre}.convs.2.conv.weight'], G[f'{f_pre}.convs.2.conv.bias'], s.lengths)
         dh = ops.conv1d(dz, W[f'T:{f_pre}.convs.2.conv.weight'], None, out_dtype=cd, relu_gate=s.h, skip_lengths=s.lengths)
@@ -644,7 +676,7 @@ class DaftExprt(nn.Module):
             dproj = ops.conv1d_lnbwd(dh, W[f'T:{f_pre}.convs.0.conv.weight'], da, s.s1, s.mean1, s.rstd1,
                                      P[f'{a_pre}.layer_norm.weight'], P[f'{a_pre}.layer_norm.bias'], s.lengths,
                                      G[f'{a_pre}.layer_norm.weight'], G[f'{a_pre}.layer_norm.bias'], p_pre=s.p_attn, seed_pre=s.seeds[1],
-                                     plan=self._plan(s.lengths, dh.shape[1]))
+                                     plan=self._plan(s.lengths, dh.shape[1]), w_frag=W.get(f'FT:{f_pre}.convs.0.conv.weight'))
             ds1 = da
         else:
             ops.conv1d(dh, W[f'T:{f_pre}.convs.0.conv.weight'], None, out=da, accumulate=True, skip_lengths=s.lengths)
@@ -665,9 +697,13 @@ class DaftExprt(nn.Module):
                                         p_pre=below.p_conv, seed_pre=below.seeds[2],
                                         plan=self._plan(below.lengths, dqkv.shape[1]) if self._plan_k1 else None)
             self._block_done()
+            if self._trace_bwd is not None:              # dx = dL/d(s2 of the block below): its LayerNorm backward ran in the launch above
+                self._trace_bwd.append(('fft_block', s, below, cap_in, dx.clone()))
             return dx, (dx, dz_below)
         ops.conv1d(dqkv, W[f'T:{mha}.in_proj_weight'], None, out=dx, accumulate=True, skip_lengths=s.lengths)
         self._block_done()
+        if self._trace_bwd is not None:                  # dx = dL/d(block input)
+            self._trace_bwd.append(('fft_block', s, None, cap_in, dx.clone()))
         return dx, None
 
     def _conv_ln_bwd(self, W, s, dy, dfilm=None, need_dx=True, dx_out=None, lengths_hint=None):
@@ -681,12 +717,20 @@ class DaftExprt(nn.Module):
         if not need_dx:   # last op of the backward pass: nothing left on the main stream to overlap with, and the side stream
             # still has the previous (large) weight gradient queued -- launch here
             ops.conv1d_wgrad(dc, s.x, G[f'{s.conv_name}.conv.weight'], G[f'{s.conv_name}.conv.bias'], self.cd, lengths_hint)
+            if self._trace_bwd is not None:
+                self._trace_bwd.append(('conv_ln', s, None, dy.clone(), None))     # no data gradient: the input needs none
             return None
         self._wgrad(dc, s.x, G[f'{s.conv_name}.conv.weight'], G[f'{s.conv_name}.conv.bias'], lengths_hint)
         self._flush_wgrads()
         if dx_out is not None:
+            if self._trace_bwd is not None:
+                self._trace_bwd.append(('conv_ln', s, None, dy.clone(), None))     # the data gradient is accumulated into dx_out: not separable
             return ops.conv1d(dc, W[f'T:{s.conv_name}.conv.weight'], None, out=dx_out, accumulate=True, skip_lengths=s.skip)
-        return ops.conv1d(dc, W[f'T:{s.conv_name}.conv.weight'], None, out_dtype=s.x.dtype, skip_lengths=s.skip)
+        dx = ops.conv1d(dc, W[f'T:{s.conv_name}.conv.weight'], None, out_dtype=s.x.dtype, skip_lengths=s.skip,
+                        w_frag=W.get(f'FT:{s.conv_name}.conv.weight'))
+        if self._trace_bwd is not None:
+            self._trace_bwd.append(('conv_ln', s, None, dy.clone(), dx.clone()))
+        return dx
 
     def _backward(self, S, d_spk, d_dur, d_energy, d_pitch, d_mel, d_mel_is_bt=False, section_done=None):
         ''' hand-written backward pass: accumulates every parameter gradient into the flat gradient buffer.

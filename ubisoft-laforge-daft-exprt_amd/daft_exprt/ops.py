@@ -74,15 +74,27 @@ def pack_conv_weight(w, dtype, transpose_flip=False, out=None):
     return out
 
 
+USE_WIDE = bool(int(os.environ.get('DX_CONV_WIDE', '1')))   # 0: the 1024 -> 1024 k = 3 GEMMs stay on conv_gemm_kernel (A/B switch)
+
+
 def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, mask_lengths=None,
-           transposed_out=False, out=None, accumulate=False, skip_lengths=None):
-    ''' x (B, N, Cin) [last dim contiguous]; w_packed (taps, Cout, Cin) -> (B, N, Cout) or (B, Cout, N) '''
+           transposed_out=False, out=None, accumulate=False, skip_lengths=None, w_frag=None):
+    ''' x (B, N, Cin) [last dim contiguous]; w_packed (taps, Cout, Cin) -> (B, N, Cout) or (B, Cout, N).
+        w_frag: the same weights in fragment order (pack_frag_major): the wide k = 3 GEMMs (bf16 in / out, Cin % 128 == 0,
+        Cout % 256 == 0, nothing but bias / ReLU in the epilogue) then run on dx_conv1d_wide '''
     H.require_gpu(x, w_packed)
     B, N, Cin = x.shape
     taps, Cout, Cin_w = w_packed.shape
     assert Cin_w == Cin, (Cin_w, Cin)
     assert x.stride(2) == 1 and (B == 1 or x.stride(0) == N * x.stride(1))
     out_dtype = out_dtype or x.dtype
+    if (w_frag is not None and USE_WIDE and taps == 3 and x.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and out is None
+            and relu_gate is None and mask_lengths is None and not transposed_out and Cin % 128 == 0 and Cin >= 256 and Cout % 256 == 0):
+        y = torch.empty((B, N, Cout), dtype=torch.bfloat16, device=x.device)
+        with _probe('conv_gemm', lambda: 2. * B * N * Cin * Cout * taps, N):
+            H.check(H.lib().dx_conv1d_wide(H.ptr(x), x.stride(1), H.ptr(w_frag), H.ptr(bias), H.ptr(y), y.stride(1), H.ptr(skip_lengths),
+                                           B, N, Cin, Cout, H.CONV_RELU if relu else 0, H.stream()))
+        return y
     if out is None:
         assert not accumulate
         out = torch.empty((B, Cout, N) if transposed_out else (B, N, Cout), dtype=out_dtype, device=x.device)
@@ -95,9 +107,11 @@ def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, m
     return out
 
 
-def conv1d_ln(x, w_packed, bias, residual, gamma, beta, lengths, film=None, save=False, p_pre=0., seed_pre=0, lp_copy=False, plan=None):
+def conv1d_ln(x, w_packed, bias, residual, gamma, beta, lengths, film=None, save=False, p_pre=0., seed_pre=0, lp_copy=False, plan=None,
+              w_frag=None):
     ''' conv / linear to 128 channels with the following LayerNorm (+dropout, residual, FiLM, mask) fused into the epilogue.
-        plan: conv_tile_plan(lengths, N) of this batch (bf16 k = 3 GEMMs only).  Returns (y, y_lp, s_out, mean, rstd) '''
+        plan: conv_tile_plan(lengths, N) of this batch (bf16 k = 3 GEMMs only); w_frag: the weights in fragment order
+        (pack_frag_major) -> split-K workgroups on the plan's tiles.  Returns (y, y_lp, s_out, mean, rstd) '''
     B, N, Cin = x.shape
     taps, Cout, _ = w_packed.shape
     assert Cout == 128 and x.stride(2) == 1 and residual.is_contiguous()
@@ -111,12 +125,12 @@ def conv1d_ln(x, w_packed, bias, residual, gamma, beta, lengths, film=None, save
         H.check(H.lib().dx_conv1d_ln(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(bias), H.ptr(residual),
                                      H.ptr(gamma), H.ptr(beta), H.ptr(film), film.stride(0) if film is not None else 0, H.ptr(lengths),
                                      H.ptr(y), H.ptr(y_lp), H.ptr(s_out), H.ptr(mean), H.ptr(rstd), B, N, Cin, taps, float(p_pre),
-                                     int(seed_pre), *_plan_args(plan, x, w_packed, B, N), H.stream()))
+                                     int(seed_pre), *_plan_args(plan, x, w_packed, B, N, w_frag=w_frag), H.stream()))
     return y, y_lp, s_out, mean, rstd
 
 
 def conv1d_lnbwd(x, w_packed, y_inout, s_in, mean, rstd, gamma, beta, lengths, dgamma, dbeta, film=None, dfilm=None,
-                 p_pre=0., seed_pre=0, plan=None):
+                 p_pre=0., seed_pre=0, plan=None, w_frag=None):
     ''' data gradient of a conv / linear into a 128-channel residual stream + the backward of the LayerNorm that consumed
         that stream, one launch (see dx_conv1d_lnbwd).  y_inout (B, N, 128) fp32: residual gradient in, ds out (in place).
         Returns the bf16 dropout_pre(ds).  dgamma / dbeta / dfilm accumulate. '''
@@ -130,7 +144,7 @@ def conv1d_lnbwd(x, w_packed, y_inout, s_in, mean, rstd, gamma, beta, lengths, d
         H.check(H.lib().dx_conv1d_lnbwd(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(y_inout), H.ptr(s_in),
                                         H.ptr(mean), H.ptr(rstd), H.ptr(gamma), H.ptr(beta), H.ptr(film), ldf, H.ptr(lengths),
                                         H.ptr(dx_lp), H.ptr(dgamma), H.ptr(dbeta), H.ptr(dfilm), lddf, B, N, Cin, taps,
-                                        float(p_pre), int(seed_pre), *_plan_args(plan, x, w_packed, B, N, k1_ok=True), H.stream()))
+                                        float(p_pre), int(seed_pre), *_plan_args(plan, x, w_packed, B, N, k1_ok=True, w_frag=w_frag), H.stream()))
     return dx_lp
 
 
@@ -144,15 +158,47 @@ def conv_tile_plan(lengths, N):
     return table, B, N
 
 
-def _plan_args(plan, x, w_packed, B, N, k1_ok=False):
-    ''' (table pointer, n_tiles) when the plan applies to this GEMM (bf16 operands, k = 3, same batch geometry) '''
+def _plan_args(plan, x, w_packed, B, N, k1_ok=False, w_frag=None):
+    ''' (table pointer, n_tiles, fragment-order weights) when the plan applies to this GEMM (bf16 operands, k = 3, same batch
+        geometry); the fragment-order copy only goes with a plan, k = 3 and Cin >= 256 '''
     taps = w_packed.shape[0]
     if plan is None or x.dtype != torch.bfloat16 or w_packed.dtype != torch.bfloat16 or x.shape[2] % 32 or \
             not (taps == 3 or (taps == 1 and k1_ok and x.shape[2] >= 256)):
-        return None, 0
+        return None, 0, None
     table, pb, pn = plan
     assert (pb, pn) == (B, N), 'tile plan built for another batch geometry'
-    return H.ptr(table), table.shape[0]
+    frag = None
+    if w_frag is not None and taps == 3 and x.shape[2] >= 256 and USE_SPLITK:
+        assert w_frag.dtype == torch.bfloat16 and w_frag.numel() == w_packed.numel()
+        frag = H.ptr(w_frag)
+    return H.ptr(table), table.shape[0], frag
+
+
+USE_SPLITK = bool(int(os.environ.get('DX_CONV_SPLITK', '1')))   # 0: the LayerNorm-fused k = 3 GEMMs stay on the ring kernel (A/B switch)
+
+
+def pack_frag_major(w_packed, out=None):
+    ''' fragment-order copy of a packed [3][Cout][Cin] bf16 weight (dx_pack_frag_major) '''
+    taps, cout, cin = w_packed.shape
+    assert taps == 3 and cout % 32 == 0 and cin % 32 == 0 and w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous()
+    out = torch.empty(w_packed.numel(), dtype=torch.bfloat16, device=w_packed.device) if out is None else out
+    H.check(H.lib().dx_pack_frag_major(H.ptr(w_packed), H.ptr(out), cin, cout, H.stream()))
+    return out
+
+
+def frag_table(pairs, device):
+    ''' device table for pack_frag_major_batched: pairs = [(w_packed [3][Cout][Cin], out)] '''
+    import struct
+    rec = H.lib().dx_frag_desc_size()
+    buf = bytearray(rec * len(pairs))
+    for i, (w, out) in enumerate(pairs):
+        struct.pack_into('<QQii', buf, i * rec, w.data_ptr(), out.data_ptr(), w.shape[2], w.shape[1])
+    table = torch.frombuffer(buf, dtype=torch.uint8).clone().to(device)
+    return table, len(pairs), max(w.numel() for w, _ in pairs)
+
+
+def pack_frag_major_batched(table, n, max_elems):
+    H.check(H.lib().dx_pack_frag_major_batched(H.ptr(table), n, max_elems, H.stream()))
 
 
 def pack_table(entries, device):
@@ -506,9 +552,10 @@ def sumsq(x, out=None):
     return out
 
 
-def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, grad_norm_sq=None, clip_thresh=_INF):
+def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, grad_norm_sq=None, clip_thresh=_INF, norm_accum=None):
     H.check(H.lib().dx_adam_step(H.ptr(p), H.ptr(g), H.ptr(m), H.ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
-                                 float(eps), float(weight_decay), int(step), H.ptr(grad_norm_sq), float(clip_thresh), H.stream()))
+                                 float(eps), float(weight_decay), int(step), H.ptr(grad_norm_sq), float(clip_thresh),
+                                 H.ptr(norm_accum), H.stream()))
 
 
 def scale_(x, s):

@@ -29,9 +29,34 @@ class FusedAdam(object):
         g = self.param_groups[0]
         self.step_count += 1
         flat, gflat = self.model.flat_parameters(), self.model.flat_gradients()
-        ops.sumsq(gflat, self.grad_norm_sq)
-        ops.adam_step(flat, gflat, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'], g['eps'], g['weight_decay'],
-                      self.step_count, self.grad_norm_sq, self.grad_clip_thresh)
+        if self.grad_clip_thresh == float('inf'):   # the norm is only logged (train.py:399): summed inside the Adam launch, no pass of its own
+            ops.H.check(ops.H.lib().dx_fill_zero(ops.H.ptr(self.grad_norm_sq), 4, ops.H.stream()))
+            ops.adam_step(flat, gflat, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'], g['eps'], g['weight_decay'],
+                          self.step_count, None, self.grad_clip_thresh, norm_accum=self.grad_norm_sq)
+        else:
+            ops.sumsq(gflat, self.grad_norm_sq)
+            ops.adam_step(flat, gflat, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'], g['eps'], g['weight_decay'],
+                          self.step_count, self.grad_norm_sq, self.grad_clip_thresh)
+        self.model.mark_updated()
+        return self.grad_norm_sq
+
+    # ---- per-section form: the Adam update of a gradient bucket runs as soon as that bucket is final (behind its all-reduce), on the
+    # stream the caller chose, while the backward pass of the other modules is still running.  Only with an infinite clipping
+    # threshold (the reference's setting, train.py:399: the norm is logged, never applied) -- a finite one needs the whole norm first.
+    def sectioned(self):
+        return self.grad_clip_thresh == float('inf')
+
+    def begin_step(self):
+        self.step_count += 1
+        ops.H.check(ops.H.lib().dx_fill_zero(ops.H.ptr(self.grad_norm_sq), 4, ops.H.stream()))
+
+    def step_slice(self, off, n):
+        g = self.param_groups[0]
+        flat, gflat = self.model.flat_parameters(), self.model.flat_gradients()
+        ops.adam_step(flat[off: off + n], gflat[off: off + n], self.exp_avg[off: off + n], self.exp_avg_sq[off: off + n], g['lr'],
+                      g['betas'], g['eps'], g['weight_decay'], self.step_count, None, float('inf'), norm_accum=self.grad_norm_sq)
+
+    def end_step(self):
         self.model.mark_updated()
         return self.grad_norm_sq
 

@@ -49,12 +49,23 @@ class GradReducer(object):
             self.model.mark_updated()
 
     def section_done(self, name):
-        ''' backward hook: launch the all-reduce of the bucket closed by this section '''
-        if self.world == 1 or name not in self._ready_after:
-            return
+        ''' backward hook: launch the all-reduce of the bucket closed by this section.  Returns (offset, numel, work) of that bucket
+            (work None on one rank) or None when the section only joins a later bucket. '''
+        if name not in self._ready_after:
+            return None
         off, n = self._ready_after[name]
+        if self.world == 1:
+            return off, n, None
         g = self.model.flat_gradients()[off: off + n]
-        self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append(work)
+        return off, n, work
+
+    def describe(self):
+        ''' one line for the rank-0 log: world size, backend and the bucket sizes in backward order '''
+        backend = dist.get_backend(self.group) if dist.is_initialized() else 'none'
+        sizes = ', '.join(f'{sec} {n * 4 / 1e6:.1f} MB' for sec, _, n in self.buckets)
+        return f'gradient all-reduce: world {self.world}, backend {backend}, {len(self.buckets)} buckets in backward order: {sizes}'
 
     def wait(self):
         for w in self._works:

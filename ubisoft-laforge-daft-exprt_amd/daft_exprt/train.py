@@ -8,11 +8,13 @@ Keeps the reference trainer's surface (`src/daft_exprt/train.py`): `update_learn
 Step loop = `train.py:368-401, 475-494` with the device work restructured for MI355X:
   * `model.forward_backward` (forward + fused 7-term loss + hand-written backward, no autograd graph);
   * gradient all-reduce over RCCL/xGMI overlapped with backward, once per optimizer step (`parallel.GradReducer`);
-  * one fused Adam kernel over the flat parameter buffer, `clip_grad_norm_` folded in (`optim.FusedAdam`);
-  * loss terms / gradient norm stay on the device and are fetched once per logged step (the reference does
-    8 `.item()` syncs per micro-batch, `loss.py:102-104`, `train.py:382`);
-  * the NaN check that guards logging is made rank-consistent (the reference's rank-local check can deadlock
-    its barrier).
+  * fused Adam over the flat parameter buffer, bucket by bucket behind each bucket's all-reduce on an optimizer stream, the
+    logged gradient norm summed on the way (`optim.FusedAdam`, `Trainer`);
+  * loss terms / gradient norm stay on the device; the scalars of iteration i reach the host (pinned copy on a side stream)
+    after iteration i + 1 has been enqueued, so logging every iteration like the reference (`train.py:404-423`; it does
+    8 `.item()` syncs per micro-batch, `loss.py:102-104`, `train.py:382`) costs no device idle time;
+  * no per-iteration `dist.barrier()` (the reference's only paces log output, and its rank-local NaN test in front of it can
+    deadlock): the gradient all-reduce keeps the ranks in step; validation and checkpoints keep their barriers.
 Validation scoring and the best-model checkpoint (`train.py:427-456`) are kept; validation figures and the
 benchmark-sentence synthesis (MFA, librosa, Griffin-Lim) are outside the accelerated path.
 """
@@ -89,17 +91,47 @@ def load_checkpoint(checkpoint_path, gpu, model, optimizer, hparams):
 
 
 class Trainer(object):
-    ''' the device-side body of one optimizer step (`train.py:368-401`) for one rank '''
+    ''' the device-side body of one optimizer step (`train.py:368-401`) for one rank.
+
+        The optimizer works per gradient BUCKET (the contiguous slices of `parallel.GradReducer`, in backward order): as soon as the
+        backward pass reports a bucket final -- and, with several ranks, its RCCL all-reduce has finished -- the Adam update of
+        that slice runs on a third stream (`_opt_stream`) under the rest of the backward pass; only the last bucket's update
+        (the prosody encoder's pre-net, 15 MB) is left after the last backward kernel.  This needs the reference's infinite
+        clipping threshold (`train.py:399` logs the norm, never applies it); with a finite one the whole-buffer step runs after
+        the backward pass as before (also the default on one GPU, see `sectioned`). '''
     def __init__(self, model, hparams, world_size=1):
         self.model, self.hp, self.world = model, hparams, world_size
         self.criterion = DaftExprtLoss(0, hparams)
         self.optimizer = FusedAdam(model, betas=hparams.betas, eps=hparams.epsilon, weight_decay=hparams.weight_decay,
                                    grad_clip_thresh=hparams.grad_clip_thresh)
-        self.reducer = GradReducer(model) if world_size > 1 else None
-        if self.reducer is not None:
+        self.reducer = GradReducer(model)     # also on one rank: its bucket table drives the per-section optimizer
+        if world_size > 1:
             self.reducer.broadcast_parameters()
         model.always_repack = False   # parameters only change through self.optimizer
         self.terms = None
+        # per-bucket Adam behind each bucket's all-reduce: default on with several ranks (it hides the optimizer pass and the wait for
+        # the last all-reduce); on ONE GPU the slice updates only compete with the backward kernels for HBM (measured 8.29 vs 8.08 ms
+        # per step), so the whole-buffer step (one launch, gradient norm summed on the way) stays the default there
+        mode = os.environ.get('DX_SECTIONED_ADAM', 'auto')
+        self.sectioned = (world_size > 1) if mode == 'auto' else bool(int(mode))
+        self._opt_stream = self._sec_event = None
+        self._done = set()
+
+    def _section_done(self, name):
+        ''' backward hook (runs with the weight-gradient side stream current, after it has caught up with the compute stream):
+            all-reduce of the bucket this section closes, then its Adam update behind the collective on the optimizer stream '''
+        hit = self.reducer.section_done(name)
+        if hit is None or not self._sectioned_now:
+            return
+        off, n, work = hit
+        cur = torch.cuda.current_stream()
+        self._sec_event.record(cur)
+        with torch.cuda.stream(self._opt_stream):
+            self._opt_stream.wait_event(self._sec_event)      # the bucket's gradients are final on the stream that reported them
+            if work is not None:
+                work.wait()                                    # stream-ordered: the optimizer stream waits for the collective
+            self.optimizer.step_slice(off, n)
+        self._done.add(name)
 
     def step(self, micro_batches, iteration):
         ''' micro_batches: list of (inputs, targets) already on the device (len = accumulation_steps).
@@ -110,14 +142,27 @@ class Trainer(object):
         self.optimizer.param_groups[0]['lr'] = lr
         weights = self.criterion.weights(iteration)
         scale = 1. / (accum * self.world)   # loss / accumulation_steps (train.py:379) and the DDP mean over ranks
+        self._sectioned_now = self.sectioned and self.optimizer.sectioned()
+        if self._sectioned_now:
+            if self._opt_stream is None:
+                self._opt_stream, self._sec_event = torch.cuda.Stream(device=model.flat_parameters().device), torch.cuda.Event()
+            self.optimizer.begin_step()     # step count, zeroed norm accumulator: on the compute stream, ahead of every slice update
+            self._done = set()
         total = None
         for k, (inputs, targets) in enumerate(micro_batches):
-            hook = self.reducer.section_done if (self.reducer is not None and k == accum - 1) else None
+            last = k == accum - 1
+            hook = self._section_done if (last and (self.world > 1 or self._sectioned_now)) else None
             terms = model.forward_backward(inputs, targets, weights, grad_scale=scale, section_done=hook)
             total = terms if total is None else total + terms
-        if self.reducer is not None:
+        main = torch.cuda.current_stream()
+        if self._sectioned_now:
+            assert self._done == set(sec for sec, _, _ in self.reducer.buckets), 'a gradient bucket was never reported'
+            main.wait_stream(self._opt_stream)      # every slice update (and with it every all-reduce) is behind us
+            self.reducer._works = []
+            gnorm_sq = self.optimizer.end_step()
+        else:
             self.reducer.wait()
-        gnorm_sq = self.optimizer.step()
+            gnorm_sq = self.optimizer.step()
         model.zero_grad()
         self.terms = total / accum
         return self.terms, gnorm_sq
@@ -153,8 +198,10 @@ def _loaders(hparams, rank, world, distributed):
     ds = SyntheticUtterances(hparams, n_items, seed=hparams.seed, force_first_full=False)
     idx = list(range(rank, n_items, world))   # DistributedSampler(shuffle=False) striding (data_loader.py:232)
     subset = torch.utils.data.Subset(ds, idx)
+    workers = int(getattr(hparams, 'synthetic_workers', 16))   # an utterance costs ~2 ms of numpy (100 ms per batch of 48): 16 processes feed an 8 ms step
     return torch.utils.data.DataLoader(subset, batch_size=hparams.batch_size, shuffle=False, drop_last=True, collate_fn=collate,
-                                       num_workers=0), None
+                                       num_workers=workers, pin_memory=True, persistent_workers=workers > 0,
+                                       prefetch_factor=4 if workers > 0 else None), None
 
 
 def train(gpu, hparams, log_file):
@@ -164,6 +211,7 @@ def train(gpu, hparams, log_file):
     distributed = bool(getattr(hparams, 'multiprocessing_distributed', False))
     if distributed:
         hparams.rank = hparams.rank * hparams.ngpus_per_node + gpu
+        os.environ.setdefault('NCCL_DEBUG', 'VERSION')     # RCCL prints its version banner once: the log shows which library ran
         dist.init_process_group(backend=hparams.dist_backend, init_method=hparams.dist_url, world_size=hparams.world_size,
                                 rank=hparams.rank)
     world = dist.get_world_size() if distributed else 1
@@ -178,6 +226,7 @@ def train(gpu, hparams, log_file):
     model.set_rank(rank)                      # per-rank dropout streams
     model.train()
     trainer = Trainer(model, hparams, world)
+    _logger.info(trainer.reducer.describe())   # rank 0: world size, backend and the bucket sizes (proof of the RCCL world in a log)
     criterion = trainer.criterion
     iteration, best_val_loss = 1, float('inf')
     if hparams.checkpoint != '':
@@ -190,33 +239,85 @@ def train(gpu, hparams, log_file):
     start, total_time = time.time(), 0.
     model.zero_grad()
     micro = []
-    while iteration <= hparams.nb_iterations:
+    # Per-iteration reporting (`train.py:404-423`) WITHOUT stalling the device: the 9 scalars of iteration i (7 loss terms, total,
+    # gradient norm) are copied to pinned memory on a side stream behind step i, and read by the host after step i + 1 has been
+    # enqueued -- the device always has the next step queued while the host formats the log line of the previous one.  The
+    # reference's per-iteration `dist.barrier()` (it only paces the ranks' log output) and the round-1 NaN all-reduce are gone:
+    # nothing in the step depends on them, and the gradient all-reduce already keeps the ranks in lockstep.
+    stats_host = torch.empty(9, dtype=torch.float32).pin_memory()
+    log_stream, stats_ready, step_done = torch.cuda.Stream(device=gpu), torch.cuda.Event(), torch.cuda.Event()
+    pending = None        # (iteration, lr, valid frames) of the step whose scalars are in flight
+
+    def report(now):
+        ''' log the pending iteration; returns False when its loss was NaN (the reference then logs nothing, train.py:404) '''
+        nonlocal pending, total_time, start
+        if pending is None:
+            return True
+        it_p, lr_p, frames_p = pending
+        pending = None
+        stats_ready.synchronize()            # waits for the END OF THE PREVIOUS step only
+        values = stats_host.tolist()
+        tot_loss, grad_norm = values[7], values[8]
+        if not math.isfinite(tot_loss):
+            return False
+        if rank == 0:
+            duration = now - start
+            total_time += duration
+            _logger.info(f'Train loss [{it_p}]: {tot_loss:.6f} Grad Norm {grad_norm:.6f} {duration:.2f}s/it (LR {lr_p:.6f})')
+            with open(metrics_path, 'a') as f:   # scalar names of DaftExprtLogger.log_training (logger.py:26-32)
+                rec = {'iteration': it_p, 'DaftExprt.optimization/grad_norm': grad_norm,
+                       'DaftExprt.optimization/learning_rate': lr_p, 'DaftExprt.optimization/duration': duration,
+                       'DaftExprt.training/loss': tot_loss, 'valid_frames': frames_p}
+                rec.update({f'DaftExprt.training/{k}': v for k, v in zip(KEYS, values[:7])})
+                f.write(json.dumps(rec) + '\n')
+        start = now
+        return True
+
+    copy_stream = torch.cuda.Stream(device=gpu)
+
+    def device_batches():
+        ''' the loader's batches one ahead of the step that consumes them: the H2D copies of batch i + 1 (15.8 MB at B = 48) run on
+            a copy stream under step i instead of in front of step i + 1 on the compute stream '''
+        ahead = None
         for batch in loader:
-            inputs, targets, _ = model.parse_batch(gpu, batch)
-            micro.append((inputs, targets))
+            frames = int(batch[9].sum())     # host tensor (collate output): no device round trip
+            with torch.cuda.stream(copy_stream):
+                inputs, targets, _ = model.parse_batch(gpu, batch)
+                ready = torch.cuda.Event()
+                ready.record(copy_stream)
+            if ahead is not None:
+                yield ahead
+            ahead = (inputs, targets, frames, ready)
+        if ahead is not None:
+            yield ahead
+
+    while iteration <= hparams.nb_iterations:
+        for inputs, targets, frames, ready in device_batches():
+            main = torch.cuda.current_stream()
+            main.wait_event(ready)
+            for t in inputs:
+                t.record_stream(main)        # allocated on the copy stream, consumed on the compute stream
+            micro.append((inputs, targets, frames))
             if len(micro) < hparams.accumulation_steps:
                 continue
-            terms, gnorm_sq = trainer.step(micro, iteration)
+            terms, gnorm_sq = trainer.step([(i, t) for i, t, _ in micro], iteration)
+            frames = sum(f for _, _, f in micro)
             micro = []
-            values = torch.cat((terms, gnorm_sq.sqrt())).tolist()   # one D2H copy per optimizer step
-            tot_loss, grad_norm = values[7], values[8]
             lr = trainer.optimizer.param_groups[0]['lr']
-            nan = torch.tensor([0. if math.isfinite(tot_loss) else 1.], device=f'cuda:{gpu}')
-            if distributed:
-                dist.all_reduce(nan)   # rank-consistent NaN decision (see module docstring)
-            if float(nan) == 0.:
-                if rank == 0:
-                    duration = time.time() - start
-                    total_time += duration
-                    _logger.info(f'Train loss [{iteration}]: {tot_loss:.6f} Grad Norm {grad_norm:.6f} {duration:.2f}s/it (LR {lr:.6f})')
-                    with open(metrics_path, 'a') as f:   # scalar names of DaftExprtLogger.log_training (logger.py:26-32)
-                        rec = {'iteration': iteration, 'DaftExprt.optimization/grad_norm': grad_norm,
-                               'DaftExprt.optimization/learning_rate': lr, 'DaftExprt.optimization/duration': duration,
-                               'DaftExprt.training/loss': tot_loss}
-                        rec.update({f'DaftExprt.training/{k}': v for k, v in zip(KEYS, values[:7])})
-                        f.write(json.dumps(rec) + '\n')
-                if distributed:
-                    dist.barrier()
+            report(time.time())              # the PREVIOUS iteration's scalars (this one is already queued on the device)
+            stats_dev = torch.cat((terms, gnorm_sq.sqrt()))
+            step_done.record()
+            with torch.cuda.stream(log_stream):
+                log_stream.wait_event(step_done)
+                stats_host.copy_(stats_dev, non_blocking=True)
+                stats_ready.record(log_stream)
+            stats_dev.record_stream(log_stream)
+            pending = (iteration, lr, frames)
+            periodic = (val_loader is not None and iteration % hparams.iters_check_for_model_improvement == 0) or \
+                iteration % hparams.iters_per_checkpoint == 0 or iteration >= hparams.nb_iterations
+            if periodic:
+                torch.cuda.synchronize()
+                report(time.time())          # validation / checkpoint / end of training: catch up first
             # ---- model evaluation (`train.py:427-456`): every rank scores the whole validation set, rank 0 keeps the best
             if val_loader is not None and iteration % hparams.iters_check_for_model_improvement == 0:
                 _logger.info('Validating....')
@@ -245,7 +346,8 @@ def train(gpu, hparams, log_file):
                 if distributed:
                     dist.barrier()
             iteration += 1
-            start = time.time()
+            if periodic:
+                start = time.time()          # validation / checkpoint time is not an iteration's duration (train.py:486)
             if iteration > hparams.nb_iterations:
                 break
     if distributed:
