@@ -102,10 +102,11 @@ int dx_pack_frag_major_batched(const void* descs_dev, int n, long max_elems, voi
  * data gradient): bf16 x (B, N, Cin) and y (B, N, Cout), weights in fragment order, Cin % 128 == 0, Cout % 256 == 0, flags = 0 or
  * DX_CONV_RELU, bias fp32 or NULL.  256 rows x 256 channels per 4-wave workgroup (one wave per SIMD, 128 x 128 per wave = 256
  * accumulator registers), activation tile through an LDS-DMA ring, weight fragments from L2 into registers one chunk ahead:
- * 0.25 KB of LDS traffic per MFMA and half the L2 -> CU bytes of 256 x 128 tiles.  Rows n >= skip_lengths[b] + 2 are written as zeros
- * (they never reach a valid output); skip_lengths may be NULL. */
-int dx_conv1d_wide(const void* x, long ldx, const void* w_frag, const float* bias, void* y, long ldy, const int64_t* skip_lengths,
-                   int B, int N, int Cin, int Cout, int flags, void* stream);
+ * 0.25 KB of LDS traffic per MFMA and half the L2 -> CU bytes of 256 x 128 tiles.  Position tiles: `plan` = dx_conv_tile_plan(lengths,
+ * ..., n_tiles, table, halo) with ANY n_tiles >= B * ceil(N / 256) -- a multiple of 64 (256 CUs / 4 channel tiles of a 1024-channel output)
+ * fills the chip in whole rounds; rows n >= lengths[b] + halo never reach a valid output and are written as zeros. */
+int dx_conv1d_wide(const void* x, long ldx, const void* w_frag, const float* bias, void* y, long ldy, const int64_t* lengths,
+                   const int* plan, int plan_tiles, int halo, int B, int N, int Cin, int Cout, int flags, void* stream);
 
 /* Balanced position tiles for dx_conv1d_ln / dx_conv1d_lnbwd (optional `plan`; bf16 operands, Cin % 32 == 0, taps = 3 --
  * dx_conv1d_lnbwd also taps = 1).
@@ -118,7 +119,8 @@ int dx_conv1d_wide(const void* x, long ldx, const void* w_frag, const float* bia
  * device memory, valid for every GEMM over the same lengths (one plan per batch).  Results are identical to the
  * unplanned call: same rows, same summation order per output; rows >= lengths[b] are written as zeros. */
 int dx_conv_tile_plan_size(int B, int N);
-int dx_conv_tile_plan(const int64_t* lengths, int B, int N, int n_tiles, int* table, void* stream);
+int dx_conv_tile_plan(const int64_t* lengths, int B, int N, int n_tiles, int* table, int halo /* rows past the length that still
+                      carry work: 0 for the LayerNorm-fused GEMMs (masked), 2 for the pre-net convs of dx_conv1d_wide */, void* stream);
 
 /* Pack an fp32 (Cout, Cin, taps) PyTorch conv / (Cout, Cin) linear weight for dx_conv1d.
  *   transpose_flip = 0: out[tap][co][ci] = w[co][ci][tap]                (forward operand)

@@ -157,3 +157,37 @@ def test_conv_weights_in_registers_kernel(shape, taps):
             ref = ref * (~dead)
         tol = (1e-2 if od == torch.bfloat16 else 1e-4) * scale    # operands are pre-rounded: only the output rounding remains
         assert float((y - ref).abs().max()) <= tol, (shape, taps, c, float((y - ref).abs().max()), tol)
+
+
+@pytest.mark.parametrize('relu', [True, False])
+@pytest.mark.parametrize('lens_list,N', [([700, 433, 257, 256, 130, 5], 700), ([1000, 31, 0, 640], 1000), ([40, 17], 40)])
+def test_wide_gemm_kernel_matches_tiled_kernel_and_fp32_reference(relu, lens_list, N):
+    ''' dx_conv1d_wide (256 x 256 tiles on the full register file, fragment-order weights from L2 into registers) against
+        dx_conv1d's tiled kernel on the same bf16 operands -- fp32 sums in another order: equal within bf16 output rounding -- and
+        against torch fp32 on the bf16-rounded operands; rows past length + 2 are zeros; bit-reproducible '''
+    from daft_exprt import ops
+    g = torch.Generator().manual_seed(N + 7 * len(lens_list))
+    B, cin, cout = len(lens_list), 1024, 1024
+    lens = torch.tensor(lens_list).to(DEV)
+    n_idx = torch.arange(N, device=DEV)[None, :, None]
+    x = (torch.randn(B, N, cin, generator=g).to(DEV) * (n_idx < lens[:, None, None] + 2)).to(torch.bfloat16)
+    w = (torch.randn(cout, cin, 3, generator=g) / (cin * 3) ** 0.5).to(DEV)
+    bias = torch.randn(cout, generator=g).to(DEV) if relu else None
+    wp = ops.pack_conv_weight(w, torch.bfloat16)
+    wf = ops.pack_frag_major(wp)
+    tiled = ops.conv1d(x, wp, bias, out_dtype=torch.bfloat16, relu=relu, skip_lengths=lens).float()
+    plan = ops.conv_tile_plan(lens, N, halo=2, round_to=64)
+    wide = ops.conv1d(x, wp, bias, out_dtype=torch.bfloat16, relu=relu, skip_lengths=lens, w_frag=wf, wide_plan=plan)
+    again = ops.conv1d(x, wp, bias, out_dtype=torch.bfloat16, relu=relu, skip_lengths=lens, w_frag=wf, wide_plan=plan)
+    assert wide.dtype == torch.bfloat16 and torch.equal(wide, again)
+    wide = wide.float()
+    live = n_idx < lens[:, None, None] + 2
+    assert float((wide * ~live).abs().max()) == 0.
+    ref = torch.nn.functional.conv1d(x.float().transpose(1, 2), w.to(torch.bfloat16).float(), bias, padding=1).transpose(1, 2)
+    if relu:
+        ref = torch.relu(ref)
+    scale = float(ref.abs().max())
+    assert float(((wide - ref) * live).abs().max()) <= 1e-2 * scale           # bf16 output rounding of values up to `scale`
+    assert float(((wide - ref) * live).abs().mean()) <= 2e-3 * float((ref * live).abs().mean() + 1e-9)
+    valid = n_idx < lens[:, None, None]
+    assert float(((wide - tiled) * valid).abs().max()) <= 1e-2 * scale

@@ -72,8 +72,10 @@ def _same(p_a, p_b, st_a, st_b, gn_a, gn_b):
     moved = ((p_a - p_b).abs() > 1e-5).float().mean()
     assert float(moved) < 0.2, float(moved)      # measured 3-4 % between two identical runs; a misordered stream gives ~100 %
     m_a, m_b = st_a[: st_a.numel() // 2], st_b[: st_b.numel() // 2]
-    assert float((m_a - m_b).abs().max()) <= 1e-4 * float(m_a.abs().max())
-    assert abs(gn_a - gn_b) <= 1e-4 * abs(gn_b)
+    # second step: the parameters the noisy elements moved to feed back into the gradients (measured 0.6 % of the largest first moment)
+    assert float((m_a - m_b).abs().max()) <= 5e-2 * float(m_a.abs().max())
+    assert float((m_a - m_b).abs().mean()) <= 2e-2 * float(m_a.abs().mean())     # a sign flip is 200 %
+    assert abs(gn_a - gn_b) <= 1e-2 * abs(gn_b)
 
 
 @pytest.mark.parametrize('sectioned', [True, False])

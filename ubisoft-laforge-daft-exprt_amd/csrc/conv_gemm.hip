@@ -1479,26 +1479,15 @@ __global__ __launch_bounds__(WD_THREADS, 1) void conv_wide_kernel(ConvArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 1, wc = wave & 1;
   const int N = p.N, Cin = p.Cin, Cout = p.Cout;
-  // XCD-aware, weight-stationary order (see conv_gemm_kernel): an XCD walks all of its position tiles for channel tile 0, then 1, ..
-  const int ptiles = dx_cdiv(N, BMW);
-  const int Lid = blockIdx.x, jj = Lid >> 3;
-  const int per_xcd = (ptiles * p.B + 7) >> 3;
-  const int pt = (Lid & 7) + 8 * (jj % per_xcd);
-  if (pt >= ptiles * p.B) return;
-  const int n0 = (pt % ptiles) * BMW, b = pt / ptiles, ct = jj / per_xcd;
+  // position tiles of the batch from dx_conv_tile_plan (rows < length + halo of every utterance, cut into equal pieces of <= 256 rows such
+  // that the tile count is a multiple of 64 = 256 CUs / 4 channel tiles); channel tile slowest: consecutive workgroups (one per XCD in
+  // turn) share a channel tile, so an XCD's L2 holds one 1.5 MB weight slice at a time
+  const int pt = blockIdx.x % p.plan_tiles, ct = blockIdx.x / p.plan_tiles;
+  const int4 e = reinterpret_cast<const int4*>(p.plan)[pt];
+  const int b = e.x, n0 = e.y, h = e.z, fill_per = e.w;
   const int co_w = ct * 256 + wc * 128;                              // first channel of this wave
   TC* Y = reinterpret_cast<TC*>(p.y);
-  const int h = N - n0 < BMW ? N - n0 : BMW;                         // rows of this tile inside the tensor
-  const int lim = p.skip_len ? (int)p.skip_len[b] + 2 : N;           // rows >= lim never reach a valid output: zeros
-  if (n0 >= lim) {                                                   // padding early-out
-    const bf16x8 z = zero8<TC>();
-    for (int c = tid; c < h * 32; c += WD_THREADS) {
-      const int n = n0 + (c >> 5), co = ct * 256 + (c & 31) * 8;
-      *reinterpret_cast<bf16x8*>(Y + ((size_t)b * N + n) * p.ldy + co) = z;
-    }
-    return;
-  }
-  const int hv = lim - n0 < h ? lim - n0 : h;                        // rows that carry work
+  if (h > 0) {
   f32x16 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1508,7 +1497,7 @@ __global__ __launch_bounds__(WD_THREADS, 1) void conv_wide_kernel(ConvArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
   const TC* X = reinterpret_cast<const TC*>(p.x) + (size_t)b * N * p.ldx;
   const int nk = Cin >> 5;
-  const int nA = (hv + TAPS - 1 + 15) >> 4;
+  const int nA = (h + TAPS - 1 + 15) >> 4;
   const int mine = __builtin_amdgcn_readfirstlane(nA > wave ? (nA - wave + 3) >> 2 : 0);
   const TC* src[WD_MAXP];
   unsigned dst[WD_MAXP];
@@ -1519,7 +1508,7 @@ __global__ __launch_bounds__(WD_THREADS, 1) void conv_wide_kernel(ConvArgs p) {
     const int c = (lane & 3) ^ ((r >> 2) & 3);
     const int n = n0 + r - HALO;
     const TC* sp = reinterpret_cast<const TC*>(dx_zero_page) + c * 8;
-    if (q < nA && r < hv + TAPS - 1 && n >= 0 && n < N) sp = X + (long)n * p.ldx + c * 8;
+    if (q < nA && r < h + TAPS - 1 && n >= 0 && n < N) sp = X + (long)n * p.ldx + c * 8;
     src[t] = sp;
     dst[t] = (unsigned)(q * 512 * 2);
   }
@@ -1540,7 +1529,9 @@ __global__ __launch_bounds__(WD_THREADS, 1) void conv_wide_kernel(ConvArgs p) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) d[c] = *reinterpret_cast<const frag_t*>(base + c * 512);
   };
-  const int nblk_w = __builtin_amdgcn_readfirstlane(hv > wr * 128 ? ((hv - wr * 128 + 31) >> 5 > 4 ? 4 : (hv - wr * 128 + 31) >> 5) : 0);   // live row blocks of this wave
+  // 32-row blocks interleaved over the two wave rows (block 2 i + wr is wave row wr's i-th), so that a tile of any height splits evenly
+  const int nblk = (h + 31) >> 5;
+  const int nact = __builtin_amdgcn_readfirstlane((nblk - wr + 1) >> 1);
   const bool counted = nk >= 8;
 #pragma unroll
   for (int st = 0; st < WD_S - 1; ++st)
@@ -1561,7 +1552,7 @@ __global__ __launch_bounds__(WD_THREADS, 1) void conv_wide_kernel(ConvArgs p) {
     frag_t a[2][NA > 0 ? NA : 1];
     if constexpr (NA > 0) {
 #pragma unroll
-      for (int i = 0; i < NA; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(&Ar[lds_at(wr * 128 + i * 32 + l31, g)]);
+      for (int i = 0; i < NA; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(&Ar[lds_at((2 * i + wr) * 32 + l31, g)]);
     }
 #pragma unroll
     for (int ks6 = 0; ks6 < 6; ++ks6) {
@@ -1569,7 +1560,7 @@ __global__ __launch_bounds__(WD_THREADS, 1) void conv_wide_kernel(ConvArgs p) {
         if (ks6 + 1 < 6) {                           // the next k-step's activation fragments are requested before this one's MFMAs
           const int tn = (ks6 + 1) >> 1, kn = (ks6 + 1) & 1;
 #pragma unroll
-          for (int i = 0; i < NA; ++i) a[(ks6 + 1) & 1][i] = *reinterpret_cast<const frag_t*>(&Ar[lds_at(wr * 128 + i * 32 + l31 + tn, kn * 2 + g)]);
+          for (int i = 0; i < NA; ++i) a[(ks6 + 1) & 1][i] = *reinterpret_cast<const frag_t*>(&Ar[lds_at((2 * i + wr) * 32 + l31 + tn, kn * 2 + g)]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1584,9 +1575,10 @@ __global__ __launch_bounds__(WD_THREADS, 1) void conv_wide_kernel(ConvArgs p) {
   auto mainloop = [&](auto na_tag) {
     for (int it = 0; it < nk; ++it) chunk(it, na_tag);
   };
-  if (nblk_w > 2) mainloop(std::integral_constant<int, 4>{});
-  else if (nblk_w == 2) mainloop(std::integral_constant<int, 2>{});
-  else if (nblk_w == 1) mainloop(std::integral_constant<int, 1>{});
+  if (nact >= 4) mainloop(std::integral_constant<int, 4>{});
+  else if (nact == 3) mainloop(std::integral_constant<int, 3>{});
+  else if (nact == 2) mainloop(std::integral_constant<int, 2>{});
+  else if (nact == 1) mainloop(std::integral_constant<int, 1>{});
   else mainloop(std::integral_constant<int, 0>{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                   // the ring is dead: every wave stages its slabs through its own region
@@ -1598,7 +1590,7 @@ __global__ __launch_bounds__(WD_THREADS, 1) void conv_wide_kernel(ConvArgs p) {
   for (int c = 0; c < 4; ++c) bv[c] = p.bias ? p.bias[co_w + c * 32 + l31] : 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r0 = wr * 128 + i * 32;                // first tile row of this 32-row block
+    const int r0 = (2 * i + wr) * 32;                // first tile row of this 32-row block
     if (r0 >= h) break;                              // wave-uniform; the staging region is wave-private: no workgroup barrier
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -1612,19 +1604,44 @@ __global__ __launch_bounds__(WD_THREADS, 1) void conv_wide_kernel(ConvArgs p) {
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {           // 16 lanes x 16 bytes = one 256-byte row segment per store instruction
       const int row = pass * 4 + (lane >> 4), cl = (lane & 15) * 8;
-      const int n = n0 + r0 + row;
       const f32x4 lo = *reinterpret_cast<const f32x4*>(&slab[row * SLAB_LD + cl]);
       const f32x4 hi = *reinterpret_cast<const f32x4*>(&slab[row * SLAB_LD + cl + 4]);
       if (r0 + row < h) {
-        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        if (r0 + row >= hv) {
-#pragma unroll
-          for (int e2 = 0; e2 < 8; ++e2) v[e2] = 0.f;
-        }
-        store8<bf16_t>(Y + ((size_t)b * N + n) * p.ldy + co_w + cl, v);
+        const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        store8<bf16_t>(Y + ((size_t)b * N + n0 + r0 + row) * p.ldy + co_w + cl, v);
       }
     }
     asm volatile("" ::: "memory");
+  }
+  }
+  // ---- padding fill (rows past length + halo of every utterance: zeros), an equal share of the flattened padding rows per position tile,
+  // this channel tile's 256 columns of them (see conv_sk_kernel)
+  {
+    const long lo = (long)pt * fill_per, hi = lo + fill_per;
+    const int halo = p.flags >> 8;
+    long carry = 0;
+    for (int base = 0; base < p.B && carry < hi; base += 64) {
+      const int ub = base + lane;
+      int ulen = ub < p.B ? (int)p.skip_len[ub] : N;
+      ulen = ulen > 0 ? ulen + halo : 0;
+      const int dead = ub < p.B ? N - (ulen > N ? N : ulen) : 0;
+      int incl = dead;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+      const long ustart = carry + incl - dead, uend = carry + incl;
+      const long fs = ustart > lo ? ustart : lo, fe = uend < hi ? uend : hi;
+      unsigned long long todo = __ballot(fs < fe);
+      while (todo) {
+        const int src_lane = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int fb = base + src_lane;
+        const int first = __shfl(N - dead + (int)(fs - ustart), src_lane, 64), cntr = __shfl((int)(fe - fs), src_lane, 64);
+        const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c = tid; c < cntr * 32; c += WD_THREADS)
+          store8<bf16_t>(Y + ((size_t)fb * N + first + (c >> 5)) * p.ldy + ct * 256 + (c & 31) * 8, z);
+      }
+      carry += __shfl(incl, 63, 64);
+    }
   }
 }
 
@@ -2448,10 +2465,10 @@ extern "C" int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const vo
 // every utterance into equal pieces of at most DX_PLAN_ROWS rows such that the batch is exactly n_tiles (a multiple of
 // the 256 CUs) pieces and the tallest piece is as short as possible.
 constexpr int DX_PLAN_ROWS = 256, DX_NUM_CU = 256;
-__global__ __launch_bounds__(64) void conv_plan_kernel(const int64_t* __restrict__ lens, int B, int N, int T, int4* __restrict__ table) {
+__global__ __launch_bounds__(64) void conv_plan_kernel(const int64_t* __restrict__ lens, int B, int N, int T, int4* __restrict__ table, int halo) {
   __shared__ int first[4096 + 1];
   const int lane = threadIdx.x;
-  auto len_of = [&](int b) { const int l = (int)lens[b]; return l < 0 ? 0 : (l > N ? N : l); };
+  auto len_of = [&](int b) { const int l = (int)lens[b] + (lens[b] > 0 ? halo : 0); return l < 0 ? 0 : (l > N ? N : l); };
   auto tiles_at = [&](int H) {
     int c = 0;
     for (int b = lane; b < B; b += 64) c += (len_of(b) + H - 1) / H;
@@ -2495,12 +2512,12 @@ extern "C" int dx_conv_tile_plan_size(int B, int N) {
   return (int)((worst + DX_NUM_CU - 1) / DX_NUM_CU * DX_NUM_CU);
 }
 
-extern "C" int dx_conv_tile_plan(const int64_t* lengths, int B, int N, int n_tiles, int* table, void* stream) {
+extern "C" int dx_conv_tile_plan(const int64_t* lengths, int B, int N, int n_tiles, int* table, int halo, void* stream) {
   DX_REQUIRE(lengths && table, DX_ERR_ARG, "dx_conv_tile_plan: null pointer");
-  DX_REQUIRE(B > 0 && B <= 4096 && N > 0, DX_ERR_SHAPE, "dx_conv_tile_plan: B=%d (1..4096), N=%d", B, N);
-  DX_REQUIRE(n_tiles >= dx_conv_tile_plan_size(B, N), DX_ERR_ARG, "dx_conv_tile_plan: n_tiles=%d < dx_conv_tile_plan_size=%d", n_tiles,
-             dx_conv_tile_plan_size(B, N));
-  hipLaunchKernelGGL(conv_plan_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lengths, B, N, n_tiles, reinterpret_cast<int4*>(table));
+  DX_REQUIRE(B > 0 && B <= 4096 && N > 0 && halo >= 0 && halo <= 8, DX_ERR_SHAPE, "dx_conv_tile_plan: B=%d (1..4096), N=%d, halo=%d (0..8)", B, N, halo);
+  DX_REQUIRE(n_tiles >= B * dx_cdiv(N, DX_PLAN_ROWS), DX_ERR_ARG, "dx_conv_tile_plan: n_tiles=%d < B * ceil(N / 256) = %d", n_tiles,
+             B * dx_cdiv(N, DX_PLAN_ROWS));
+  hipLaunchKernelGGL(conv_plan_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lengths, B, N, n_tiles, reinterpret_cast<int4*>(table), halo);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
@@ -2612,17 +2629,17 @@ extern "C" int dx_pack_frag_major(const void* w_packed, void* out, int Cin, int 
   return DX_OK;
 }
 
-extern "C" int dx_conv1d_wide(const void* x, long ldx, const void* w_frag, const float* bias, void* y, long ldy, const int64_t* skip_lengths,
-                              int B, int N, int Cin, int Cout, int flags, void* stream) {
-  DX_REQUIRE(x && w_frag && y, DX_ERR_ARG, "dx_conv1d_wide: null pointer");
+extern "C" int dx_conv1d_wide(const void* x, long ldx, const void* w_frag, const float* bias, void* y, long ldy, const int64_t* lengths,
+                              const int* plan, int plan_tiles, int halo, int B, int N, int Cin, int Cout, int flags, void* stream) {
+  DX_REQUIRE(x && w_frag && y && lengths && plan, DX_ERR_ARG, "dx_conv1d_wide: null pointer");
   DX_REQUIRE(B > 0 && N > 0, DX_ERR_SHAPE, "dx_conv1d_wide: empty shape");
   DX_REQUIRE(Cin % 128 == 0 && Cin >= 256 && Cin <= DX_ZERO_PAGE_EL && Cout % 256 == 0 && ldx % 8 == 0 && ldy % 8 == 0, DX_ERR_UNSUPPORTED,
              "dx_conv1d_wide: Cin %% 128 == 0 (256..4096), Cout %% 256 == 0, row strides multiples of 8 (got Cin=%d Cout=%d)", Cin, Cout);
-  DX_REQUIRE((flags & ~DX_CONV_RELU) == 0, DX_ERR_UNSUPPORTED, "dx_conv1d_wide: only DX_CONV_RELU is supported (flags=%d)", flags);
-  ConvArgs a{x, ldx, nullptr, bias, y, ldy, nullptr, nullptr, skip_lengths, N, Cin, Cout, flags, B, LNEpi{}};
-  a.w_frag = w_frag;
-  const long ptiles = (long)dx_cdiv(N, 256) * B;
-  dim3 grid((unsigned)(((ptiles + 7) / 8) * 8 * (Cout / 256)));
+  DX_REQUIRE((flags & ~DX_CONV_RELU) == 0 && halo >= 0 && halo <= 8, DX_ERR_UNSUPPORTED, "dx_conv1d_wide: only DX_CONV_RELU is supported (flags=%d), halo 0..8", flags);
+  DX_REQUIRE(plan_tiles >= B * dx_cdiv(N, DX_PLAN_ROWS), DX_ERR_ARG, "dx_conv1d_wide: plan_tiles=%d < B * ceil(N / 256)", plan_tiles);
+  ConvArgs a{x, ldx, nullptr, bias, y, ldy, nullptr, nullptr, lengths, N, Cin, Cout, flags | (halo << 8), B, LNEpi{}};
+  a.w_frag = w_frag; a.plan = plan; a.plan_tiles = plan_tiles;
+  dim3 grid((unsigned)(plan_tiles * (Cout / 256)));
   hipLaunchKernelGGL(conv_wide_kernel, grid, dim3(WD_THREADS), 0, (hipStream_t)stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;

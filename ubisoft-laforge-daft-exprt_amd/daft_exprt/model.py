@@ -348,6 +348,16 @@ class DaftExprt(nn.Module):
             hit = self._plans[key] = (lengths, ops.conv_tile_plan(lengths, N))
         return hit[1]
 
+    def _plan_wide(self, lengths, N):
+        ''' balanced tiles for the wide pre-net GEMMs (`dx_conv1d_wide`): rows < length + 2, tile count a multiple of 64 '''
+        if self.cd != torch.bfloat16 or lengths is None:
+            return None
+        key = ('wide', lengths.data_ptr(), N)
+        hit = self._plans.get(key)
+        if hit is None or hit[0] is not lengths:
+            hit = self._plans[key] = (lengths, ops.conv_tile_plan(lengths, N, halo=2, round_to=64))
+        return hit[1]
+
     def _order(self, lengths):
         ''' longest-first launch order of the attention kernels (`ops.length_order`), one per distinct lengths tensor per step '''
         if not self.attn_lpt or lengths.shape[0] < 2:
@@ -459,7 +469,7 @@ class DaftExprt(nn.Module):
         cout = P[f'{conv_name}.conv.weight'].shape[0]
         c_dtype = torch.float32 if (self.cd == torch.float32 or cout == 128) else self.cd   # wide tensors in the MFMA operand type
         c = ops.conv1d(x, W[f'{conv_name}.conv.weight'], P[f'{conv_name}.conv.bias'], relu=True, out_dtype=c_dtype, skip_lengths=skip,
-                       w_frag=W.get(f'F:{conv_name}.conv.weight'))
+                       w_frag=W.get(f'F:{conv_name}.conv.weight'), wide_plan=self._plan_wide(skip, x.shape[1]) if f'F:{conv_name}.conv.weight' in W else None)
         seed = self._seed()
         y, _, mean, rstd = ops.layernorm_fwd(c, P[f'{ln_name}.weight'], P[f'{ln_name}.bias'], film=film, lengths=lengths,
                                              out_dtype=out_dtype, save=save, p_post=p_drop, seed_post=seed, skip_lengths=skip)
@@ -727,7 +737,8 @@ class DaftExprt(nn.Module):
                 self._trace_bwd.append(('conv_ln', s, None, dy.clone(), None))     # the data gradient is accumulated into dx_out: not separable
             return ops.conv1d(dc, W[f'T:{s.conv_name}.conv.weight'], None, out=dx_out, accumulate=True, skip_lengths=s.skip)
         dx = ops.conv1d(dc, W[f'T:{s.conv_name}.conv.weight'], None, out_dtype=s.x.dtype, skip_lengths=s.skip,
-                        w_frag=W.get(f'FT:{s.conv_name}.conv.weight'))
+                        w_frag=W.get(f'FT:{s.conv_name}.conv.weight'),
+                        wide_plan=self._plan_wide(s.skip, dc.shape[1]) if f'FT:{s.conv_name}.conv.weight' in W else None)
         if self._trace_bwd is not None:
             self._trace_bwd.append(('conv_ln', s, None, dy.clone(), dx.clone()))
         return dx
@@ -739,7 +750,14 @@ class DaftExprt(nn.Module):
             registration order (frame_decoder first) -- the data-parallel reducer launches that slice's all-reduce. '''
         use_side = bool(int(__import__('os').environ.get('DX_WGRAD_SIDE_STREAM', '1')))
         if use_side and self._side is None:
-            self._side = torch.cuda.Stream(device=S.enc_out.device)
+            # DX_WGRAD_PRIO: stream priority of the weight-gradient stream (default: the runtime's default; 'low' = the lowest the device
+            # offers, so that the dispatcher prefers the data-gradient chain whenever both streams have workgroups waiting)
+            prio = __import__('os').environ.get('DX_WGRAD_PRIO', '')
+            if prio == 'low':
+                lo, _hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, 'priority_range') else (0, 0)
+                self._side = torch.cuda.Stream(device=S.enc_out.device, priority=lo)
+            else:
+                self._side = torch.cuda.Stream(device=S.enc_out.device)
             self._hop = torch.cuda.Event()
         self._side_stream = self._side if use_side else None
 

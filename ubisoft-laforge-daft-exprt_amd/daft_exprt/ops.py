@@ -78,9 +78,10 @@ USE_WIDE = bool(int(os.environ.get('DX_CONV_WIDE', '1')))   # 0: the 1024 -> 102
 
 
 def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, mask_lengths=None,
-           transposed_out=False, out=None, accumulate=False, skip_lengths=None, w_frag=None):
+           transposed_out=False, out=None, accumulate=False, skip_lengths=None, w_frag=None, wide_plan=None):
     ''' x (B, N, Cin) [last dim contiguous]; w_packed (taps, Cout, Cin) -> (B, N, Cout) or (B, Cout, N).
-        w_frag: the same weights in fragment order (pack_frag_major): the wide k = 3 GEMMs (bf16 in / out, Cin % 128 == 0,
+        w_frag + wide_plan: the same weights in fragment order (pack_frag_major) and the balanced tiles of the batch
+        (conv_tile_plan(skip_lengths, N, halo=2, round_to=64)): the wide k = 3 GEMMs (bf16 in / out, Cin % 128 == 0,
         Cout % 256 == 0, nothing but bias / ReLU in the epilogue) then run on dx_conv1d_wide '''
     H.require_gpu(x, w_packed)
     B, N, Cin = x.shape
@@ -88,12 +89,15 @@ def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, m
     assert Cin_w == Cin, (Cin_w, Cin)
     assert x.stride(2) == 1 and (B == 1 or x.stride(0) == N * x.stride(1))
     out_dtype = out_dtype or x.dtype
-    if (w_frag is not None and USE_WIDE and taps == 3 and x.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and out is None
-            and relu_gate is None and mask_lengths is None and not transposed_out and Cin % 128 == 0 and Cin >= 256 and Cout % 256 == 0):
+    if (w_frag is not None and wide_plan is not None and USE_WIDE and taps == 3 and x.dtype == torch.bfloat16 and out_dtype == torch.bfloat16
+            and out is None and relu_gate is None and mask_lengths is None and skip_lengths is not None and not transposed_out
+            and Cin % 128 == 0 and Cin >= 256 and Cout % 256 == 0):
+        table, pb, pn = wide_plan
+        assert (pb, pn) == (B, N), 'tile plan built for another batch geometry'
         y = torch.empty((B, N, Cout), dtype=torch.bfloat16, device=x.device)
         with _probe('conv_gemm', lambda: 2. * B * N * Cin * Cout * taps, N):
             H.check(H.lib().dx_conv1d_wide(H.ptr(x), x.stride(1), H.ptr(w_frag), H.ptr(bias), H.ptr(y), y.stride(1), H.ptr(skip_lengths),
-                                           B, N, Cin, Cout, H.CONV_RELU if relu else 0, H.stream()))
+                                           H.ptr(table), table.shape[0], 2, B, N, Cin, Cout, H.CONV_RELU if relu else 0, H.stream()))
         return y
     if out is None:
         assert not accumulate
@@ -148,13 +152,19 @@ def conv1d_lnbwd(x, w_packed, y_inout, s_in, mean, rstd, gamma, beta, lengths, d
     return dx_lp
 
 
-def conv_tile_plan(lengths, N):
-    ''' balanced position tiles of one batch for the LayerNorm-fused k = 3 GEMMs (dx_conv_tile_plan): build once per batch,
-        pass as plan= to conv1d_ln / conv1d_lnbwd.  Returns (int32 table (n_tiles, 4) on the device, B, N) '''
+def conv_tile_plan(lengths, N, halo=0, round_to=None):
+    ''' balanced position tiles of one batch (dx_conv_tile_plan): build once per batch, pass as plan= to conv1d_ln / conv1d_lnbwd
+        (halo 0: rows past the length are masked) or to the wide GEMMs of conv1d (halo 2: the pre-net convs compute two rows past
+        the length; round_to 64: their 4 channel tiles x 64 position tiles fill the 256 CUs in whole rounds).
+        Returns (int32 table (n_tiles, 4) on the device, B, N) '''
     B = lengths.shape[0]
-    n = H.lib().dx_conv_tile_plan_size(B, N)
+    if round_to is None:
+        n = H.lib().dx_conv_tile_plan_size(B, N)
+    else:
+        worst = B * ((N + 255) // 256)
+        n = (worst + round_to - 1) // round_to * round_to
     table = torch.empty((n, 4), dtype=torch.int32, device=lengths.device)
-    H.check(H.lib().dx_conv_tile_plan(H.ptr(lengths), B, N, n, H.ptr(table), H.stream()))
+    H.check(H.lib().dx_conv_tile_plan(H.ptr(lengths), B, N, n, H.ptr(table), int(halo), H.stream()))
     return table, B, N
 
 
