@@ -1623,7 +1623,7 @@ __global__ __launch_bounds__(WD_THREADS, 1) void conv_wide_kernel(ConvArgs p) {
     for (int base = 0; base < p.B && carry < hi; base += 64) {
       const int ub = base + lane;
       int ulen = ub < p.B ? (int)p.skip_len[ub] : N;
-      ulen = ulen > 0 ? ulen + halo : 0;
+      ulen = (ulen < 0 ? 0 : ulen) + halo;
       const int dead = ub < p.B ? N - (ulen > N ? N : ulen) : 0;
       int incl = dead;
 #pragma unroll
@@ -2468,7 +2468,7 @@ constexpr int DX_PLAN_ROWS = 256, DX_NUM_CU = 256;
 __global__ __launch_bounds__(64) void conv_plan_kernel(const int64_t* __restrict__ lens, int B, int N, int T, int4* __restrict__ table, int halo) {
   __shared__ int first[4096 + 1];
   const int lane = threadIdx.x;
-  auto len_of = [&](int b) { const int l = (int)lens[b] + (lens[b] > 0 ? halo : 0); return l < 0 ? 0 : (l > N ? N : l); };
+  auto len_of = [&](int b) { const int l0 = (int)lens[b], l = (l0 < 0 ? 0 : l0) + halo; return l > N ? N : l; };   // rows that carry work
   auto tiles_at = [&](int H) {
     int c = 0;
     for (int b = lane; b < B; b += 64) c += (len_of(b) + H - 1) / H;
