@@ -11,7 +11,7 @@
 Per kernel (template instance): launches, average duration, FETCH_SIZE bytes (raw and with the gfx950 x2 correction for wide
 coalesced reads, MI355X_MICROARCH.md "HBM"), WRITE_SIZE bytes, and MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8 XCDs)
 * 256 CUs * 4 SIMDs) (the gfx94x `MfmaUtil` formula; the counter counts cycles in which a SIMD's matrix pipe is busy).
-`families` groups the kernels the way bench.py's roofline does (conv_gemm = conv_gemm_kernel + conv_wreg_kernel; conv_wgrad = the weight-gradient kernels) and averages per launch, weighted by launches."""
+`families` groups the kernels the way bench.py's roofline does (conv_gemm = conv_gemm_kernel + conv_wreg_kernel + conv_sk_kernel + conv_wide_kernel; conv_wgrad = the weight-gradient kernels) and averages per launch, weighted by launches."""
 import argparse
 import glob
 import json
@@ -22,7 +22,7 @@ from collections import defaultdict
 
 N_SIMD = 256 * 4
 N_XCD = 8       # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (a 72 us kernel at 2.4 GHz reads 1.38 M), SQ_* summed over all SIMDs
-FAMILIES = {'conv_gemm': ('conv_gemm_kernel', 'conv_wreg_kernel'), 'conv_wgrad': ('conv_wgrad', 'wgrad_reduce'),
+FAMILIES = {'conv_gemm': ('conv_gemm_kernel', 'conv_wreg_kernel', 'conv_sk_kernel', 'conv_wide_kernel'), 'conv_wgrad': ('conv_wgrad', 'wgrad_reduce'),
             'attention': ('attn_',), 'layernorm': ('ln_fwd_kernel', 'ln_bwd_kernel')}
 
 
@@ -56,6 +56,25 @@ def read_db(path):
     return out
 
 
+def families_of(kernels):
+    ''' per-launch averages of each kernel family, weighted by launches '''
+    fams = {}
+    for fam, keys in FAMILIES.items():
+        members = {k: r for k, r in kernels.items() if any(s in k for s in keys)}
+        n = sum(r['launches'] for r in members.values())
+        if not n:
+            continue
+        agg = {'launches': n, 'kernels': sorted(members)}
+        for field in ('fetch_x2_bytes', 'write_bytes', 'avg_us'):
+            if all(field in r for r in members.values()):
+                agg[field] = sum(r[field] * r['launches'] for r in members.values()) / n
+        if all('SQ_VALU_MFMA_BUSY_CYCLES' in r and r.get('GRBM_GUI_ACTIVE') for r in members.values()):
+            agg['mfma_util'] = sum(r['SQ_VALU_MFMA_BUSY_CYCLES'] * r['launches'] for r in members.values()) / \
+                (sum(r['GRBM_GUI_ACTIVE'] * r['launches'] for r in members.values()) / N_XCD * N_SIMD)
+        fams[fam] = agg
+    return fams
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('runs', nargs='+', help='rocprofv3 output directories (or .db files), one per --pmc pass')
@@ -83,20 +102,7 @@ def main():
             rec['write_bytes'] = rec.pop('WRITE_SIZE') * 1024.
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in rec and rec.get('GRBM_GUI_ACTIVE'):
             rec['mfma_util'] = rec['SQ_VALU_MFMA_BUSY_CYCLES'] / (rec['GRBM_GUI_ACTIVE'] / N_XCD * N_SIMD)
-    fams = {}
-    for fam, keys in FAMILIES.items():
-        members = {k: r for k, r in kernels.items() if any(s in k for s in keys)}
-        n = sum(r['launches'] for r in members.values())
-        if not n:
-            continue
-        agg = {'launches': n, 'kernels': sorted(members)}
-        for field in ('fetch_x2_bytes', 'write_bytes', 'avg_us'):
-            if all(field in r for r in members.values()):
-                agg[field] = sum(r[field] * r['launches'] for r in members.values()) / n
-        if all('SQ_VALU_MFMA_BUSY_CYCLES' in r and r.get('GRBM_GUI_ACTIVE') for r in members.values()):
-            agg['mfma_util'] = sum(r['SQ_VALU_MFMA_BUSY_CYCLES'] * r['launches'] for r in members.values()) / \
-                (sum(r['GRBM_GUI_ACTIVE'] * r['launches'] for r in members.values()) / N_XCD * N_SIMD)
-        fams[fam] = agg
+    fams = families_of(kernels)
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
     from bench import csrc_sha16
