@@ -113,8 +113,9 @@ int dx_conv1d_wide(const void* x, long ldx, const void* w_frag, const float* bia
  * The k = 3 GEMMs into the 128-channel stream are bound by what a compute unit fetches from L2, and every workgroup
  * fetches the whole weight slice whatever the height of its tile; a ragged batch (model.py:21-23 masks, lengths differ
  * 10x inside a batch) cut into fixed 128-row tiles ends a few tiles above a multiple of the 256 CUs.  The plan cuts
- * each utterance into equal pieces of <= 256 rows so that the batch is exactly n_tiles = dx_conv_tile_plan_size(B, N)
- * pieces (a multiple of 256) with the smallest possible maximum height.  table: n_tiles x 4 int32 {b, n0, rows, f}
+ * each utterance into equal pieces of <= 256 rows so that the batch is at most n_tiles pieces with the smallest possible
+ * maximum height.  n_tiles: any count >= B * ceil(N / 256); dx_conv_tile_plan_size(B, N) is that bound rounded up to a
+ * multiple of the 256 CUs (the default of the Python host side).  table: n_tiles x 4 int32 {b, n0, rows, f}
  * (f = padding rows of the batch each workgroup zero-fills beside its tile),
  * device memory, valid for every GEMM over the same lengths (one plan per batch).  Results are identical to the
  * unplanned call: same rows, same summation order per output; rows >= lengths[b] are written as zeros. */

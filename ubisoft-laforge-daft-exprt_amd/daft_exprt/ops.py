@@ -152,13 +152,16 @@ def conv1d_lnbwd(x, w_packed, y_inout, s_in, mean, rstd, gamma, beta, lengths, d
     return dx_lp
 
 
-def conv_tile_plan(lengths, N, halo=0, round_to=None):
+def conv_tile_plan(lengths, N, halo=0, round_to=None, tiles=None):
     ''' balanced position tiles of one batch (dx_conv_tile_plan): build once per batch, pass as plan= to conv1d_ln / conv1d_lnbwd
         (halo 0: rows past the length are masked) or to the wide GEMMs of conv1d (halo 2: the pre-net convs compute two rows past
-        the length; round_to 64: their 4 channel tiles x 64 position tiles fill the 256 CUs in whole rounds).
+        the length; round_to 64: their 4 channel tiles x 64 position tiles fill the 256 CUs in whole rounds; tiles: an explicit
+        tile count >= B * ceil(N / 256) -- fewer, taller tiles for a batch too small to give 256 workgroups a useful height).
         Returns (int32 table (n_tiles, 4) on the device, B, N) '''
     B = lengths.shape[0]
-    if round_to is None:
+    if tiles is not None:
+        n = max(int(tiles), B * ((N + 255) // 256))
+    elif round_to is None:
         n = H.lib().dx_conv_tile_plan_size(B, N)
     else:
         worst = B * ((N + 255) // 256)
@@ -207,8 +210,8 @@ def frag_table(pairs, device):
     return table, len(pairs), max(w.numel() for w, _ in pairs)
 
 
-def pack_frag_major_batched(table, n, max_elems):
-    H.check(H.lib().dx_pack_frag_major_batched(H.ptr(table), n, max_elems, H.stream()))
+def pack_frag_major_batched(table, n, max_elems, stream=None):
+    H.check(H.lib().dx_pack_frag_major_batched(H.ptr(table), n, max_elems, H.stream() if stream is None else stream))
 
 
 def pack_table(entries, device):
@@ -226,8 +229,9 @@ def pack_table(entries, device):
     return table, len(entries), begin
 
 
-def pack_weights_batched(table, n, total, dtype):
-    H.check(H.lib().dx_pack_conv_weights_batched(H.ptr(table), n, total, H._DT[dtype], H.stream()))
+def pack_weights_batched(table, n, total, dtype, stream=None):
+    ''' stream: raw hipStream_t to launch on (default: torch's current stream) '''
+    H.check(H.lib().dx_pack_conv_weights_batched(H.ptr(table), n, total, H._DT[dtype], H.stream() if stream is None else stream))
 
 
 def conv1d_wgrad(dy, x, dw, db, compute_dtype, lengths=None, stream=None, ws=None):
@@ -252,6 +256,7 @@ def conv1d_wgrad(dy, x, dw, db, compute_dtype, lengths=None, stream=None, ws=Non
 
 def wgrad_ws_floats(B, N, Cin, Cout, taps):
     return H.lib().dx_conv1d_wgrad_ws_floats(B, N, Cin, Cout, taps)
+
 
 
 # ----------------------------------------------------------------------------- LayerNorm (+ residual, dropout, FiLM, mask)
