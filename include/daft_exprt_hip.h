@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DX_ABI_VERSION 8
+#define DX_ABI_VERSION 9
 
 enum { DX_F32 = 0, DX_BF16 = 1, DX_I64 = 2 };
 enum { DX_OK = 0, DX_ERR_ARG = -1, DX_ERR_SHAPE = -2, DX_ERR_DTYPE = -3, DX_ERR_LAUNCH = -4, DX_ERR_UNSUPPORTED = -5 };
@@ -122,6 +122,11 @@ int dx_conv1d_wide(const void* x, long ldx, const void* w_frag, const float* bia
 int dx_conv_tile_plan_size(int B, int N);
 int dx_conv_tile_plan(const int64_t* lengths, int B, int N, int n_tiles, int* table, int halo /* rows past the length that still
                       carry work: 0 for the LayerNorm-fused GEMMs (masked), 2 for the pre-net convs of dx_conv1d_wide */, void* stream);
+/* One launch for everything a step derives from one lengths tensor: dx_conv_tile_plan(halo 0) into table0 (n_tiles0 entries),
+ * dx_conv_tile_plan(halo 2) into table2 (n_tiles2 entries) and dx_length_order into order (B ints); any of the three
+ * outputs may be NULL.  Same results as the three separate calls. */
+int dx_batch_prep(const int64_t* lengths, int B, int N, int n_tiles0, int* table0, int n_tiles2, int* table2, int* order,
+                  void* stream);
 
 /* Pack an fp32 (Cout, Cin, taps) PyTorch conv / (Cout, Cin) linear weight for dx_conv1d.
  *   transpose_flip = 0: out[tap][co][ci] = w[co][ci][tap]                (forward operand)

@@ -191,3 +191,20 @@ def test_wide_gemm_kernel_matches_tiled_kernel_and_fp32_reference(relu, lens_lis
     assert float(((wide - ref) * live).abs().mean()) <= 2e-3 * float((ref * live).abs().mean() + 1e-9)
     valid = n_idx < lens[:, None, None]
     assert float(((wide - tiled) * valid).abs().max()) <= 1e-2 * scale
+
+
+@pytest.mark.gpu
+def test_batch_prep_equals_the_three_separate_launches():
+    ''' dx_batch_prep: both tile plans and the launch order of one lengths tensor from one launch == dx_conv_tile_plan (halo 0),
+        dx_conv_tile_plan (halo 2, tile count a multiple of 64), dx_length_order; switched-off outputs come back as None '''
+    from daft_exprt import ops
+    for lens, N in (([1000, 3, 0, 517, 256, 255, 999], 1000), ([160, 40, 41, 159, 0, 1], 160), ([70], 70)):
+        lt = torch.tensor(lens, device=DEV)
+        p0, p2, od = ops.batch_prep(lt, N)
+        r0 = ops.conv_tile_plan(lt, N)
+        r2 = ops.conv_tile_plan(lt, N, halo=2, round_to=64)
+        ro = ops.length_order(lt)
+        assert p0[1:] == r0[1:] and p2[1:] == r2[1:]
+        assert torch.equal(p0[0], r0[0]) and torch.equal(p2[0], r2[0]) and torch.equal(od, ro)
+    a, b, c = ops.batch_prep(lt, N, plan=False, wide=True, order=False)
+    assert a is None and c is None and torch.equal(b[0], r2[0])

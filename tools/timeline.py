@@ -27,7 +27,9 @@ def short(n):
 out = [f"{(r[0] - t0) / 1e3:9.1f} {(r[1] - r[0]) / 1e3:7.1f} {'M' if r[2] == main_q else 's'} g={r[3] // r[5]}x{r[4]} {short(r[6])}" for r in step]
 m = [r for r in step if r[2] == main_q]
 gaps = sum(max(0, m[i + 1][0] - m[i][1]) for i in range(len(m) - 1))
-head = (f"# step span {(max(r[1] for r in step) - t0) / 1e6:.3f} ms; main-queue kernel time {sum(r[1] - r[0] for r in m) / 1e6:.3f} ms "
+period = (rows[idx[-1]][1] - rows[idx[-2]][1]) / 1e6   # Adam end to Adam end: the step as the stream sees it, launch bubbles between steps included
+periods = [(rows[idx[i + 1]][1] - rows[idx[i]][1]) / 1e6 for i in range(len(idx) - 1)]
+head = (f"# step period {period:.3f} ms (all: {' '.join(f'{x:.2f}' for x in periods)}); step span {(max(r[1] for r in step) - t0) / 1e6:.3f} ms; main-queue kernel time {sum(r[1] - r[0] for r in m) / 1e6:.3f} ms "
         f"({len(m)} dispatches, gaps {gaps / 1e6:.3f} ms); other queues {sum(r[1] - r[0] for r in step if r[2] != main_q) / 1e6:.3f} ms")
 text = head + '\n' + '\n'.join(out)
 if len(sys.argv) > 2:

@@ -266,25 +266,31 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
     constexpr int NR = MT * 16 + 2;
     static_assert(SP == 1 || WQ * NR * 64 * sizeof(float) <= KT * LD * sizeof(TC), "merge buffer must fit in the K tile");
     float* red = reinterpret_cast<float*>(Ks) + (long)wq * NR * 64 + lane;
-    if (kh) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+    for (int k = 1; k < SP; ++k) {   // wave group k hands its partial to group 0, one group per round (fixed merge order)
+      if (kh == k) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[(mt * 16 + r) * 64] = oT[mt][r];
-      red[(MT * 16) * 64] = m;
-      red[(MT * 16 + 1) * 64] = l;
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[(mt * 16 + r) * 64] = oT[mt][r];
+        red[(MT * 16) * 64] = m;
+        red[(MT * 16 + 1) * 64] = l;
+      }
+      __syncthreads();
+      if (kh == 0) {
+        const float m1 = red[(MT * 16) * 64], l1 = red[(MT * 16 + 1) * 64];   // m1 = -inf, l1 = 0 if that group saw no key
+        const float mm = fmaxf(m, m1);
+        const float a0 = fast_exp2<TC>(m - mm), a1 = fast_exp2<TC>(m1 - mm);
+        l = l * a0 + l1 * a1;
+        m = mm;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oT[mt][r] = oT[mt][r] * a0 + red[(mt * 16 + r) * 64] * a1;
+      }
+      if (k + 1 < SP) __syncthreads();
     }
-    __syncthreads();
     if (kh) return;
-    const float m1 = red[(MT * 16) * 64], l1 = red[(MT * 16 + 1) * 64];   // m1 = -inf, l1 = 0 if that group saw no key
-    const float mm = fmaxf(m, m1);
-    const float a0 = fast_exp2<TC>(m - mm), a1 = fast_exp2<TC>(m1 - mm);
-    l = l * a0 + l1 * a1;
-    m = mm;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oT[mt][r] = oT[mt][r] * a0 + red[(mt * 16 + r) * 64] * a1;
   }
   if (q < N) {
     const float inv_l = wave_live ? inv_keep / l : 0.f;
@@ -455,18 +461,22 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
     if (SP > 1) {   // sum the two wave groups' partial dQ^T through the (dead) K tile
       static_assert(SP == 1 || WQ * MT * 16 * 64 * sizeof(float) <= KT * LD * sizeof(TC), "merge buffer must fit in the K tile");
       float* red = reinterpret_cast<float*>(Ks) + (long)wq * (MT * 16) * 64 + lane;
-      if (kh) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+      for (int k = 1; k < SP; ++k) {   // one wave group per round, added in group order
+        if (kh == k) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) red[(mt * 16 + r) * 64] = dqT[mt][r];
-      }
-      __syncthreads();
-      if (!kh) {
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int r = 0; r < 16; ++r) red[(mt * 16 + r) * 64] = dqT[mt][r];
+        }
+        __syncthreads();
+        if (!kh) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) dqT[mt][r] += red[(mt * 16 + r) * 64];
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dqT[mt][r] += red[(mt * 16 + r) * 64];
+        }
+        if (k + 1 < SP) __syncthreads();
       }
     }
   }
@@ -634,18 +644,22 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : 2) void attn_bwd_dkv_kernel(Att
       static_assert(SP == 1 || WQ * MT * 16 * 64 * sizeof(float) <= KT * LD * sizeof(TC), "merge buffer must fit in a tile");
       float* red_v = reinterpret_cast<float*>(Qs) + (long)wq * (MT * 16) * 64 + lane;
       float* red_k = reinterpret_cast<float*>(dOs) + (long)wq * (MT * 16) * 64 + lane;
-      if (kh) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+      for (int k = 1; k < SP; ++k) {   // one wave group per round, added in group order
+        if (kh == k) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { red_v[(mt * 16 + r) * 64] = dvT[mt][r]; red_k[(mt * 16 + r) * 64] = dkT[mt][r]; }
-      }
-      __syncthreads();
-      if (!kh) {
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int r = 0; r < 16; ++r) { red_v[(mt * 16 + r) * 64] = dvT[mt][r]; red_k[(mt * 16 + r) * 64] = dkT[mt][r]; }
+        }
+        __syncthreads();
+        if (!kh) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { dvT[mt][r] += red_v[(mt * 16 + r) * 64]; dkT[mt][r] += red_k[(mt * 16 + r) * 64]; }
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dvT[mt][r] += red_v[(mt * 16 + r) * 64]; dkT[mt][r] += red_k[(mt * 16 + r) * 64]; }
+        }
+        if (k + 1 < SP) __syncthreads();
       }
     }
   }

@@ -2465,7 +2465,7 @@ extern "C" int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const vo
 // every utterance into equal pieces of at most DX_PLAN_ROWS rows such that the batch is exactly n_tiles (a multiple of
 // the 256 CUs) pieces and the tallest piece is as short as possible.
 constexpr int DX_PLAN_ROWS = 256, DX_NUM_CU = 256;
-__global__ __launch_bounds__(64) void conv_plan_kernel(const int64_t* __restrict__ lens, int B, int N, int T, int4* __restrict__ table, int halo) {
+__device__ __forceinline__ void conv_plan_body(const int64_t* __restrict__ lens, int B, int N, int T, int4* __restrict__ table, int halo) {
   __shared__ int first[4096 + 1];
   const int lane = threadIdx.x;
   auto len_of = [&](int b) { const int l0 = (int)lens[b], l = (l0 < 0 ? 0 : l0) + halo; return l > N ? N : l; };   // rows that carry work
@@ -2506,6 +2506,26 @@ __global__ __launch_bounds__(64) void conv_plan_kernel(const int64_t* __restrict
   for (int i = first[B] + lane; i < T; i += 64) table[i] = make_int4(0, 0, 0, per);
 }
 
+__global__ __launch_bounds__(64) void conv_plan_kernel(const int64_t* __restrict__ lens, int B, int N, int T, int4* __restrict__ table, int halo) {
+  conv_plan_body(lens, B, N, T, table, halo);
+}
+// Everything the step derives from one lengths tensor, in one launch of three single-wave workgroups: the halo-0 plan of the
+// LayerNorm-fused GEMMs, the halo-2 plan of the wide GEMMs, and the longest-first launch order of the attention kernels
+// (dx_length_order) -- three 5-9 us launches per lengths tensor otherwise, each a dispatch boundary on the launch stream.
+__global__ __launch_bounds__(64) void batch_prep_kernel(const int64_t* __restrict__ lens, int B, int N, int T0, int4* __restrict__ table0,
+                                                        int T2, int4* __restrict__ table2, int* __restrict__ order) {
+  if (blockIdx.x == 0) { if (table0) conv_plan_body(lens, B, N, T0, table0, 0); }
+  else if (blockIdx.x == 1) { if (table2) conv_plan_body(lens, B, N, T2, table2, 2); }
+  else if (order) {
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {    // rank by (length descending, index ascending), as dx_length_order
+      const int64_t li = lens[i];
+      int rank = 0;
+      for (int j = 0; j < B; ++j) { const int64_t lj = lens[j]; rank += (lj > li) || (lj == li && j < i); }
+      order[rank] = i;
+    }
+  }
+}
+
 extern "C" int dx_conv_tile_plan_size(int B, int N) {
   if (B <= 0 || N <= 0) return 0;
   const long worst = (long)B * dx_cdiv(N, DX_PLAN_ROWS);
@@ -2518,6 +2538,18 @@ extern "C" int dx_conv_tile_plan(const int64_t* lengths, int B, int N, int n_til
   DX_REQUIRE(n_tiles >= B * dx_cdiv(N, DX_PLAN_ROWS), DX_ERR_ARG, "dx_conv_tile_plan: n_tiles=%d < B * ceil(N / 256) = %d", n_tiles,
              B * dx_cdiv(N, DX_PLAN_ROWS));
   hipLaunchKernelGGL(conv_plan_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lengths, B, N, n_tiles, reinterpret_cast<int4*>(table), halo);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+extern "C" int dx_batch_prep(const int64_t* lengths, int B, int N, int n_tiles0, int* table0, int n_tiles2, int* table2, int* order,
+                             void* stream) {
+  DX_REQUIRE(lengths, DX_ERR_ARG, "dx_batch_prep: null pointer");
+  DX_REQUIRE(B > 0 && B <= 4096 && N > 0, DX_ERR_SHAPE, "dx_batch_prep: B=%d (1..4096), N=%d", B, N);
+  const int need = B * dx_cdiv(N, DX_PLAN_ROWS);
+  DX_REQUIRE((!table0 || n_tiles0 >= need) && (!table2 || n_tiles2 >= need), DX_ERR_ARG, "dx_batch_prep: a tile count below B * ceil(N / 256) = %d", need);
+  hipLaunchKernelGGL(batch_prep_kernel, dim3(3), dim3(64), 0, (hipStream_t)stream, lengths, B, N, n_tiles0, reinterpret_cast<int4*>(table0),
+                     n_tiles2, reinterpret_cast<int4*>(table2), order);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }

@@ -129,6 +129,7 @@ def _init_tensor(shape, init, gen):
 
 
 _SKIP_WGRAD = bool(int(__import__('os').environ.get('DX_SKIP_WGRAD', '0')))
+_BATCH_PREP = bool(int(__import__('os').environ.get('DX_BATCH_PREP', '1')))   # 0: tile plans / launch orders by their own (lazy) launches (A/B switch)
 _MEL_BF16 = bool(int(__import__('os').environ.get('DX_MEL_BF16', '1')))   # 0: the first pre-net conv and its weight gradient read the fp32 mel rows (A/B switch)
 _PACK_SIDE_STREAM = bool(int(__import__('os').environ.get('DX_PACK_SIDE_STREAM', '0')))   # 1: the weight copies the pre-net does not read are refreshed on a pack stream underneath it (measured: 8.22 vs 8.17 ms -- the copies then share the chip with the pre-net's kernels, nothing is gained)
 
@@ -402,6 +403,24 @@ class DaftExprt(nn.Module):
             hit = self._plans[key] = (lengths, ops.conv_tile_plan(lengths, N, halo=2, round_to=64))
         return hit[1]
 
+    def _prep(self, lengths, N):
+        ''' the tile plans and the attention launch order of one lengths tensor from ONE launch (`ops.batch_prep`) instead of
+            up to three lazy ones (`_plan`, `_plan_wide`, `_order` then find their entries) '''
+        if lengths is None or not lengths.is_cuda or not _BATCH_PREP:
+            return
+        bf, B = self.cd == torch.bfloat16, lengths.shape[0]
+        plan = bf and self.balanced_tiles and B * N >= self._plan_min_rows and not (0 < B * N < 256 * self._plan_small_rows)
+        order = self.attn_lpt and B >= 2
+        if not (plan or bf or order):
+            return
+        p0, p2, od = ops.batch_prep(lengths, N, plan, bf, order)
+        if plan:
+            self._plans[(lengths.data_ptr(), N)] = (lengths, p0)
+        if bf:
+            self._plans[('wide', lengths.data_ptr(), N)] = (lengths, p2)
+        if order:
+            self._plans[('order', lengths.data_ptr())] = (lengths, od)
+
     def _order(self, lengths):
         ''' longest-first launch order of the attention kernels (`ops.length_order`), one per distinct lengths tensor per step '''
         if not self.attn_lpt or lengths.shape[0] < 2:
@@ -635,6 +654,8 @@ class DaftExprt(nn.Module):
         self._step_id += 1
         self._site = 0
         self._plans = {}
+        self._prep(output_lengths, mel_specs.shape[2])
+        self._prep(input_lengths, symbols.shape[1])
         W = self._weights(need_dgrad=save, defer=True)
         S = _Saved() if save else None
         emb, films, s_pe = self._prosody_encoder_fwd(W, frames_energy, frames_pitch, mel_specs, speaker_ids, output_lengths, train, save)
@@ -832,7 +853,9 @@ class DaftExprt(nn.Module):
         B, L = S.symbols.shape
         zeros = lambda *shape: ops.zeros(shape, dev)
         layout = film_layout(hp)
-        dfilms = [zeros(B, nb, 2 * ch) for nb, ch in layout]
+        sizes = [B * nb * 2 * ch for nb, ch in layout]                  # the FiLM gradient accumulators of the three stacks: one buffer, one fill
+        dfilm_all = zeros(sum(sizes))
+        dfilms = [v.view(B, nb, 2 * ch) for v, (nb, ch) in zip(torch.split(dfilm_all, sizes), layout)]
         # ---- decoder
         blocks, dec_x = S.dec
         pre = 'frame_decoder'

@@ -171,6 +171,21 @@ def conv_tile_plan(lengths, N, halo=0, round_to=None, tiles=None):
     return table, B, N
 
 
+def batch_prep(lengths, N, plan=True, wide=True, order=True):
+    ''' (conv_tile_plan(lengths, N), conv_tile_plan(lengths, N, halo=2, round_to=64), length_order(lengths)) from ONE launch
+        (dx_batch_prep); an output that is switched off comes back as None '''
+    B = lengths.shape[0]
+    worst = B * ((N + 255) // 256)
+    n0 = H.lib().dx_conv_tile_plan_size(B, N)
+    n2 = (worst + 63) // 64 * 64
+    dev = lengths.device
+    t0 = torch.empty((n0, 4), dtype=torch.int32, device=dev) if plan else None
+    t2 = torch.empty((n2, 4), dtype=torch.int32, device=dev) if wide else None
+    od = torch.empty((B,), dtype=torch.int32, device=dev) if order else None
+    H.check(H.lib().dx_batch_prep(H.ptr(lengths), B, N, n0, H.ptr(t0), n2, H.ptr(t2), H.ptr(od), H.stream()))
+    return (t0, B, N) if plan else None, (t2, B, N) if wide else None, od
+
+
 def _plan_args(plan, x, w_packed, B, N, k1_ok=False, w_frag=None):
     ''' (table pointer, n_tiles, fragment-order weights) when the plan applies to this GEMM (bf16 operands, k = 3, same batch
         geometry); the fragment-order copy only goes with a plan, k = 3 and Cin >= 256 '''
