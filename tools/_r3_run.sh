@@ -1,5 +1,9 @@
 set -u
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r3
-python -m pytest tests/test_gpu_model.py tests/test_gpu_conv.py tests/test_gpu_full_size.py tests/test_gpu_generate.py -q -m gpu --tb=short -x 2>&1 | tail -5
-python tools/ab_bench.py DX_BATCH_PREP 0 1 -- --no-cpu-baseline 2>&1 | tee gpurun_out/r3/ab_prep.log
+python -m pytest tests/test_gpu_kernels.py tests/test_gpu_conv.py -q -m gpu --tb=short -x 2>&1 | tail -3
+L0=$PWD/ubisoft-laforge-daft-exprt_amd/csrc/libdx_sk0.so
+for i in 1 2 3; do
+DX_HIP_LIB=$L0 python bench.py --no-cpu-baseline --steps 20 --warmup 8 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('spread0', d['ms_per_step'], d['roofline']['avg_launch_us'])"
+python bench.py --no-cpu-baseline --steps 20 --warmup 8 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('spread1', d['ms_per_step'], d['roofline']['avg_launch_us'])"
+done

@@ -1076,6 +1076,9 @@ namespace {
 //     backward: dx_conv1d_lnbwd), the row-wise code of conv_gemm_kernel run by one 256-thread team.
 // The padding rows of the batch (an equal share per workgroup, as in the ring kernel) are zero-filled after the epilogue.
 constexpr int SK_THREADS = 256, SK_S = 4, SK_NB = 4, SK_MAXP = 5;
+#ifndef SK_SPREAD
+#define SK_SPREAD 1   // 1: memory requests of a chunk spread through its MFMA sequence (0: clustered at the chunk start / between the taps)
+#endif
 #ifdef SK_TIMING   // development: per-workgroup stamps of the launches with LNM == SK_TIMING (tools/sk_timing.py), s_memrealtime ticks (10 ns)
 __device__ unsigned long long dx_sk_ts[1024 * 8];
 #define SK_STAMP(i) do { if (LNM == SK_TIMING && threadIdx.x == 0) dx_sk_ts[(blockIdx.x & 1023) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -1197,7 +1200,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       SK_CHUNK(it, 2);
-      if (it + SK_S - 1 < nk) issue_dma(kc_of(it + SK_S - 1), (it + SK_S - 1) % SK_S);
+      if (!SK_SPREAD) { if (it + SK_S - 1 < nk) issue_dma(kc_of(it + SK_S - 1), (it + SK_S - 1) % SK_S); }
       SK_CHUNK(it, 3);
       const TC* Ar = ring + (it % SK_S) * STAGE_EL;
       const int knext = kc_of(it + SK_NB < nk ? it + SK_NB : nk - 1);
@@ -1211,12 +1214,35 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
           for (int i = 0; i < NA; ++i) a[(tap + 1) & 1][i] = *reinterpret_cast<const frag_t*>(&Ar[lds_at(i * 32 + l31 + tap + 1, wk * 2 + g)]);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (SK_SPREAD && NA >= 4) {
+          // one wave per SIMD: a vector-memory instruction that finds the CU's request queue full stalls the wave, and MFMAs it has
+          // not issued yet with it.  The CU fetches ~25 B/clk from L2, a chunk is 8 KiB-instructions per wave for 24 MFMAs: spread
+          // the requests through the MFMA sequence (the matrix pipe works off what was issued while the next request waits)
+          // instead of issuing them in clusters between the taps.
+          constexpr int HALF = NA / 2;
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
+          for (int i = 0; i < HALF; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) dx_mma(acc[i][j], a[tap & 1][i], bq[U][tap][j]);
-        __builtin_amdgcn_sched_barrier(0);
-        load_b(knext, tap, bq[U][tap]);              // refill the slots just read: chunk it + NB
+            for (int j = 0; j < 2; ++j) dx_mma(acc[i][j], a[tap & 1][i], bq[U][tap][j]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (tap == 0) { if (it + SK_S - 1 < nk) issue_dma(kc_of(it + SK_S - 1), (it + SK_S - 1) % SK_S); }
+          else load_b(knext, tap - 1, bq[U][tap - 1]);          // the previous tap's slots: every MFMA that read them has been issued
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = HALF; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dx_mma(acc[i][j], a[tap & 1][i], bq[U][tap][j]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (tap == TAPS - 1) load_b(knext, tap, bq[U][tap]);
+        } else {
+          if (SK_SPREAD && tap == 0) { if (it + SK_S - 1 < nk) issue_dma(kc_of(it + SK_S - 1), (it + SK_S - 1) % SK_S); }
+#pragma unroll
+          for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dx_mma(acc[i][j], a[tap & 1][i], bq[U][tap][j]);
+          __builtin_amdgcn_sched_barrier(0);
+          load_b(knext, tap, bq[U][tap]);              // refill the slots just read: chunk it + NB
+        }
       }
       SK_CHUNK(it, 4);
     };
