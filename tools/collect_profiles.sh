@@ -9,9 +9,7 @@ OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-probe"
-python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
-python bench.py --batch 256 --tmin 500 --steps 10 --warmup 15 --no-cpu-baseline > $OUT/${TAG}_bench_train_c5.json 2>> $OUT/bench.err
-python bench.py --workload synth --batch 256 --steps 10 --warmup 3 > $OUT/${TAG}_bench_synth_c4.json 2>> $OUT/bench.err
+python bench.py --batch 256 --tmin 500 --steps 10 --warmup 15 --no-cpu-baseline > $OUT/${TAG}_bench_train_c5.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace -d $OUT/kt -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-probe > /dev/null 2> $OUT/kt.err
 DB=$(ls $OUT/kt/*/*.db | head -1)
 python tools/rocprof_stats.py $DB > $OUT/${TAG}_kernel_trace.md
@@ -39,5 +37,10 @@ rocprofv3 --kernel-trace --pmc $P1 -d $OUT/pa1 -- python tools/bench_ops.py attn
 rocprofv3 --kernel-trace --pmc $P2 -d $OUT/pa2 -- python tools/bench_ops.py attn > /dev/null 2>&1
 python tools/pmc_counters.py $OUT/pa1 $OUT/pa2 --out $OUT/${TAG}_attention_counters.json --command "python tools/bench_ops.py attn" > /dev/null
 rm -rf $OUT/pa1 $OUT/pa2
+# the bench lines of C2 / C4 LAST: bench.py quotes roofline.traffic / hbm from profiles/<tag>_counters.json only when that file was
+# recorded for the kernel build that is running, so the counters of THIS build go into profiles/ (of this box's copy) first
+cp $OUT/${TAG}_counters.json $OUT/${TAG}_synth_counters.json profiles/
+python bench.py > $OUT/${TAG}_bench.json 2>> $OUT/bench.err
+python bench.py --workload synth --batch 256 --steps 10 --warmup 3 > $OUT/${TAG}_bench_synth_c4.json 2>> $OUT/bench.err
 cat $OUT/counters_summary.txt
 head -c 400 $OUT/${TAG}_bench.json; echo
