@@ -1,6 +1,11 @@
 set -u
 export TMPDIR=/tmp
-mkdir -p gpurun_out/profiles_r03
-python bench.py > gpurun_out/profiles_r03/r03_bench.json 2> gpurun_out/profiles_r03/bench.err
-python bench.py --workload synth --batch 256 --steps 10 --warmup 3 > gpurun_out/profiles_r03/r03_bench_synth_c4.json 2>> gpurun_out/profiles_r03/bench.err
-python bench.py --loop train --steps 60 --warmup 20 2>/dev/null | tail -1 | cut -c1-300
+mkdir -p gpurun_out/r3
+python -m pytest tests/test_gpu_kernels.py -q -m gpu --tb=short -x -k attention 2>&1 | tail -3
+LP=$PWD/ubisoft-laforge-daft-exprt_amd/csrc/libdx_prev.so
+DX_HIP_LIB=$LP python tools/bench_ops.py attn 2>&1 | grep attn
+python tools/bench_ops.py attn 2>&1 | grep attn
+for i in 1 2 3; do
+DX_HIP_LIB=$LP python bench.py --no-cpu-baseline --steps 20 --warmup 8 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('prev', d['ms_per_step'])"
+python bench.py --no-cpu-baseline --steps 20 --warmup 8 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('xcd ', d['ms_per_step'])"
+done

@@ -36,8 +36,24 @@ struct AttnArgs {
   int N, H, E;
   float scale, p_drop;
   uint64_t seed;
-  const int* order;        // blockIdx.z -> utterance, longest first (dx_length_order); NULL = identity
+  const int* order;        // launch rank -> utterance, longest first (dx_length_order); NULL = identity
+  int B, gx;               // set by the launchers: utterances, tiles per (utterance, head) along the owned axis
 };
+
+// XCD-aware launch order.  Workgroups go to the 8 XCDs round-robin in flat index order, and every XCD has its own L2.  With the
+// natural (tile, head, utterance) order the heads of one utterance land on eight different XCDs, and since a 128-byte line of
+// the (B, N, 3E) / (B, N, E) rows holds the 16-channel slices of FOUR heads, every XCD fetched every line: FETCH_SIZE was 8x
+// the tensors (290 MB per fused-backward launch for 37 MB of live rows).  Here all workgroups of one utterance -- every head,
+// every tile -- decode to the same XCD (the ranks of the longest-first order dealt to the XCDs in a snake), so a line is fetched into one L2
+// once and the other heads hit it.  `per` = workgroups per utterance; the grid is rounded up to 8 utterances (extras exit).
+constexpr int DX_XCDS = 8;
+__device__ __forceinline__ bool attn_decode(int flat, int per, int B, int& rank, int& inner) {
+  const int xcd = flat % DX_XCDS, j = flat / DX_XCDS, grp = j / per;
+  rank = grp * DX_XCDS + ((grp & 1) ? DX_XCDS - 1 - xcd : xcd);   // snake over the length-sorted ranks: the XCDs get equal shares of the long utterances
+  inner = j - grp * per;
+  return rank < B;
+}
+static inline unsigned attn_grid(int B, int per) { return (unsigned)(((B + DX_XCDS - 1) / DX_XCDS) * DX_XCDS * per); }
 
 template <typename TC> struct APad;
 template <> struct APad<bf16_t> { static constexpr int value = 8; };
@@ -134,15 +150,18 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
   // form of this kernel measured 45 vs 41 us
   const int wv = DH >= 64 ? wave : __builtin_amdgcn_readfirstlane(wave);
   const int wq = wv % WQ, kh = wv / WQ;
-  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, N = a.N, E = a.E;
+  int rank_, inner_;
+  if (!attn_decode((int)blockIdx.x, a.gx * a.H, a.B, rank_, inner_)) return;      // (grid rounded up to 8 utterances)
+  const int bx = inner_ % a.gx;                                                    // tile along the owned axis
+  const int b = a.order ? a.order[rank_] : rank_, h = inner_ / a.gx, N = a.N, E = a.E;
   const int len = (int)a.lengths[b];
-  const int q = blockIdx.x * QB + wq * 32 + l31;
+  const int q = bx * QB + wq * 32 + l31;
   const long ld_g = 3L * E;
   const TC* base = reinterpret_cast<const TC*>(a.qkv) + (long)b * N * ld_g + h * DH;
   TC* O = reinterpret_cast<TC*>(a.o) + (long)b * N * E + h * DH;
   float* lse = a.lse ? a.lse + ((long)b * a.H + h) * N : nullptr;
 
-  if (blockIdx.x * QB >= len) {  // whole tile of pad queries: their rows are zeroed after the LayerNorm anyway
+  if (bx * QB >= len) {  // whole tile of pad queries: their rows are zeroed after the LayerNorm anyway
     if (q < N && kh == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -156,7 +175,7 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
 
   // a wave whose 32 queries are all padding (the ragged end of an utterance: half the waves of its last tile on average)
   // still stages tiles and meets the barriers, but issues no MFMA / softmax work; its rows leave as zeros
-  const bool wave_live = blockIdx.x * QB + wq * 32 < len;
+  const bool wave_live = bx * QB + wq * 32 < len;
   frag_t qf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
@@ -336,9 +355,12 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
   constexpr int SP = Split<DH>::value, QB = 128 / SP, WQ = 4 / SP;
   const int wv = __builtin_amdgcn_readfirstlane(wave);   // scalar: the row-group tests below become s_cbranch (5 % on the backward kernels)
   const int wq = wv % WQ, kh = wv / WQ;
-  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, N = a.N, E = a.E;
+  int rank_, inner_;
+  if (!attn_decode((int)blockIdx.x, a.gx * a.H, a.B, rank_, inner_)) return;      // (grid rounded up to 8 utterances)
+  const int bx = inner_ % a.gx;                                                    // tile along the owned axis
+  const int b = a.order ? a.order[rank_] : rank_, h = inner_ / a.gx, N = a.N, E = a.E;
   const int len = (int)a.lengths[b];
-  const int q = blockIdx.x * QB + wq * 32 + l31;
+  const int q = bx * QB + wq * 32 + l31;
   const long ld_g = 3L * E;
   const TC* base = reinterpret_cast<const TC*>(a.qkv) + (long)b * N * ld_g + h * DH;
   const TC* dO = reinterpret_cast<const TC*>(a.d_o) + (long)b * N * E + h * DH;
@@ -351,9 +373,9 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqT[mt][r] = 0.f;
 
-  if (blockIdx.x * QB >= len && q < N && g == 0)   // pad-query tiles: delta is never used, keep it finite
+  if (bx * QB >= len && q < N && g == 0)   // pad-query tiles: delta is never used, keep it finite
     const_cast<float*>(a.delta)[((long)b * a.H + h) * N + q] = 0.f;
-  if (blockIdx.x * QB < len) {
+  if (bx * QB < len) {
     frag_t qf[KS], dof[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -377,8 +399,8 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
     delta_q = xhalf_sum(delta_q);
     if (q < N && g == 0 && kh == 0) const_cast<float*>(a.delta)[stat] = delta_q;
     const float c2 = a.scale * LOG2E, lse2 = lse_q * LOG2E;
-    const bool tile_q_valid = blockIdx.x * QB + wq * 32 + 32 <= len;
-    const bool wave_live = blockIdx.x * QB + wq * 32 < len;
+    const bool tile_q_valid = bx * QB + wq * 32 + 32 <= len;
+    const bool wave_live = bx * QB + wq * 32 < len;
     const uint32_t th8 = dx_drop_th8(a.p_drop);
     const float inv_keep = dx_drop_inv_keep8(th8);
     const uint32_t NB = (uint32_t)(N + 3) >> 2;
@@ -504,9 +526,12 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : 2) void attn_bwd_dkv_kernel(Att
   constexpr int SP = Split<DH>::value, QB = 128 / SP, WQ = 4 / SP;
   const int wv = __builtin_amdgcn_readfirstlane(wave);   // scalar: the row-group tests below become s_cbranch (5 % on the backward kernels)
   const int wq = wv % WQ, kh = wv / WQ;
-  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, N = a.N, E = a.E;
+  int rank_, inner_;
+  if (!attn_decode((int)blockIdx.x, a.gx * a.H, a.B, rank_, inner_)) return;      // (grid rounded up to 8 utterances)
+  const int bx = inner_ % a.gx;                                                    // tile along the owned axis
+  const int b = a.order ? a.order[rank_] : rank_, h = inner_ / a.gx, N = a.N, E = a.E;
   const int len = (int)a.lengths[b];
-  const int key = blockIdx.x * QB + wq * 32 + l31;
+  const int key = bx * QB + wq * 32 + l31;
   const long ld_g = 3L * E;
   const TC* base = reinterpret_cast<const TC*>(a.qkv) + (long)b * N * ld_g + h * DH;
   const TC* dO = reinterpret_cast<const TC*>(a.d_o) + (long)b * N * E + h * DH;
@@ -523,7 +548,7 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : 2) void attn_bwd_dkv_kernel(Att
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dvT[mt][r] = 0.f; dkT[mt][r] = 0.f; }
 
-  if (blockIdx.x * QB < len) {
+  if (bx * QB < len) {
     frag_t kf[KS], vf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -538,8 +563,8 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : 2) void attn_bwd_dkv_kernel(Att
     const uint32_t ctr_lane = dx_opaque(((uint32_t)(key >> 2) + g * NB) * DX_CTR_MUL + dx_key32(a.seed, (uint32_t)(b * a.H + h)));
     const uint32_t shl_lane = 24u - 8u * (key & 3);
     const float c2 = a.scale * LOG2E;
-    const bool tile_k_valid = blockIdx.x * QB + wq * 32 + 32 <= len;
-    const bool wave_live = blockIdx.x * QB + wq * 32 < len;
+    const bool tile_k_valid = bx * QB + wq * 32 + 32 <= len;
+    const bool wave_live = bx * QB + wq * 32 < len;
 
     TileRegs<TC, DH, KT> qreg, doreg;
     float lse_r = 0.f, delta_r = 0.f;
@@ -741,7 +766,7 @@ __host__ __device__ static inline long fb_ws_floats(int B, int N, int H) {
   return (long)B * H * 2 * npad * 16 + (long)B * H;
 }
 
-__global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, float* ws) {
+__global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, float* ws) {   // grid: attn_grid(B, 2 H)
   constexpr int DH = 16;
   typedef bf16_t TC;
   typedef bf16x8 frag_t;
@@ -756,8 +781,9 @@ __global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, f
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5, i16 = lane & 15, G = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = a.H, N = a.N, E = a.E;
-  const int half = blockIdx.x & 1, bh = blockIdx.x >> 1;
-  const int bi = bh / H, h = bh - bi * H;
+  int bi, inner_;
+  if (!attn_decode((int)blockIdx.x, 2 * H, a.B, bi, inner_)) return;
+  const int half = inner_ & 1, h = inner_ >> 1;
   const int b = a.order ? a.order[bi] : bi;
   int len = (int)a.lengths[b];
   len = len < 0 ? 0 : (len > N ? N : len);
@@ -772,7 +798,7 @@ __global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, f
   const float* lse = a.lse + ((long)b * H + h) * N;
   const long npad = (N + 31) & ~31;
   float* part = ws + (((long)b * H + h) * 2 + half) * npad * 16;        // split utterances: this workgroup's dQ partial [query][d]
-  int* counter = reinterpret_cast<int*>(ws + (long)gridDim.x * npad * 16) + (b * H + h);
+  int* counter = reinterpret_cast<int*>(ws + (long)a.B * H * 2 * npad * 16) + (b * H + h);
   if (!half) {   // rows past the last live block: dQ | dK | dV are zero (this head's 16 columns of each)
     const frag_t z = zero8<TC>();
     const int nz = (N - rows_live) * 6;
@@ -995,8 +1021,11 @@ __global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, f
 }
 
 template <typename TC>
-int launch_fwd(const AttnArgs& a, int B, int dh, hipStream_t s) {
-  dim3 grid(dx_cdiv(a.N, dh == 64 ? 128 / Split<64>::value : 128), a.H, B), block(256);
+int launch_fwd(const AttnArgs& a0, int B, int dh, hipStream_t s) {
+  AttnArgs a = a0;
+  a.B = B;
+  a.gx = dx_cdiv(a.N, dh == 64 ? 128 / Split<64>::value : 128);
+  dim3 grid(attn_grid(B, a.gx * a.H)), block(256);
   if (dh == 16) hipLaunchKernelGGL((attn_fwd_kernel<TC, 16>), grid, block, 0, s, a);
   else if (dh == 64) hipLaunchKernelGGL((attn_fwd_kernel<TC, 64>), grid, block, 0, s, a);
   else { dx_set_error("attention: head dim %d unsupported (16, 64)", dh); return DX_ERR_UNSUPPORTED; }
@@ -1009,18 +1038,21 @@ static int fused_bwd_enabled() {
   return on;
 }
 template <typename TC>
-int launch_bwd(const AttnArgs& a, int B, int dh, float* delta, int algo, hipStream_t s) {
+int launch_bwd(const AttnArgs& a0, int B, int dh, float* delta, int algo, hipStream_t s) {
+  AttnArgs a = a0;
+  a.B = B;
+  a.gx = dx_cdiv(a.N, dh == 64 ? 128 / Split<64>::value : 128);
   const bool can_fuse = std::is_same<TC, bf16_t>::value && dh == 16 && a.N <= FB_MAXN;
   if (algo == DX_ATTN_FUSED && !can_fuse) {
     dx_set_error("dx_attention_bwd: the fused kernel needs bf16, d_head 16, N <= %d (got d_head %d, N %d)", FB_MAXN, dh, a.N);
     return DX_ERR_UNSUPPORTED;
   }
   if (can_fuse && (algo == DX_ATTN_FUSED || (algo == DX_ATTN_AUTO && fused_bwd_enabled()))) {
-    hipLaunchKernelGGL(attn_bwd_fused16_kernel, dim3(B * a.H * 2), dim3(FB_T), 0, s, a, delta + (long)B * a.H * a.N);
+    hipLaunchKernelGGL(attn_bwd_fused16_kernel, dim3(attn_grid(B, 2 * a.H)), dim3(FB_T), 0, s, a, delta + (long)B * a.H * a.N);
     DX_LAUNCH_CHECK();
     return DX_OK;
   }
-  dim3 grid(dx_cdiv(a.N, dh == 64 ? 128 / Split<64>::value : 128), a.H, B), block(256);
+  dim3 grid(attn_grid(B, a.gx * a.H)), block(256);
   if (dh == 16) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, 16>), grid, block, 0, s, a);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<TC, 16>), grid, block, 0, s, a);
