@@ -1483,6 +1483,9 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
 // L2 -> CU traffic per launch = 2 bytes x M N K x (1 / 256 + 1 / 256): half of what 256 x 128 tiles fetch.
 // Epilogue: bias, ReLU, rows past length + 2 zeroed; a wave stages one 32-row x 128-channel slab at a time through its own LDS
 // region and stores whole 256-byte row segments in bf16.
+#ifndef WD_KOFF_PT
+#define WD_KOFF_PT 1
+#endif
 constexpr int WD_THREADS = 256, WD_S = 3, WD_RING = 6, WD_MAXP = 5;
 __device__ __forceinline__ void wd_wait_vmcnt(int n) {
   switch (n) {
@@ -1544,7 +1547,11 @@ __global__ __launch_bounds__(WD_THREADS, 1) void conv_wide_kernel(ConvArgs p) {
     for (int t = 0; t < WD_MAXP; ++t)
       if (t < mine) sk_dma16(src[t] + kc * 32, __builtin_amdgcn_readfirstlane(ring_base + (unsigned)(buf * STAGE_EL * 2) + dst[t]));
   };
-  const int koff = (int)((blockIdx.x >> 3) % (unsigned)nk);         // per-workgroup rotation of the chunk order (see conv_sk_kernel)
+  // rotation of the chunk order (see conv_sk_kernel) by POSITION tile only: the channel tiles of one position tile run on the same
+  // XCD (plan_tiles % 8 == 0) at the same time and read the same activation chunks -- in the same chunk order the first one
+  // pulls a chunk into the XCD's L2 and the others hit it (with the rotation keyed on blockIdx they walked the chunks 8 apart and
+  // each fetched the activation tile for itself: FETCH_SIZE 188 MB per launch for 61 MB of activations)
+  const int koff = WD_KOFF_PT ? (int)((pt >> 3) % (unsigned)nk) : (int)((blockIdx.x >> 3) % (unsigned)nk);
   auto kc_of = [&](int it) { const int k = it + koff; return k >= nk ? k - nk : k; };
   // fragment (k-step q = chunk * 6 + tap * 2 + half, channel block c) at q * (Cout / 32) * 512 + c * 512 elements
   const size_t qstride = (size_t)(Cout >> 5) * 512;
