@@ -199,6 +199,7 @@ class DaftExprt(nn.Module):
         self._wgrad_batch_rows = int(__import__('os').environ.get('DX_WGRAD_BATCH_ROWS', '1000000000'))   # GEMMs with fewer rows wait for the block's flush (measured: always waiting is best, 8.35 vs 8.42 ms)
         self._wgrad_flush_blocks = int(__import__('os').environ.get('DX_WGRAD_FLUSH_BLOCKS', '1'))   # FFT blocks per flush
         self._blocks_since_flush = 0
+        self._wgrad_defer_rows = int(__import__('os').environ.get('DX_WGRAD_DEFER_ROWS', '0'))   # see _block_done (0: never defer; 16384 measured 7.99 vs 7.79 ms)
         self._wgrad_ws = None
         self._hop = None
         self.fuse_ln_backward = bool(int(__import__('os').environ.get('DX_FUSE_LN_BWD', '1')))   # see _fft_block_bwd
@@ -688,7 +689,15 @@ class DaftExprt(nn.Module):
         if dy.shape[0] * dy.shape[1] >= self._wgrad_batch_rows:   # frame-level GEMMs: the GPU is the bottleneck, start right away
             self._flush_wgrads()
 
-    def _block_done(self):
+    def _block_done(self, rows=1 << 30):
+        ''' end of an FFT block / conv stage of the backward pass: its queued weight gradients go to the side stream.
+            `_wgrad_defer_rows` > 0 holds the launches of small stages (phoneme level) back until the end of their section: the
+            profiler shows the launch stream starved for 60-80 us at those block boundaries while the host issues the 8 side-stream
+            launches, but deferring them is WORSE (7.99 vs 7.79 ms): the phoneme-level kernels of the main stream leave most of the
+            chip idle, which is exactly where the weight gradients run for free; deferred, they land on the frame-level kernels of
+            the prosody encoder instead '''
+        if rows < self._wgrad_defer_rows:
+            return
         self._blocks_since_flush += 1
         if self._blocks_since_flush >= self._wgrad_flush_blocks:
             self._flush_wgrads()
@@ -775,12 +784,12 @@ class DaftExprt(nn.Module):
                                         G[f'{fb}.layer_norm.weight'], G[f'{fb}.layer_norm.bias'], film=below.film, dfilm=dfilm_below,
                                         p_pre=below.p_conv, seed_pre=below.seeds[2],
                                         plan=self._plan(below.lengths, dqkv.shape[1]) if self._plan_k1 else None)
-            self._block_done()
+            self._block_done(dqkv.shape[0] * dqkv.shape[1])
             if self._trace_bwd is not None:              # dx = dL/d(s2 of the block below): its LayerNorm backward ran in the launch above
                 self._trace_bwd.append(('fft_block', s, below, cap_in, dx.clone()))
             return dx, (dx, dz_below)
         ops.conv1d(dqkv, W[f'T:{mha}.in_proj_weight'], None, out=dx, accumulate=True, skip_lengths=s.lengths)
-        self._block_done()
+        self._block_done(dqkv.shape[0] * dqkv.shape[1])
         if self._trace_bwd is not None:                  # dx = dL/d(block input)
             self._trace_bwd.append(('fft_block', s, None, cap_in, dx.clone()))
         return dx, None
@@ -800,7 +809,7 @@ class DaftExprt(nn.Module):
                 self._trace_bwd.append(('conv_ln', s, None, dy.clone(), None))     # no data gradient: the input needs none
             return None
         self._wgrad(dc, s.x, G[f'{s.conv_name}.conv.weight'], G[f'{s.conv_name}.conv.bias'], lengths_hint)
-        self._flush_wgrads()
+        self._block_done(dc.shape[0] * dc.shape[1])
         if dx_out is not None:
             if self._trace_bwd is not None:
                 self._trace_bwd.append(('conv_ln', s, None, dy.clone(), None))     # the data gradient is accumulated into dx_out: not separable
