@@ -57,6 +57,14 @@ int dx_conv1d(const void* x, int x_dtype, long ldx, const void* w_packed, int w_
               void* y, int y_dtype, long ldy, const void* relu_gate, int gate_dtype, const int64_t* mask_lengths,
               const int64_t* skip_lengths, int B, int N, int Cin, int Cout, int taps, int flags, void* stream);
 
+/* dx_conv1d with an optional fragment-order copy of the weights (dx_pack_frag_major(_batched) of w_packed; NULL = dx_conv1d):
+ * the register-weights kernel of the Cin = 128, Cout % 256 == 0 GEMMs (FF conv 128 -> 1024 and the data gradient of
+ * 1024 -> 128) then loads every MFMA fragment of its weight slice straight into its registers -- one round trip instead of
+ * a pass through LDS in front of the first position tile.  Same results bit for bit. */
+int dx_conv1d_wfrag(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const void* w_frag, const float* bias,
+                    void* y, int y_dtype, long ldy, const void* relu_gate, int gate_dtype, const int64_t* mask_lengths,
+                    const int64_t* skip_lengths, int B, int N, int Cin, int Cout, int taps, int flags, void* stream);
+
 /* dx_conv1d with Cout = 128 and the following LayerNorm fused into its epilogue (a 128-row tile holds complete rows):
  *   s = dropout_pre(conv(x) + bias) + residual;  y = LN(s) * gamma + beta;  y = film[b,:128] * y + film[b,128:];
  *   y = 0 where n >= lengths[b]

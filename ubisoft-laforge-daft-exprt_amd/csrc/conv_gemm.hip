@@ -777,7 +777,19 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
   static_assert((WR_BN * KCH) % WR_THREADS == 0, "weight slice must split evenly over the workgroup");
   constexpr int W_PT = WR_BN * KCH / WR_THREADS;
   bf16x8 wtmp[TAPS][W_PT];
-  {
+  // With a fragment-order copy of the weights (dx_pack_frag_major: a fragment is one contiguous KiB, and it is exactly
+  // wreg[tap][ks] of the wave that owns channel block co0 / 32) the wave loads its 8 x TAPS fragments straight into their
+  // registers: one round trip, no pass through LDS, none of the 2 TAPS barriers below.
+  const bool wfrag = TAPS == 3 && p.w_frag != nullptr;
+  if (wfrag) {
+    const TC* wf = reinterpret_cast<const TC*>(p.w_frag) + (size_t)(co0 >> 5) * 512 + lane * 8;
+    const size_t fstride = (size_t)(Cout >> 5) * 512;            // fragments of one (chunk, tap, half): all channel blocks
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks)
+        wreg[tap][ks] = *reinterpret_cast<const frag_t*>(wf + (size_t)((((ks >> 1) * TAPS + tap) << 1) + (ks & 1)) * fstride);
+  } else {
     const int cblk = (blockIdx.x % ztiles) * WR_BN;
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
@@ -937,7 +949,7 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
 
   int buf = 0;
   if (left > 0) fetch(b, pt);
-  {   // weights: registers (whole rows) -> LDS -> registers (MFMA fragments), see the top of the kernel
+  if (!wfrag) {   // weights: registers (whole rows) -> LDS -> registers (MFMA fragments), see the top of the kernel
     TC* Ws = reinterpret_cast<TC*>(smem);
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
@@ -2398,15 +2410,39 @@ extern "C" int dx_pack_conv_weights_batched(const void* descs_dev, int n, long t
   return DX_OK;
 }
 
+static int conv1d_impl(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const float* bias,
+                       void* y, int y_dtype, long ldy, const void* relu_gate, int gate_dtype,
+                       const int64_t* mask_lengths, const int64_t* skip_lengths, int B, int N, int Cin, int Cout,
+                       int taps, int flags, const void* w_frag, void* stream);
+
 extern "C" int dx_conv1d(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const float* bias,
                          void* y, int y_dtype, long ldy, const void* relu_gate, int gate_dtype,
                          const int64_t* mask_lengths, const int64_t* skip_lengths, int B, int N, int Cin, int Cout,
                          int taps, int flags, void* stream) {
+  return conv1d_impl(x, x_dtype, ldx, w_packed, w_dtype, bias, y, y_dtype, ldy, relu_gate, gate_dtype, mask_lengths, skip_lengths, B, N,
+                     Cin, Cout, taps, flags, nullptr, stream);
+}
+
+extern "C" int dx_conv1d_wfrag(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const void* w_frag,
+                               const float* bias, void* y, int y_dtype, long ldy, const void* relu_gate, int gate_dtype,
+                               const int64_t* mask_lengths, const int64_t* skip_lengths, int B, int N, int Cin, int Cout,
+                               int taps, int flags, void* stream) {
+  DX_REQUIRE(!w_frag || (taps == 3 && w_dtype == DX_BF16 && Cin % 32 == 0 && Cout % 32 == 0), DX_ERR_ARG,
+             "dx_conv1d_wfrag: a fragment-order copy goes with bf16 weights, taps = 3, Cin %% 32 == 0 and Cout %% 32 == 0");
+  return conv1d_impl(x, x_dtype, ldx, w_packed, w_dtype, bias, y, y_dtype, ldy, relu_gate, gate_dtype, mask_lengths, skip_lengths, B, N,
+                     Cin, Cout, taps, flags, w_frag, stream);
+}
+
+static int conv1d_impl(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const float* bias,
+                       void* y, int y_dtype, long ldy, const void* relu_gate, int gate_dtype,
+                       const int64_t* mask_lengths, const int64_t* skip_lengths, int B, int N, int Cin, int Cout,
+                       int taps, int flags, const void* w_frag, void* stream) {
   DX_REQUIRE(x && w_packed && y, DX_ERR_ARG, "dx_conv1d: null pointer");
   DX_REQUIRE(B > 0 && N > 0 && Cin > 0 && Cout > 0, DX_ERR_SHAPE, "dx_conv1d: empty shape B=%d N=%d Cin=%d Cout=%d", B, N, Cin, Cout);
   DX_REQUIRE(Cin % 8 == 0 && ldx % 8 == 0, DX_ERR_SHAPE, "dx_conv1d: Cin (%d) and ldx (%ld) must be multiples of 8", Cin, ldx);
   DX_REQUIRE(taps == 1 || taps == 3, DX_ERR_UNSUPPORTED, "dx_conv1d: taps=%d (only 1 and 3)", taps);
   ConvArgs a{x, ldx, w_packed, bias, y, ldy, relu_gate, mask_lengths, skip_lengths, N, Cin, Cout, flags, B, LNEpi{}};
+  a.w_frag = w_frag;
   hipStream_t s = (hipStream_t)stream;
   const int gd = relu_gate ? gate_dtype : y_dtype;
   if (w_dtype == DX_BF16) {

@@ -328,6 +328,14 @@ class DaftExprt(nn.Module):
                     if name.endswith('feed_forward.convs.0.conv.weight') and w.shape[1] == 128 and w.shape[0] % 32 == 0 and w.shape[0] >= 256:
                         self._packed['FT:' + name] = torch.empty(w.numel(), dtype=self.cd, device=dev)
                         fbwd.append((self._packed['T:' + name], self._packed['FT:' + name]))
+                    # the register-weights kernel (Cin = 128 -> Cout % 256 == 0: first FF conv forward, second FF conv data gradient)
+                    # loads its weight slice fragment by fragment from the same layout
+                    if ops.USE_WFRAG and name.endswith('feed_forward.convs.0.conv.weight') and w.shape[1] == 128 and w.shape[0] % 256 == 0:
+                        self._packed['F:' + name] = torch.empty(w.numel(), dtype=self.cd, device=dev)
+                        ffwd[0 if early(name) else 1].append((self._packed[name], self._packed['F:' + name]))
+                    if ops.USE_WFRAG and name.endswith('feed_forward.convs.2.conv.weight') and w.shape[0] == 128 and w.shape[1] % 256 == 0:
+                        self._packed['FT:' + name] = torch.empty(w.numel(), dtype=self.cd, device=dev)
+                        fbwd.append((self._packed['T:' + name], self._packed['FT:' + name]))
                 self._frag_fwd = [ops.frag_table(f, dev) if f else None for f in ffwd]
                 self._frag_bwd = ops.frag_table(fbwd, dev) if fbwd else None
             self._packed_version = self._dgrad_version = -1
@@ -513,7 +521,7 @@ class DaftExprt(nn.Module):
                                                   lp_copy=lp)
         ain = a_lp if lp else a
         h = ops.conv1d(ain, W[f'{f_pre}.convs.0.conv.weight'], P[f'{f_pre}.convs.0.conv.bias'], out_dtype=cd, relu=True,
-                       skip_lengths=lengths)
+                       skip_lengths=lengths, w_frag=W.get(f'F:{f_pre}.convs.0.conv.weight'))
         # second FF conv + Dropout + residual + LayerNorm + FiLM + mask in ONE launch
         u, u_lp, s2, mean2, rstd2 = ops.conv1d_ln(h, W[f'{f_pre}.convs.2.conv.weight'], P[f'{f_pre}.convs.2.conv.bias'], a,
                                                   P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'], lengths, film=film,
@@ -758,7 +766,8 @@ class DaftExprt(nn.Module):
         cap_in = ds2.clone() if self._trace_bwd is not None else None   # dL/d(s2 of this block): the residual gradient is updated in place below
         da = ds2
         self._wgrad(dz, s.h, G[f'{f_pre}.convs.2.conv.weight'], G[f'{f_pre}.convs.2.conv.bias'], s.lengths)
-        dh = ops.conv1d(dz, W[f'T:{f_pre}.convs.2.conv.weight'], None, out_dtype=cd, relu_gate=s.h, skip_lengths=s.lengths)
+        dh = ops.conv1d(dz, W[f'T:{f_pre}.convs.2.conv.weight'], None, out_dtype=cd, relu_gate=s.h, skip_lengths=s.lengths,
+                        w_frag=W.get(f'FT:{f_pre}.convs.2.conv.weight'))
         self._wgrad(dh, s.a, G[f'{f_pre}.convs.0.conv.weight'], G[f'{f_pre}.convs.0.conv.bias'], s.lengths)
         if fuse:
             dproj = ops.conv1d_lnbwd(dh, W[f'T:{f_pre}.convs.0.conv.weight'], da, s.s1, s.mean1, s.rstd1,

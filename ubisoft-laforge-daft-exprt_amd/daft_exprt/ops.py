@@ -74,6 +74,7 @@ def pack_conv_weight(w, dtype, transpose_flip=False, out=None):
     return out
 
 
+USE_WFRAG = bool(int(os.environ.get('DX_CONV_WFRAG', '1')))   # 0: the register-weights kernel stages its weights through LDS (A/B switch)
 USE_WIDE = bool(int(os.environ.get('DX_CONV_WIDE', '1')))   # 0: the 1024 -> 1024 k = 3 GEMMs stay on conv_gemm_kernel (A/B switch)
 
 
@@ -82,7 +83,8 @@ def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, m
     ''' x (B, N, Cin) [last dim contiguous]; w_packed (taps, Cout, Cin) -> (B, N, Cout) or (B, Cout, N).
         w_frag + wide_plan: the same weights in fragment order (pack_frag_major) and the balanced tiles of the batch
         (conv_tile_plan(skip_lengths, N, halo=2, round_to=64)): the wide k = 3 GEMMs (bf16 in / out, Cin % 128 == 0,
-        Cout % 256 == 0, nothing but bias / ReLU in the epilogue) then run on dx_conv1d_wide '''
+        Cout % 256 == 0, nothing but bias / ReLU in the epilogue) then run on dx_conv1d_wide; w_frag alone with Cin = 128, k = 3:
+        the register-weights kernel loads its fragments from it (dx_conv1d_wfrag) '''
     H.require_gpu(x, w_packed)
     B, N, Cin = x.shape
     taps, Cout, Cin_w = w_packed.shape
@@ -103,11 +105,15 @@ def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, m
         assert not accumulate
         out = torch.empty((B, Cout, N) if transposed_out else (B, N, Cout), dtype=out_dtype, device=x.device)
     flags = (H.CONV_RELU if relu else 0) | (H.CONV_TRANSPOSED_OUT if transposed_out else 0) | (4 if accumulate else 0)
+    frag = None
+    if w_frag is not None and USE_WFRAG and taps == 3 and Cin == 128 and w_packed.dtype == torch.bfloat16:
+        assert w_frag.dtype == torch.bfloat16 and w_frag.numel() == w_packed.numel()
+        frag = w_frag                                 # register-weights kernel: fragments straight into registers (dx_conv1d_wfrag)
     with _probe('conv_gemm', lambda: 2. * B * N * Cin * Cout * taps, N):
-      H.check(H.lib().dx_conv1d(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(bias),
-                              H.ptr(out), H.dt(out), out.stride(1), H.ptr(relu_gate),
-                              H.dt(relu_gate) if relu_gate is not None else 0,
-                              H.ptr(mask_lengths), H.ptr(skip_lengths), B, N, Cin, Cout, taps, flags, H.stream()))
+      H.check(H.lib().dx_conv1d_wfrag(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(frag), H.ptr(bias),
+                                    H.ptr(out), H.dt(out), out.stride(1), H.ptr(relu_gate),
+                                    H.dt(relu_gate) if relu_gate is not None else 0,
+                                    H.ptr(mask_lengths), H.ptr(skip_lengths), B, N, Cin, Cout, taps, flags, H.stream()))
     return out
 
 
