@@ -759,7 +759,14 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
 #endif
   const int l31 = lane & 31, g = lane >> 5;
   const int ztiles = p.Cout / WR_BN, ptiles = dx_cdiv(p.N, BM);
-  const int grp = blockIdx.x / ztiles, co0 = (blockIdx.x % ztiles) * WR_BN + wave * 32;
+  // workgroup -> (position group, channel slice).  WR_ZMAJOR: slice-major, so that the ztiles workgroups of one position group sit
+  // 64 indices apart = on the SAME XCD (round-robin dispatch, ngrp % 8 == 0) and read their common activation tiles through one L2
+#ifndef WR_ZMAJOR
+#define WR_ZMAJOR 1
+#endif
+  const bool zmajor = WR_ZMAJOR && (ngrp % 8 == 0);
+  const int grp = zmajor ? (int)blockIdx.x % ngrp : (int)blockIdx.x / ztiles, zt = zmajor ? (int)blockIdx.x / ngrp : (int)blockIdx.x % ztiles;
+  const int co0 = zt * WR_BN + wave * 32;
   const int N = p.N, Cout = p.Cout;
   const TC* W = reinterpret_cast<const TC*>(p.w);
   TO* Y = reinterpret_cast<TO*>(p.y);
@@ -790,7 +797,7 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
       for (int ks = 0; ks < KSTEPS; ++ks)
         wreg[tap][ks] = *reinterpret_cast<const frag_t*>(wf + (size_t)((((ks >> 1) * TAPS + tap) << 1) + (ks & 1)) * fstride);
   } else {
-    const int cblk = (blockIdx.x % ztiles) * WR_BN;
+    const int cblk = zt * WR_BN;
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const TC* src = W + ((size_t)tap * Cout + cblk) * CIN;
@@ -1036,7 +1043,7 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
 #endif
   // ---- dead tiles (start past length + conv halo): zeros, no reads; split evenly like the live ones
   if (p.skip_len) {
-    const int cblk = (blockIdx.x % ztiles) * WR_BN;
+    const int cblk = zt * WR_BN;
     const int dead = ptiles * p.B - total;
     const int j0 = (int)((long)dead * grp / ngrp), j1 = (int)((long)dead * (grp + 1) / ngrp);
     int db = 0, dpt = 0, cum = 0;
