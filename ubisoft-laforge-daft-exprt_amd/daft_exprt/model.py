@@ -199,6 +199,8 @@ class DaftExprt(nn.Module):
         self._wgrad_batch_rows = int(__import__('os').environ.get('DX_WGRAD_BATCH_ROWS', '1000000000'))   # GEMMs with fewer rows wait for the block's flush (measured: always waiting is best, 8.35 vs 8.42 ms)
         self._wgrad_flush_blocks = int(__import__('os').environ.get('DX_WGRAD_FLUSH_BLOCKS', '1'))   # FFT blocks per flush
         self._blocks_since_flush = 0
+        self._hold_flush = False
+        self._wgrad_hold_dec = int(__import__('os').environ.get('DX_WGRAD_HOLD_DEC', '0'))   # weight gradients of the decoder's last K blocks wait for the end of the decoder's backward pass (they then run under the phoneme-level stretch)
         self._wgrad_defer_rows = int(__import__('os').environ.get('DX_WGRAD_DEFER_ROWS', '0'))   # see _block_done (0: never defer; 16384 measured 7.99 vs 7.79 ms)
         self._wgrad_ws = None
         self._hop = None
@@ -704,7 +706,7 @@ class DaftExprt(nn.Module):
             launches, but deferring them is WORSE (7.99 vs 7.79 ms): the phoneme-level kernels of the main stream leave most of the
             chip idle, which is exactly where the weight gradients run for free; deferred, they land on the frame-level kernels of
             the prosody encoder instead '''
-        if rows < self._wgrad_defer_rows:
+        if rows < self._wgrad_defer_rows or self._hold_flush:
             return
         self._blocks_since_flush += 1
         if self._blocks_since_flush >= self._wgrad_flush_blocks:
@@ -737,14 +739,18 @@ class DaftExprt(nn.Module):
             # the host than two record_stream calls per launch; the small-N encoder blocks are host-bound)
             self._wgrad_keep.append((dy, x))
 
-    def _fft_stack_bwd(self, W, blocks, du, dfilms):
-        ''' backward through a stack of FFT blocks, top block first.  dfilms: (B, nb_blocks, 2C) gradient view or None '''
+    def _fft_stack_bwd(self, W, blocks, du, dfilms, hold=0):
+        ''' backward through a stack of FFT blocks, top block first.  dfilms: (B, nb_blocks, 2C) gradient view or None.
+            hold: the weight gradients of the LAST `hold` blocks of the walk (blocks hold-1 .. 0) stay queued until the caller's
+            next flush (`done()`): see DX_WGRAD_HOLD_DEC '''
         pre = None
         for blk in reversed(range(len(blocks))):
             below = blocks[blk - 1] if blk > 0 else None
             dfilm = dfilms[:, blk, :] if dfilms is not None else None
             dfilm_below = dfilms[:, blk - 1, :] if (dfilms is not None and blk > 0) else None
+            self._hold_flush = blk < hold
             du, pre = self._fft_block_bwd(W, blocks[blk], du, dfilm, pre, below, dfilm_below)
+        self._hold_flush = False
         return du
 
     def _fft_block_bwd(self, W, s, du, dfilm, pre=None, below=None, dfilm_below=None):
@@ -885,7 +891,7 @@ class DaftExprt(nn.Module):
             self._wgrad(d_mel_bt, dec_x, G[f'{wname}.weight'], G[f'{wname}.bias'], S.gu.output_lengths)
             self._flush_wgrads()
             d_dec = ops.conv1d(d_mel_bt, W[f'T:{wname}.weight'], None, out_dtype=torch.float32, skip_lengths=S.gu.output_lengths)
-        d_dec = self._fft_stack_bwd(W, blocks, d_dec, dfilms[2])
+        d_dec = self._fft_stack_bwd(W, blocks, d_dec, dfilms[2], hold=self._wgrad_hold_dec)
         done('frame_decoder')
         # ---- Gaussian upsampling (ground-truth durations / energy / pitch: no gradient into the predictor here)
         g = S.gu
