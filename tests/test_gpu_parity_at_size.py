@@ -369,7 +369,7 @@ def test_c5_long_utterance_batch_matches_oracle_slice(mode):
     from daft_exprt import ops
     t0, g0, m0 = step()
     t1, g1, m1 = step()
-    assert torch.equal(m0, m1) and torch.allclose(t0, t1, rtol=1e-6, atol=0.)
+    assert torch.equal(m0, m1) and torch.allclose(t0, t1, rtol=1e-5, atol=0.)      # (loss sums: block partials meet in fp32 atomics)
     assert float((g0 - g1).norm()) <= 2e-4 * float(g0.norm())
     ops.USE_SPLITK = False            # (the phoneme-level GEMMs of this batch fit one round of tiles and take the split-K kernel: other sums)
     try:
