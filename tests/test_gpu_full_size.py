@@ -93,7 +93,7 @@ def test_balanced_tiles_match_fixed_tiles_at_full_size():
         d, scale = (a.float() - b.float()).abs(), max(1., float(b.float().abs().max()))
         assert float(d.mean()) <= 1e-2 * scale and float(d.max()) <= 0.3 * scale, (float(d.mean()), float(d.max()), scale)
     assert float((ts - t0).abs().max()) <= 2e-2 * float(t0.abs().max())
-    assert torch.allclose(t0, t1, rtol=1e-6, atol=0.)
+    assert torch.allclose(t0, t1, rtol=1e-5, atol=0.)
     gn = float(g0.norm())
     assert float((g0 - g1).norm()) <= 2e-4 * gn, float((g0 - g1).norm()) / gn
 
