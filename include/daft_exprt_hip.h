@@ -85,12 +85,16 @@ int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_packed, int
  *   dgamma += sum g * xhat, dbeta += sum g;  ds = rstd * (g*gamma - mean_c(g*gamma) - xhat * mean_c(g*gamma*xhat))
  *   y_inout <- ds (fp32, the residual gradient that flows on);  dx_pre_lp <- dropout_pre(ds) as bf16 (MFMA operand of the
  *   previous layer's data / weight gradient).   s_in / mean / rstd: saved by dx_conv1d_ln / dx_layernorm_fwd.
- * Cout is 128 by construction.  lengths also drives the padding early-out (rows >= lengths[b] + 2 stay zero). */
+ * Cout is 128 by construction.  lengths also drives the padding early-out (rows >= lengths[b] + 2 stay zero).
+ * y2 (NULL = off; bf16 (B, N, 128)) with w2_packed (bf16 [1][128][128], forward packing of the map to apply): y2 = dx_pre_lp . w2^T,
+ * the 128 -> 128 linear layer whose data gradient consumes dx_pre_lp next (the attention output projection, model.py:182-186),
+ * computed by the epilogue from the rows it has just produced instead of by a launch of its own; needs the split-K path (bf16,
+ * taps = 3, plan + w_frag, Cin % 128 == 0, B * N <= 65536: DX_ERR_UNSUPPORTED otherwise).  Same values as dx_conv1d on dx_pre_lp. */
 int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, float* y_inout,
                     const float* s_in, const float* mean, const float* rstd, const float* gamma, const float* beta,
                     const float* film, long ldf, const int64_t* lengths, void* dx_pre_lp, float* dgamma, float* dbeta,
                     float* dfilm, long lddf, int B, int N, int Cin, int taps, float p_pre, uint64_t seed_pre,
-                    const int* plan, int plan_tiles, const void* w_frag, void* stream);
+                    const int* plan, int plan_tiles, const void* w_frag, const void* w2_packed, void* y2, void* stream);
 
 /* The weights of a k = 3 conv in MFMA-fragment order: out[chunk][tap][half][block][lane][8] = w_packed[tap][32 block + (lane & 31)]
  * [32 chunk + 16 half + 8 (lane >> 5) + 0..7], block < Cout / 32; w_packed = the [3][Cout][Cin] bf16 packing of dx_pack_conv_weight

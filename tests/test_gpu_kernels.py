@@ -430,6 +430,24 @@ def test_splitk_conv_ln_and_lnbwd_match_ring_kernel_and_fp32_reference(film, len
         assert float(((r[0][k] - r[1][k]) * valid).abs().max()) <= tol * max(1., float((r[0][k] * valid).abs().max())), k
     for k in (2, 3) + ((4,) if film else ()):
         assert float((r[0][k] - r[1][k]).abs().max()) <= 1e-3 * float(r[0][k].abs().max()) + 1e-4, k
+    # second GEMM in the epilogue (y2 = dx . w2^T, the output-projection data gradient): the launch's own dx through dx_conv1d,
+    # bit for bit (same bf16 operands, one 128-term fp32 MFMA chain per output either way), zeros on the padding rows; nothing
+    # else of the launch changes
+    w2 = ops.pack_conv_weight((torch.randn(128, 128, generator=g) / 128 ** 0.5).to(DEV), torch.bfloat16, transpose_flip=True)
+    y = gin.clone()
+    dg, db = torch.zeros(128, device=DEV), torch.zeros(128, device=DEV)
+    df = torch.zeros(B, 256, device=DEV) if film else None
+    y2_buf = torch.full((B, N, 128), float('nan'), dtype=torch.bfloat16, device=DEV)   # (the caching allocator hands the kernel whatever is there)
+    del y2_buf
+    dx2, y2 = ops.conv1d_lnbwd(x, wpt, y, s_in, mean, rstd, gamma, beta, lens, dg, db, film=fl, dfilm=df, p_pre=0.1, seed_pre=4, plan=plan,
+                               w_frag=wft, w2_packed=w2)
+    assert torch.equal(y, r[1][0]) and torch.equal(dx2.float(), r[1][1])
+    ref2 = ops.conv1d(dx2, w2, None, out_dtype=torch.bfloat16, skip_lengths=lens)
+    assert torch.isfinite(y2.float()).all() and float((y2.float() * ~valid).abs().max()) == 0.
+    assert float(((y2.float() - ref2.float()) * valid).abs().max()) <= 1e-2 * float(ref2.float().abs().max())
+    dxr, y2r = ops.conv1d_lnbwd(x, wpt, gin.clone(), s_in, mean, rstd, gamma, beta, lens, torch.zeros(128, device=DEV), torch.zeros(128, device=DEV),
+                                film=fl, dfilm=torch.zeros(B, 256, device=DEV) if film else None, p_pre=0.1, seed_pre=4, plan=plan, w2_packed=w2)
+    assert float(((y2r.float() - ref2.float()) * valid).abs().max()) <= 5e-2 * float(ref2.float().abs().max())   # no fragment copy: separate launch
 
 
 @pytest.mark.parametrize('B,N,cin', [(1, 5, 256), (300, 40, 128), (70, 130, 1024)])

@@ -41,6 +41,7 @@ struct LNEpi {
   float p_pre; uint64_t seed_pre;
   int enabled;
   float* dgamma; float* dbeta; float* dfilm; long lddf;
+  const void* w2; void* y2;   // backward variant on the split-K kernel: y2 = y_lp . w2^T, a 128 -> 128 k = 1 GEMM on the rows the epilogue has just produced
 };
 
 struct ConvArgs {
@@ -1312,6 +1313,20 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
       for (int e2 = 0; e2 < 8; ++e2) csum[q][e2] = 0.f;
     const int cb = 2 * wc + wk;
     const float bv = p.bias ? p.bias[cb * 32 + l31] : 0.f;
+    // second GEMM of the backward variant (LayerNorm backward -> output-projection data gradient, model.py:182-186): the rows this
+    // epilogue writes as y_lp are the operand of a 128 -> 128 k = 1 GEMM that used to be the next launch (18 us for 3 us of work).
+    // Weights as the A operand (wave = 32 output channels, its 8 fragments in registers), the 64 freshly written rows as B from an
+    // LDS image beside the staging buffer: D[channel][row], a lane owns one row and 4 x 4 consecutive channels (8-byte stores).
+    constexpr int A2_LD = BN + 8, A2_OFF = 64 * 1024;
+    static_assert(A2_OFF >= STG_BYTES && A2_OFF + 64 * A2_LD * 2 <= SMEM_BYTES, "second-GEMM operand tile must fit beside the staging buffer");
+    const bool gemm2 = LN == 2 && p.ln.y2 != nullptr;
+    TC* a2 = reinterpret_cast<TC*>(smem + A2_OFF);
+    frag_t w2f[8];
+    if (gemm2) {
+      const TC* w2 = reinterpret_cast<const TC*>(p.ln.w2) + (size_t)(wave * 32 + l31) * BN + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) w2f[ks] = *reinterpret_cast<const frag_t*>(w2 + ks * 16);
+    }
 #pragma unroll
     for (int i = 0; i < MAXBLK / 2; ++i) {
       if (i * 64 >= h) break;                          // workgroup-uniform: the barriers below stay matched
@@ -1390,6 +1405,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
               for (int e2 = 0; e2 < 8; ++e2) v[e2] = dx_keep(key, (uint32_t)rowg * BN + cl + e2, th) ? v[e2] * sc : 0.f;
             }
             store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + offl, v);
+            if (gemm2) store8<bf16_t>(a2 + sr * A2_LD + cl, v);
           } else {              // fused LayerNorm: 16 lanes hold one complete 128-channel row
             if (p.ln.p_pre > 0.f) {
               const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(p.ln.seed_pre, 0);
@@ -1431,9 +1447,36 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
             store8<float>(p.ln.y + offl, v);
             if (p.ln.y_lp) store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + offl, v);
           }
+        } else if (LN == 2 && gemm2 && sr < 64) {      // rows outside the tile / the tensor: zeros in the operand image
+          const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          store8<bf16_t>(a2 + sr * A2_LD + cl, z8);
         }
       }
       __syncthreads();
+      if (LN == 2 && gemm2) {   // (the next iteration writes the image only behind its own barrier, i.e. after every wave has read it)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          f32x16 d2;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) d2[r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) {
+            const frag_t xr = *reinterpret_cast<const frag_t*>(a2 + (rb * 32 + l31) * A2_LD + ks * 16 + g * 8);
+            dx_mma(d2, w2f[ks], xr);
+          }
+          const int trow = i * 64 + rb * 32 + l31, n = n0 + trow;
+          if (trow < h && n < N) {
+            TC* yo = reinterpret_cast<TC*>(p.ln.y2) + ((size_t)b * N + n) * BN + wave * 32 + 4 * g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              bf16x4 o4;
+#pragma unroll
+              for (int e2 = 0; e2 < 4; ++e2) o4[e2] = (TC)d2[4 * j + e2];
+              *reinterpret_cast<bf16x4*>(yo + 8 * j) = o4;
+            }
+          }
+        }
+      }
     }
     if (LN == 2) {   // column sums: 16 row-threads per channel segment -> LDS -> one atomic per channel per workgroup
       for (int q = 0; q < NCS; ++q)
@@ -1479,6 +1522,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
           const size_t off = ((size_t)fb * N + n) * BN + cl;
           store8<float>(p.ln.y + off, z);
           if (LN == 2 || p.ln.y_lp) store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + off, z);
+          if (LN == 2 && p.ln.y2) store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y2) + off, z);
           if (LN == 1) {
             if (p.ln.s_out) store8<float>(p.ln.s_out + off, z);
             if (p.ln.mean && cl == 0) { p.ln.mean[(size_t)fb * N + n] = 0.f; p.ln.rstd[(size_t)fb * N + n] = 0.f; }
@@ -2672,7 +2716,8 @@ extern "C" int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void*
                                const float* s_in, const float* mean, const float* rstd, const float* gamma,
                                const float* beta, const float* film, long ldf, const int64_t* lengths, void* dx_pre_lp,
                                float* dgamma, float* dbeta, float* dfilm, long lddf, int B, int N, int Cin, int taps,
-                               float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, const void* w_frag, void* stream) {
+                               float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, const void* w_frag, const void* w2_packed,
+                               void* y2, void* stream) {
   if (int rc = plan_check("dx_conv1d_lnbwd", plan, plan_tiles, lengths, x_dtype, w_dtype, ldx, Cin, taps, B, N, true)) return rc;
   DX_REQUIRE(!w_frag || plan, DX_ERR_ARG, "dx_conv1d_lnbwd: fragment-order weights go with a tile plan");
   DX_REQUIRE(x && w_packed && y_inout && s_in && mean && rstd && gamma && beta && lengths && dx_pre_lp && dgamma && dbeta,
@@ -2686,6 +2731,12 @@ extern "C" int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void*
              LNEpi{gamma, beta, nullptr, film, ldf, y_inout, dx_pre_lp, const_cast<float*>(s_in), const_cast<float*>(mean),
                    const_cast<float*>(rstd), p_pre, seed_pre, 2, dgamma, dbeta, dfilm, lddf}};
   a.plan = plan; a.plan_tiles = plan_tiles; a.w_frag = w_frag;
+  if (y2) {   // second GEMM in the epilogue: only the split-K workgroups carry it (same gate as launch_taps)
+    DX_REQUIRE(w2_packed && plan && w_frag && taps == 3 && Cin >= 256 && Cin % 128 == 0 && (long)B * N <= 256L * 256 && w_dtype == DX_BF16 &&
+               x_dtype == DX_BF16, DX_ERR_UNSUPPORTED, "dx_conv1d_lnbwd: y2 needs the split-K path (bf16, taps = 3, plan + fragment-order weights, "
+               "Cin %% 128 == 0, B * N <= 65536)");
+    a.ln.w2 = w2_packed; a.ln.y2 = y2;
+  }
   { static int dbg = getenv("DX_PLAN_DEBUG") ? atoi(getenv("DX_PLAN_DEBUG")) : 0; a.flags |= dbg; }
   hipStream_t s = (hipStream_t)stream;
   if (w_dtype == DX_BF16 && x_dtype == DX_BF16) return launch_taps<bf16_t, bf16_t, float, float, 2>(a, B, taps, s);

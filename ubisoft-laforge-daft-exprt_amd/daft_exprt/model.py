@@ -775,11 +775,15 @@ class DaftExprt(nn.Module):
         dh = ops.conv1d(dz, W[f'T:{f_pre}.convs.2.conv.weight'], None, out_dtype=cd, relu_gate=s.h, skip_lengths=s.lengths,
                         w_frag=W.get(f'FT:{f_pre}.convs.2.conv.weight'))
         self._wgrad(dh, s.a, G[f'{f_pre}.convs.0.conv.weight'], G[f'{f_pre}.convs.0.conv.bias'], s.lengths)
+        mha = f'{a_pre}.multi_head_attention'
+        d_o = None
         if fuse:
-            dproj = ops.conv1d_lnbwd(dh, W[f'T:{f_pre}.convs.0.conv.weight'], da, s.s1, s.mean1, s.rstd1,
-                                     P[f'{a_pre}.layer_norm.weight'], P[f'{a_pre}.layer_norm.bias'], s.lengths,
-                                     G[f'{a_pre}.layer_norm.weight'], G[f'{a_pre}.layer_norm.bias'], p_pre=s.p_attn, seed_pre=s.seeds[1],
-                                     plan=self._plan(s.lengths, dh.shape[1]), w_frag=W.get(f'FT:{f_pre}.convs.0.conv.weight'))
+            # (+ the data gradient of the attention output projection, a 128 -> 128 linear map on the rows this launch produces)
+            dproj, d_o = ops.conv1d_lnbwd(dh, W[f'T:{f_pre}.convs.0.conv.weight'], da, s.s1, s.mean1, s.rstd1,
+                                          P[f'{a_pre}.layer_norm.weight'], P[f'{a_pre}.layer_norm.bias'], s.lengths,
+                                          G[f'{a_pre}.layer_norm.weight'], G[f'{a_pre}.layer_norm.bias'], p_pre=s.p_attn, seed_pre=s.seeds[1],
+                                          plan=self._plan(s.lengths, dh.shape[1]), w_frag=W.get(f'FT:{f_pre}.convs.0.conv.weight'),
+                                          w2_packed=W[f'T:{mha}.out_proj.weight'])
             ds1 = da
         else:
             ops.conv1d(dh, W[f'T:{f_pre}.convs.0.conv.weight'], None, out=da, accumulate=True, skip_lengths=s.lengths)
@@ -787,9 +791,9 @@ class DaftExprt(nn.Module):
                                            G[f'{a_pre}.layer_norm.weight'], G[f'{a_pre}.layer_norm.bias'], lengths=s.lengths,
                                            p_pre=s.p_attn, seed_pre=s.seeds[1], skip_lengths=s.lengths, lp_only=lp, separate=True)
         dx = ds1
-        mha = f'{a_pre}.multi_head_attention'
         self._wgrad(dproj, s.o, G[f'{mha}.out_proj.weight'], G[f'{mha}.out_proj.bias'], s.lengths)
-        d_o = ops.conv1d(dproj, W[f'T:{mha}.out_proj.weight'], None, out_dtype=cd, skip_lengths=s.lengths)
+        if d_o is None:
+            d_o = ops.conv1d(dproj, W[f'T:{mha}.out_proj.weight'], None, out_dtype=cd, skip_lengths=s.lengths)
         dqkv = ops.attention_bwd(s.qkv, s.o, d_o, s.lse, s.lengths, s.cfg['attn_nb_heads'], s.p_attn, s.seeds[0], order=self._order(s.lengths))
         self._wgrad(dqkv, s.x, G[f'{mha}.in_proj_weight'], G[f'{mha}.in_proj_bias'], s.lengths)
         if fuse and below is not None:

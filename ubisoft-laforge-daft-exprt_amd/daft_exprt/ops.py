@@ -139,23 +139,38 @@ def conv1d_ln(x, w_packed, bias, residual, gamma, beta, lengths, film=None, save
     return y, y_lp, s_out, mean, rstd
 
 
+USE_GEMM2 = bool(int(os.environ.get('DX_LNBWD_GEMM2', '1')))   # 0: the output-projection data gradient stays a launch of its own (A/B switch)
+
+
 def conv1d_lnbwd(x, w_packed, y_inout, s_in, mean, rstd, gamma, beta, lengths, dgamma, dbeta, film=None, dfilm=None,
-                 p_pre=0., seed_pre=0, plan=None, w_frag=None):
+                 p_pre=0., seed_pre=0, plan=None, w_frag=None, w2_packed=None):
     ''' data gradient of a conv / linear into a 128-channel residual stream + the backward of the LayerNorm that consumed
         that stream, one launch (see dx_conv1d_lnbwd).  y_inout (B, N, 128) fp32: residual gradient in, ds out (in place).
-        Returns the bf16 dropout_pre(ds).  dgamma / dbeta / dfilm accumulate. '''
+        Returns the bf16 dropout_pre(ds) -- and, with w2_packed (bf16 (1, 128, 128): the packed weight of the 128 -> 128 linear map
+        to apply to it), the pair (dropout_pre(ds), conv1d(dropout_pre(ds), w2_packed)): the second product comes out of the same
+        launch when the split-K path takes it, else from a conv1d call.  dgamma / dbeta / dfilm accumulate. '''
     B, N, Cin = x.shape
     taps, Cout, _ = w_packed.shape
     assert Cout == 128 and x.stride(2) == 1 and y_inout.is_contiguous() and y_inout.dtype == torch.float32
     dx_lp = torch.empty((B, N, 128), dtype=torch.bfloat16, device=x.device)
     ldf = film.stride(0) if film is not None else 0
     lddf = dfilm.stride(0) if dfilm is not None else 0
-    with _probe('conv_gemm', lambda: 2. * B * N * Cin * Cout * taps, N):
+    pargs = _plan_args(plan, x, w_packed, B, N, k1_ok=True, w_frag=w_frag)
+    y2 = None
+    if (w2_packed is not None and USE_GEMM2 and pargs[2] is not None and taps == 3 and Cin % 128 == 0 and B * N <= 65536
+            and w2_packed.dtype == torch.bfloat16 and tuple(w2_packed.shape) == (1, 128, 128)):
+        y2 = torch.empty((B, N, 128), dtype=torch.bfloat16, device=x.device)
+    with _probe('conv_gemm', lambda: 2. * B * N * Cin * Cout * taps + (2. * B * N * 128 * 128 if y2 is not None else 0.), N):
         H.check(H.lib().dx_conv1d_lnbwd(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(y_inout), H.ptr(s_in),
                                         H.ptr(mean), H.ptr(rstd), H.ptr(gamma), H.ptr(beta), H.ptr(film), ldf, H.ptr(lengths),
                                         H.ptr(dx_lp), H.ptr(dgamma), H.ptr(dbeta), H.ptr(dfilm), lddf, B, N, Cin, taps,
-                                        float(p_pre), int(seed_pre), *_plan_args(plan, x, w_packed, B, N, k1_ok=True, w_frag=w_frag), H.stream()))
-    return dx_lp
+                                        float(p_pre), int(seed_pre), *pargs, H.ptr(w2_packed if y2 is not None else None), H.ptr(y2),
+                                        H.stream()))
+    if w2_packed is None:
+        return dx_lp
+    if y2 is None:
+        y2 = conv1d(dx_lp, w2_packed, None, out_dtype=dx_lp.dtype, skip_lengths=lengths)
+    return dx_lp, y2
 
 
 def conv_tile_plan(lengths, N, halo=0, round_to=None, tiles=None):
