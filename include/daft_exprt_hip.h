@@ -70,12 +70,14 @@ int dx_conv1d_wfrag(const void* x, int x_dtype, long ldx, const void* w_packed, 
  *   y = 0 where n >= lengths[b]
  * i.e. the attention out-projection + Dropout + residual + LayerNorm + mask (model.py:186-191, 259) and the second FF conv
  * + Dropout + residual + LayerNorm + FiLM + mask (model.py:226-235, 262) in one launch.  Outputs: y fp32, y_lp optional
- * bf16 copy, s_out / mean / rstd for dx_layernorm_bwd (NULL at inference).  lengths also drives the padding early-out. */
+ * bf16 copy, s_out / mean / rstd for dx_layernorm_bwd (NULL at inference).  lengths also drives the padding early-out.  * y2 (NULL = off; bf16 (B, N, n2), n2 = 128 or 384) with w2_packed (bf16 [1][n2][128]) and b2 (fp32 (n2) or NULL):
+ * y2 = y_lp . w2^T + b2, the k = 1 projection that reads this LayerNorm's output next (the QKV projection of the following FFT
+ * block, model.py:165-171), computed by the epilogue from the rows it has just normalised; split-K path only (see dx_conv1d_lnbwd). */
 int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const float* bias,
                  const float* residual, const float* gamma, const float* beta, const float* film, long ldf,
                  const int64_t* lengths, float* y, void* y_lp, float* s_out, float* mean, float* rstd, int B, int N,
                  int Cin, int taps, float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, const void* w_frag,
-                 void* stream);
+                 const void* w2_packed, const float* b2, void* y2, int n2, void* stream);
 
 /* Data gradient of a conv / linear INTO a 128-channel residual stream, fused with the BACKWARD of the LayerNorm that
  * consumed that stream in the forward pass (autograd of model.py:189-191 resp. 226-235 + 259/262, i.e. what

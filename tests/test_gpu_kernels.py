@@ -408,6 +408,24 @@ def test_splitk_conv_ln_and_lnbwd_match_ring_kernel_and_fp32_reference(film, len
         assert float((b_ * ~m).abs().max()) == 0., name                     # padding rows are zeros
         tol = 2e-2 if name == 'y_lp' else 2e-4
         assert float(((a - b_) * m).abs().max()) <= tol * max(1., float((a * m).abs().max())), (name, float(((a - b_) * m).abs().max()))
+    # second GEMM in the forward epilogue (the next block's QKV projection): y2 = y_lp . w2^T + b2 from the same launch == dx_conv1d
+    # on the launch's own y_lp; the five regular outputs unchanged bit for bit; padding rows of y2 zero
+    for n2 in (384, 128):
+        w2 = ops.pack_conv_weight((torch.randn(n2, 128, generator=g) / 128 ** 0.5).to(DEV), torch.bfloat16)
+        b2 = torch.randn(n2, generator=g).to(DEV)
+        out6 = ops.conv1d_ln(x, wp, bias, res, gamma, beta, lens, film=fl, save=True, p_pre=0.1, seed_pre=9, lp_copy=True, plan=plan, w_frag=wf,
+                             w2_packed=w2, b2=b2)
+        assert len(out6) == 6 and out6[5] is not None and out6[5].shape == (B, N, n2)
+        for a, b_ in zip(out6[:5], sk):
+            assert torch.equal(a, b_)
+        ref2 = ops.conv1d(out6[1], w2, b2, out_dtype=torch.bfloat16, skip_lengths=lens).float()
+        y2 = out6[5].float()
+        assert torch.isfinite(y2).all()
+        live = n_idx < lens[:, None, None] + 2           # (rows in [len, len + 2) of a live tile: bias, like dx_conv1d; dead rows: zeros)
+        assert float(((y2 - ref2) * valid).abs().max()) <= 1e-2 * float(ref2.abs().max())
+        assert float((y2 * ~live).abs().max()) <= float(b2.abs().max()) + 1e-3
+    assert ops.conv1d_ln(x, wp, bias, res, gamma, beta, lens, film=fl, save=True, p_pre=0.1, seed_pre=9, lp_copy=True, plan=plan, w2_packed=w2,
+                         b2=b2)[5] is None               # no fragment-order weights -> ring kernel: the caller launches the projection
     # s = dropout(conv) + residual with p = 0: the plain conv against torch on the bf16-rounded operands
     s0 = ops.conv1d_ln(x, wp, bias, res, gamma, beta, lens, film=fl, save=True, lp_copy=True, plan=plan, w_frag=wf)[2]
     ref = torch.nn.functional.conv1d(x.float().transpose(1, 2), w.to(torch.bfloat16).float(), bias, padding=1).transpose(1, 2) + res

@@ -41,7 +41,8 @@ struct LNEpi {
   float p_pre; uint64_t seed_pre;
   int enabled;
   float* dgamma; float* dbeta; float* dfilm; long lddf;
-  const void* w2; void* y2;   // backward variant on the split-K kernel: y2 = y_lp . w2^T, a 128 -> 128 k = 1 GEMM on the rows the epilogue has just produced
+  const void* w2; void* y2;   // split-K kernel: y2 = y_lp . w2^T (+ b2), a 128 -> n2 k = 1 GEMM on the rows the epilogue has just produced
+  const float* b2; int n2;    // (n2 = 128: output-projection data gradient behind the LayerNorm backward; 384: the next block's QKV projection)
 };
 
 struct ConvArgs {
@@ -1317,15 +1318,22 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
     // epilogue writes as y_lp are the operand of a 128 -> 128 k = 1 GEMM that used to be the next launch (18 us for 3 us of work).
     // Weights as the A operand (wave = 32 output channels, its 8 fragments in registers), the 64 freshly written rows as B from an
     // LDS image beside the staging buffer: D[channel][row], a lane owns one row and 4 x 4 consecutive channels (8-byte stores).
-    constexpr int A2_LD = BN + 8, A2_OFF = 64 * 1024;
+    // The forward variant does the same with the NEXT block's QKV projection (128 -> 384, model.py:165-171): three channel blocks per
+    // wave, bias added in the store.
+    constexpr int A2_LD = BN + 8, A2_OFF = 64 * 1024, NC2 = LN == 2 ? 1 : 3;
     static_assert(A2_OFF >= STG_BYTES && A2_OFF + 64 * A2_LD * 2 <= SMEM_BYTES, "second-GEMM operand tile must fit beside the staging buffer");
-    const bool gemm2 = LN == 2 && p.ln.y2 != nullptr;
+    const bool gemm2 = p.ln.y2 != nullptr;
+    const int n2 = p.ln.n2, ncb2 = __builtin_amdgcn_readfirstlane(n2 >> 7);      // channel blocks per wave (1 or 3)
     TC* a2 = reinterpret_cast<TC*>(smem + A2_OFF);
-    frag_t w2f[8];
+    frag_t w2f[NC2][8];
     if (gemm2) {
-      const TC* w2 = reinterpret_cast<const TC*>(p.ln.w2) + (size_t)(wave * 32 + l31) * BN + g * 8;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) w2f[ks] = *reinterpret_cast<const frag_t*>(w2 + ks * 16);
+      for (int c = 0; c < NC2; ++c)
+        if (c < ncb2) {
+          const TC* w2 = reinterpret_cast<const TC*>(p.ln.w2) + (size_t)((c * 4 + wave) * 32 + l31) * BN + g * 8;
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) w2f[c][ks] = *reinterpret_cast<const frag_t*>(w2 + ks * 16);
+        }
     }
 #pragma unroll
     for (int i = 0; i < MAXBLK / 2; ++i) {
@@ -1446,33 +1454,41 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
             }
             store8<float>(p.ln.y + offl, v);
             if (p.ln.y_lp) store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + offl, v);
+            if (gemm2) store8<bf16_t>(a2 + sr * A2_LD + cl, v);
           }
-        } else if (LN == 2 && gemm2 && sr < 64) {      // rows outside the tile / the tensor: zeros in the operand image
+        } else if (gemm2) {                            // rows outside the tile / the tensor: zeros in the operand image
           const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           store8<bf16_t>(a2 + sr * A2_LD + cl, z8);
         }
       }
       __syncthreads();
-      if (LN == 2 && gemm2) {   // (the next iteration writes the image only behind its own barrier, i.e. after every wave has read it)
+      if (gemm2) {   // (the next iteration writes the image only behind its own barrier, i.e. after every wave has read it)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-          f32x16 d2;
+        for (int c = 0; c < NC2; ++c) {
+          if (c >= ncb2) break;
+          const int co2 = (c * 4 + wave) * 32 + 4 * g;            // this lane's channels: co2 + 8 j + 0..3
 #pragma unroll
-          for (int r = 0; r < 16; ++r) d2[r] = 0.f;
+          for (int rb = 0; rb < 2; ++rb) {
+            f32x16 d2;
 #pragma unroll
-          for (int ks = 0; ks < 8; ++ks) {
-            const frag_t xr = *reinterpret_cast<const frag_t*>(a2 + (rb * 32 + l31) * A2_LD + ks * 16 + g * 8);
-            dx_mma(d2, w2f[ks], xr);
-          }
-          const int trow = i * 64 + rb * 32 + l31, n = n0 + trow;
-          if (trow < h && n < N) {
-            TC* yo = reinterpret_cast<TC*>(p.ln.y2) + ((size_t)b * N + n) * BN + wave * 32 + 4 * g;
+            for (int r = 0; r < 16; ++r) d2[r] = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              bf16x4 o4;
+            for (int ks = 0; ks < 8; ++ks) {
+              const frag_t xr = *reinterpret_cast<const frag_t*>(a2 + (rb * 32 + l31) * A2_LD + ks * 16 + g * 8);
+              dx_mma(d2, w2f[c][ks], xr);
+            }
+            const int trow = i * 64 + rb * 32 + l31, n = n0 + trow;
+            if (trow < h && n < N) {
+              TC* yo = reinterpret_cast<TC*>(p.ln.y2) + ((size_t)b * N + n) * n2 + co2;
 #pragma unroll
-              for (int e2 = 0; e2 < 4; ++e2) o4[e2] = (TC)d2[4 * j + e2];
-              *reinterpret_cast<bf16x4*>(yo + 8 * j) = o4;
+              for (int j = 0; j < 4; ++j) {
+                f32x4 bj = {0.f, 0.f, 0.f, 0.f};
+                if (p.ln.b2) bj = *reinterpret_cast<const f32x4*>(p.ln.b2 + co2 + 8 * j);
+                bf16x4 o4;
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) o4[e2] = (TC)(d2[4 * j + e2] + bj[e2]);
+                *reinterpret_cast<bf16x4*>(yo + 8 * j) = o4;
+              }
             }
           }
         }
@@ -1517,12 +1533,18 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
         const int fb = base + src_lane;
         const int first = __shfl(N - dead + (int)(fs - ustart), src_lane, 64), cntr = __shfl((int)(fe - fs), src_lane, 64);
         float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.ln.y2) {                                   // rows of the second GEMM's output (n2 channels, bf16)
+          const int segs = p.ln.n2 >> 3;
+          for (int c = tid; c < cntr * segs; c += SK_THREADS) {
+            const int n = first + c / segs, cl = (c % segs) * 8;
+            store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y2) + ((size_t)fb * N + n) * p.ln.n2 + cl, z);
+          }
+        }
         for (int c = tid; c < cntr * (BN / 8); c += SK_THREADS) {
           const int n = first + (c >> 4), cl = (c & 15) * 8;
           const size_t off = ((size_t)fb * N + n) * BN + cl;
           store8<float>(p.ln.y + off, z);
           if (LN == 2 || p.ln.y_lp) store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + off, z);
-          if (LN == 2 && p.ln.y2) store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y2) + off, z);
           if (LN == 1) {
             if (p.ln.s_out) store8<float>(p.ln.s_out + off, z);
             if (p.ln.mean && cl == 0) { p.ln.mean[(size_t)fb * N + n] = 0.f; p.ln.rstd[(size_t)fb * N + n] = 0.f; }
@@ -2691,7 +2713,7 @@ extern "C" int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_
                             const float* residual, const float* gamma, const float* beta, const float* film, long ldf,
                             const int64_t* lengths, float* y, void* y_lp, float* s_out, float* mean, float* rstd, int B, int N,
                             int Cin, int taps, float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, const void* w_frag,
-                            void* stream) {
+                            const void* w2_packed, const float* b2, void* y2, int n2, void* stream) {
   DX_REQUIRE(x && w_packed && residual && gamma && beta && y, DX_ERR_ARG, "dx_conv1d_ln: null pointer");
   DX_REQUIRE(!w_frag || plan, DX_ERR_ARG, "dx_conv1d_ln: fragment-order weights go with a tile plan");
   if (int rc = plan_check("dx_conv1d_ln", plan, plan_tiles, lengths, x_dtype, w_dtype, ldx, Cin, taps, B, N)) return rc;
@@ -2703,6 +2725,12 @@ extern "C" int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_
   ConvArgs a{x, ldx, w_packed, bias, nullptr, BN, nullptr, lengths, lengths, N, Cin, BN, 0, B,
              LNEpi{gamma, beta, residual, film, ldf, y, y_lp, s_out, mean, rstd, p_pre, seed_pre, 1}};
   a.plan = plan; a.plan_tiles = plan_tiles; a.w_frag = w_frag;
+  if (y2) {   // second GEMM in the epilogue (the next block's QKV projection): only the split-K workgroups carry it (gate of launch_taps)
+    DX_REQUIRE(w2_packed && (n2 == 128 || n2 == 384) && plan && w_frag && taps == 3 && Cin >= 256 && Cin % 128 == 0 && (long)B * N <= 256L * 256 &&
+               w_dtype == DX_BF16 && x_dtype == DX_BF16, DX_ERR_UNSUPPORTED, "dx_conv1d_ln: y2 needs n2 in {128, 384} and the split-K path (bf16, "
+               "taps = 3, plan + fragment-order weights, Cin %% 128 == 0, B * N <= 65536)");
+    a.ln.w2 = w2_packed; a.ln.y2 = y2; a.ln.b2 = b2; a.ln.n2 = n2;
+  }
   { static int dbg = getenv("DX_PLAN_DEBUG") ? atoi(getenv("DX_PLAN_DEBUG")) : 0; a.flags |= dbg; }
   hipStream_t s = (hipStream_t)stream;
   if (w_dtype == DX_BF16 && x_dtype == DX_BF16) return launch_taps<bf16_t, bf16_t, float, float, 1>(a, B, taps, s);
@@ -2735,7 +2763,7 @@ extern "C" int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void*
     DX_REQUIRE(w2_packed && plan && w_frag && taps == 3 && Cin >= 256 && Cin % 128 == 0 && (long)B * N <= 256L * 256 && w_dtype == DX_BF16 &&
                x_dtype == DX_BF16, DX_ERR_UNSUPPORTED, "dx_conv1d_lnbwd: y2 needs the split-K path (bf16, taps = 3, plan + fragment-order weights, "
                "Cin %% 128 == 0, B * N <= 65536)");
-    a.ln.w2 = w2_packed; a.ln.y2 = y2;
+    a.ln.w2 = w2_packed; a.ln.y2 = y2; a.ln.b2 = nullptr; a.ln.n2 = BN;
   }
   { static int dbg = getenv("DX_PLAN_DEBUG") ? atoi(getenv("DX_PLAN_DEBUG")) : 0; a.flags |= dbg; }
   hipStream_t s = (hipStream_t)stream;

@@ -501,10 +501,12 @@ class DaftExprt(nn.Module):
             [mel, output_lengths], weights
 
     # ------------------------------------------------------------------ forward building blocks
-    def _fft_block_fwd(self, W, pre, x, film, lengths, cfg, train, save, x_lp=None):
+    def _fft_block_fwd(self, W, pre, x, film, lengths, cfg, train, save, x_lp=None, qkv=None, next_pre=None):
         ''' one FFT block (`model.py:251-264`).  In bf16 mode the LayerNorm kernels also emit bf16 copies of their
             outputs (`*_lp`): they are what the following GEMMs read (half the bytes, no in-kernel conversion) --
-            numerically identical to casting at operand-load time.  Returns (u, u_lp, saved). '''
+            numerically identical to casting at operand-load time.  qkv: this block's QKV projection when the block below has
+            already computed it (in the epilogue of its last launch); next_pre: the block above, whose QKV projection this block's
+            last launch computes when it can.  Returns (u, u_lp, saved, qkv of the next block or None). '''
         P, cd = self._P, self.cd
         lp = cd == torch.bfloat16
         a_pre, f_pre = f'{pre}.attention', f'{pre}.feed_forward'
@@ -513,8 +515,9 @@ class DaftExprt(nn.Module):
         s = _Saved() if save else None
         seeds = [self._seed() for _ in range(3)]
         xin = x_lp if x_lp is not None else x
-        qkv = ops.conv1d(xin, W[f'{a_pre}.multi_head_attention.in_proj_weight'], P[f'{a_pre}.multi_head_attention.in_proj_bias'],
-                         out_dtype=cd, skip_lengths=lengths)
+        if qkv is None:
+            qkv = ops.conv1d(xin, W[f'{a_pre}.multi_head_attention.in_proj_weight'], P[f'{a_pre}.multi_head_attention.in_proj_bias'],
+                             out_dtype=cd, skip_lengths=lengths)
         o, lse = ops.attention_fwd(qkv, lengths, cfg['attn_nb_heads'], p_attn, seeds[0], need_lse=save, order=self._order(lengths))
         # out-projection + Dropout + residual + LayerNorm + mask in ONE launch (the GEMM tile holds complete 128-ch rows)
         a, a_lp, s1, mean1, rstd1 = ops.conv1d_ln(o, W[f'{a_pre}.multi_head_attention.out_proj.weight'],
@@ -525,17 +528,19 @@ class DaftExprt(nn.Module):
         h = ops.conv1d(ain, W[f'{f_pre}.convs.0.conv.weight'], P[f'{f_pre}.convs.0.conv.bias'], out_dtype=cd, relu=True,
                        skip_lengths=lengths, w_frag=W.get(f'F:{f_pre}.convs.0.conv.weight'))
         # second FF conv + Dropout + residual + LayerNorm + FiLM + mask in ONE launch
-        u, u_lp, s2, mean2, rstd2 = ops.conv1d_ln(h, W[f'{f_pre}.convs.2.conv.weight'], P[f'{f_pre}.convs.2.conv.bias'], a,
-                                                  P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'], lengths, film=film,
-                                                  save=save, p_pre=p_conv, seed_pre=seeds[2], lp_copy=lp, plan=self._plan(lengths, x.shape[1]),
-                                                  w_frag=W.get(f'F:{f_pre}.convs.2.conv.weight'))
+        nmha = f'{next_pre}.attention.multi_head_attention' if (next_pre is not None and lp) else None
+        u, u_lp, s2, mean2, rstd2, qkv_next = ops.conv1d_ln(
+            h, W[f'{f_pre}.convs.2.conv.weight'], P[f'{f_pre}.convs.2.conv.bias'], a, P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'],
+            lengths, film=film, save=save, p_pre=p_conv, seed_pre=seeds[2], lp_copy=lp, plan=self._plan(lengths, x.shape[1]),
+            w_frag=W.get(f'F:{f_pre}.convs.2.conv.weight'), w2_packed=W[f'{nmha}.in_proj_weight'] if nmha else None,
+            b2=P[f'{nmha}.in_proj_bias'] if nmha else None) + ((None,) if nmha is None else ())
         if save:
             s.pre, s.cfg, s.x, s.film, s.lengths = pre, cfg, xin, film, lengths
             s.qkv, s.o, s.lse, s.s1, s.mean1, s.rstd1, s.a, s.h, s.s2, s.mean2, s.rstd2 = qkv, o, lse, s1, mean1, rstd1, ain, h, s2, mean2, rstd2
             s.seeds, s.p_attn, s.p_conv = seeds, p_attn, p_conv
         if self._trace is not None:
             self._trace.append(('fft_block', pre, x, film, lengths, (a, u)))
-        return u, u_lp, s
+        return u, u_lp, s, qkv_next
 
     def _conv_ln_fwd(self, W, conv_name, ln_name, x, p_drop, out_dtype, save, film=None, lengths=None, skip=None):
         ''' conv k3 -> ReLU -> LayerNorm -> Dropout [-> FiLM -> mask]  (prenet `model.py:341-363`, predictor 528-566) '''
@@ -575,9 +580,10 @@ class DaftExprt(nn.Module):
                                   [P[f'{pre}.energy_embedding.conv.bias'], P[f'{pre}.pitch_embedding.conv.bias']],
                                   base=l3, pos_table=self._pos_table(), lengths=output_lengths)
         s.blocks = []
-        x_lp = None
+        x_lp = qkv = None
         for blk in range(cfg['nb_blocks']):
-            x0, x_lp, sb = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x0, None, output_lengths, cfg, train, save, x_lp)
+            x0, x_lp, sb, qkv = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x0, None, output_lengths, cfg, train, save, x_lp, qkv,
+                                                    f'{pre}.blocks.{blk + 1}' if blk + 1 < cfg['nb_blocks'] else None)
             s.blocks.append(sb)
         emb = ops.masked_mean_fwd(x0, output_lengths)
         z = ops.gather_add_fwd(emb, P[f'{pre}.spk_embedding.weight'], speaker_ids)
@@ -603,9 +609,10 @@ class DaftExprt(nn.Module):
         ''' `model.py:490-509` '''
         cfg, pre = self.hp.phoneme_encoder, 'phoneme_encoder'
         x = ops.embed_pos_fwd(symbols, self._P[f'{pre}.symbols_embedding.weight'], self._pos_table(), input_lengths)
-        blocks, x_lp = [], None
+        blocks, x_lp, qkv = [], None, None
         for blk in range(cfg['nb_blocks']):
-            x, x_lp, sb = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x, film[:, blk, :], input_lengths, cfg, train, save, x_lp)
+            x, x_lp, sb, qkv = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x, film[:, blk, :], input_lengths, cfg, train, save, x_lp, qkv,
+                                                   f'{pre}.blocks.{blk + 1}' if blk + 1 < cfg['nb_blocks'] else None)
             blocks.append(sb)
         return x, blocks
 
@@ -648,9 +655,10 @@ class DaftExprt(nn.Module):
     def _decoder_fwd(self, W, x, film, output_lengths, train, save):
         ''' `model.py:689-710` (positional add + mask already applied by the upsampling kernel) '''
         cfg, pre, P = self.hp.frame_decoder, 'frame_decoder', self._P
-        blocks, x_lp = [], None
+        blocks, x_lp, qkv = [], None, None
         for blk in range(cfg['nb_blocks']):
-            x, x_lp, sb = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x, film[:, blk, :], output_lengths, cfg, train, save, x_lp)
+            x, x_lp, sb, qkv = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x, film[:, blk, :], output_lengths, cfg, train, save, x_lp, qkv,
+                                                   f'{pre}.blocks.{blk + 1}' if blk + 1 < cfg['nb_blocks'] else None)
             blocks.append(sb)
         mel = ops.conv1d(x, W[f'{pre}.projection.linear_layer.weight'], P[f'{pre}.projection.linear_layer.bias'],
                          out_dtype=torch.float32, mask_lengths=output_lengths, transposed_out=True, skip_lengths=output_lengths)
