@@ -1,8 +1,8 @@
 set -u
-export TMPDIR=/tmp
-for i in 1 2; do
-for v in 0 1; do
-DX_LN_GEMM2=$v DX_LNBWD_GEMM2=$v python bench.py --batch 256 --tmin 500 --steps 10 --warmup 15 --no-cpu-baseline --no-probe 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c5 gemm2=$v', round(d['ms_per_step'],3))"
-DX_LN_GEMM2=$v DX_LNBWD_GEMM2=$v python bench.py --workload synth --batch 256 --steps 10 --warmup 3 --no-cpu-baseline --no-probe 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('synth gemm2=$v', round(d['ms_per_step'],3))"
-done; done
-python bench.py --no-cpu-baseline --no-probe 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c2', round(d['ms_per_step'],3))"
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/profiles_r03
+rm -rf /tmp/kt && rocprofv3 --kernel-trace -d /tmp/kt -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-probe > /tmp/kt.out 2> /tmp/kt.err
+DB=$(find /tmp/kt -name "*.db" | head -1)
+python $R/tools/rocprof_stats.py $DB > $R/gpurun_out/profiles_r03/r03_kernel_trace.md
+python $R/tools/timeline.py $DB $R/gpurun_out/profiles_r03/r03_step_timeline.txt
