@@ -345,7 +345,7 @@ __global__ void attn_delta_kernel(const TC* __restrict__ o, const TC* __restrict
 
 // =============================================================================== backward: dQ
 template <typename TC, int DH>
-__global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : DX_ATTN_OCC64) : 2) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? 4 : DX_ATTN_OCC64) : 2) void attn_bwd_dq_kernel(AttnArgs a) {   // (d_head 16: 4 waves per SIMD -- at 5 the kernel kept 20 bytes of scratch; it is the N > 1024 fallback of the fused backward)
   constexpr int KT = Stage<DH>::KT;
   constexpr int LD = DH + APad<TC>::value, KS = DH / 16, MT = (DH + 31) / 32, WRAP = DH >= 32 ? 32 : 16;
   typedef typename Vec8<TC>::type frag_t;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
 
 // =============================================================================== backward: dK, dV
 template <typename TC, int DH>
-__global__ __launch_bounds__(256, DH <= 16 ? 3 : 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, DH <= 16 ? 3 : (sizeof(TC) == 4 ? 1 : 2)) void attn_bwd_dkv_kernel(AttnArgs a) {   // (exact-fp32 parity path, d_head 64: twice the operand registers -- one wave per SIMD instead of 148 bytes of scratch)
   constexpr int KT = Stage<DH>::KT;
   constexpr int LD = DH + APad<TC>::value, KS = DH / 16, MT = (DH + 31) / 32, WRAP = DH >= 32 ? 32 : 16;
   typedef typename Vec8<TC>::type frag_t;
