@@ -2154,6 +2154,9 @@ __device__ __forceinline__ bf16x8 gather8_swz(const bf16_t* tile, int kA, int kB
 // register-staged kernel spent 4800 cycles per item on 2048 cycles of MFMA work (two barriers, ds_write staging, and
 // the bias MFMAs in every wave); here the bias gradient is a column sum the loader waves take from the LDS tile.
 constexpr int WGR_THREADS = 768, WGR_RING = 4;
+#ifndef WGR_XCD_BLOCKS
+#define WGR_XCD_BLOCKS 1
+#endif
 template <int TAPS>
 __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradArgs p) {
   constexpr int HALO = TAPS / 2, XROWS = WG_P + TAPS - 1;
@@ -2162,7 +2165,15 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
   __shared__ __attribute__((aligned(16))) bf16_t ring[WGR_RING * ITEM_EL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
   const int ntiles = dx_cdiv(p.Cout, WG_CO) * p.tiles_ci;
-  const int split = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+  const int split = blockIdx.x / ntiles;
+  int tile = blockIdx.x % ntiles;
+  // XCD-aware tile order for the 8 x 8 tile grid of a 1024 x 1024 weight (workgroup L runs on XCD L % 8, ntiles % 8 == 0): in index
+  // order an XCD owns one ci column of tiles and reads ALL of dY (8 x 61 MB per launch over the chip); dealt as 4 (co) x 2 (ci)
+  // blocks it reads half of dY and a quarter of X.  Only the assignment of tile ids to workgroups changes.
+  if (WGR_XCD_BLOCKS && ntiles == 64 && p.tiles_ci == 8) {
+    const int x = tile & 7, k8 = tile >> 3;
+    tile = (4 * (x >> 2) + (k8 & 3)) * 8 + 2 * (x & 3) + (k8 >> 2);
+  }
   const int co0 = (tile / p.tiles_ci) * WG_CO, ci0 = (tile % p.tiles_ci) * WG_CI;
   const int N = p.N, Cin = p.Cin, Cout = p.Cout;
   auto nlim_of = [&](int b) { return p.lengths ? min(N, (int)p.lengths[b] + 2) : N; };
