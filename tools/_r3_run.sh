@@ -1,5 +1,7 @@
-# scratch script for gpurun calls during development (rewritten per run)
+# scratch script for gpurun calls during development (rewritten per run):
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/_r3_run.sh'
 set -u
 export TMPDIR=/tmp
-python -m pytest tests -q -m gpu --tb=short -k "mel or frontend or feature or generate" 2>&1 | grep -E "^E |passed|failed|rror|ERROR" | head
-python tools/bench_ops.py mel 2>&1 | grep "mel front-end"
+python -m pytest tests -q -m gpu --tb=short 2>&1 | grep -E "^E |passed|failed|rror|ERROR" | head
+python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -1
+python bench.py 2>/dev/null | cut -c1-200
