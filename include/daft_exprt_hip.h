@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DX_ABI_VERSION 9
+#define DX_ABI_VERSION 10
 
 enum { DX_F32 = 0, DX_BF16 = 1, DX_I64 = 2 };
 enum { DX_OK = 0, DX_ERR_ARG = -1, DX_ERR_SHAPE = -2, DX_ERR_DTYPE = -3, DX_ERR_LAUNCH = -4, DX_ERR_UNSUPPORTED = -5 };
@@ -34,6 +34,26 @@ enum { DX_CONV_RELU = 1, DX_CONV_TRANSPOSED_OUT = 2, DX_CONV_ACCUMULATE = 4 /* y
 
 int dx_abi_version(void);
 const char* dx_last_error(void);
+
+/* ---- the step block: what changes from one optimizer step to the next, in DEVICE memory.
+ * The reference's trainer recomputes these on the host every iteration and they reach its kernels as scalar arguments: the
+ * learning rate (train.py:139-151, 491-494), Adam's bias corrections (torch.optim.Adam, train.py:299-301), the adversarial
+ * loss weight (loss.py:22-28), and -- through torch's Philox offset -- the dropout streams.  A captured step (hipGraph) replays
+ * FIXED kernel arguments, so every entry point that consumes one of them takes an optional `const DxStepScalars* step`
+ * (NULL = use the by-value arguments, the eager path):
+ *   dropout:  effective seed = (seed argument + step->seed_salt) mod 2^63     (dx_conv1d_ln, dx_conv1d_lnbwd, dx_layernorm_fwd / _bwd,
+ *             dx_attention_fwd / _bwd) -- the same number the eager path passes by value, hence the same masks bit for bit;
+ *   dx_adam_step: lr, bc1 = 1 - beta1^t, bc2_sqrt = sqrt(1 - beta2^t) replace the lr / step arguments;
+ *   dx_loss_fwd_bwd: w_speaker replaces w_spk.
+ * dx_step_scalars_set fills the block with one single-thread launch (stream-ordered in front of the step that reads it). */
+typedef struct DxStepScalars {
+  uint64_t seed_salt;
+  float lr, bc1, bc2_sqrt, w_speaker;
+  int step;
+  int reserved[3];
+} DxStepScalars;
+int dx_step_scalars_set(DxStepScalars* dev, uint64_t seed_salt, float lr, float beta1, float beta2, int step, float w_speaker,
+                        void* stream);
 
 /* ---- K1/K3/K12: k-tap (1 or 3) stride-1 "same" conv on channel-last activations as an implicit GEMM
  * on MFMA; also nn.Linear (taps = 1).  Replaces ConvNorm1D.forward (model.py:86-94: transpose, nn.Conv1d,
@@ -77,7 +97,7 @@ int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_packed, int
                  const float* residual, const float* gamma, const float* beta, const float* film, long ldf,
                  const int64_t* lengths, float* y, void* y_lp, float* s_out, float* mean, float* rstd, int B, int N,
                  int Cin, int taps, float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, const void* w_frag,
-                 const void* w2_packed, const float* b2, void* y2, int n2, void* stream);
+                 const void* w2_packed, const float* b2, void* y2, int n2, const DxStepScalars* step, void* stream);
 
 /* Data gradient of a conv / linear INTO a 128-channel residual stream, fused with the BACKWARD of the LayerNorm that
  * consumed that stream in the forward pass (autograd of model.py:189-191 resp. 226-235 + 259/262, i.e. what
@@ -96,7 +116,8 @@ int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void* w_packed, 
                     const float* s_in, const float* mean, const float* rstd, const float* gamma, const float* beta,
                     const float* film, long ldf, const int64_t* lengths, void* dx_pre_lp, float* dgamma, float* dbeta,
                     float* dfilm, long lddf, int B, int N, int Cin, int taps, float p_pre, uint64_t seed_pre,
-                    const int* plan, int plan_tiles, const void* w_frag, const void* w2_packed, void* y2, void* stream);
+                    const int* plan, int plan_tiles, const void* w_frag, const void* w2_packed, void* y2, const DxStepScalars* step,
+                    void* stream);
 
 /* The weights of a k = 3 conv in MFMA-fragment order: out[chunk][tap][half][block][lane][8] = w_packed[tap][32 block + (lane & 31)]
  * [32 chunk + 16 half + 8 (lane >> 5) + 0..7], block < Cout / 32; w_packed = the [3][Cout][Cin] bf16 packing of dx_pack_conv_weight
@@ -180,7 +201,7 @@ int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const void* x, int 
 int dx_layernorm_fwd(const void* x, int x_dtype, const float* residual, const float* gamma, const float* beta,
                      const float* film, long ldf, const int64_t* lengths, const int64_t* skip_lengths, void* y,
                      int y_dtype, void* y_lp /* optional bf16 copy of y */, float* s_out, float* mean, float* rstd, int B, int N, int C, float p_pre,
-                     uint64_t seed_pre, float p_post, uint64_t seed_post, void* stream);
+                     uint64_t seed_pre, float p_post, uint64_t seed_post, const DxStepScalars* step, void* stream);
 
 /* Backward of dx_layernorm_fwd.  dy: grad wrt y.  s_in: s_out of the forward (or x itself when there was no
  * residual / pre-dropout).  Outputs: ds = grad wrt s (equals the residual-branch gradient); dx_pre = grad wrt x
@@ -194,7 +215,7 @@ int dx_layernorm_bwd(const void* dy, int dy_dtype, const void* s_in, int s_dtype
                      float* dgamma, float* dbeta, float* dfilm, long lddf, int B, int N, int C, float p_pre, uint64_t seed_pre,
                      float p_post, uint64_t seed_post, int relu_input,
                      float* ws /* NULL: fp32 atomics; else dx_layernorm_bwd_ws_floats(B,N,C) floats: deterministic two-stage reduction */,
-                     void* stream);
+                     const DxStepScalars* step, void* stream);
 long dx_layernorm_bwd_ws_floats(int B, int N, int C);
 
 /* ---- K4: multi-head self-attention with key-padding mask, flash-style on MFMA (d_head in {16, 64}).
@@ -206,21 +227,25 @@ long dx_layernorm_bwd_ws_floats(int B, int N, int C);
  * order: NULL, or the (B) int32 table of dx_length_order -- workgroups are then launched longest utterance first
  * (same results; a ragged batch finishes sooner). */
 int dx_attention_fwd(const void* qkv, int dtype, const int64_t* lengths, const int* order, void* o, float* lse, int B, int N,
-                     int H, int E, float p_drop, uint64_t seed, void* stream);
+                     int H, int E, float p_drop, uint64_t seed, const DxStepScalars* step, void* stream);
 
 /* Backward of dx_attention_fwd (autograd of model.py:182-186): dqkv (B, N, 3E) <- d_o (B, N, E).  delta_ws: (B, H, N) fp32 workspace.
  * algo: DX_ATTN_AUTO picks the fused kernel where it exists (bf16, d_head 16, N <= 1024: one workgroup per (utterance, head)
  * recomputes S / dP once for dQ, dK and dV) and the two-pass pair (dQ kernel, dK/dV kernel) elsewhere; DX_ATTN_TWO_PASS forces the
  * pair; DX_ATTN_FUSED returns DX_ERR_UNSUPPORTED where the fused kernel does not apply.  Both draw the forward's dropout mask.
- * delta_ws: dx_attention_bwd_ws_floats(B, N, H) floats.  The LAST B * H of them are arrival counters of the fused kernel (an
- * utterance of more than 512 keys is shared by two workgroups): they must be zero before the first call and are left in a valid
- * state by every call, so the caller zeroes the workspace once and keeps it (one workspace per stream: calls that run
- * concurrently must not share it). */
+ * delta_ws: dx_attention_bwd_ws_floats(B, N, H) floats of scratch (delta + the fused kernel's dQ partials); nothing in it has to be
+ * initialised or to survive the call, so one grow-only buffer per stream serves every batch shape.
+ * counters: dx_attention_bwd_counters(B, H) ints, the arrival counters of the fused kernel (an utterance of more than 512 keys is
+ * shared by two workgroups): zero before the FIRST launch, and every launch puts the counters it used back to zero (the second
+ * arrival of a pair resets its counter), so the caller zeroes a buffer of max(B * H) ints once per stream and keeps it.  May be
+ * NULL when the fused kernel cannot run (fp32 operands, d_head 64, N > 1024, or DX_ATTN_TWO_PASS).  Calls that may run
+ * CONCURRENTLY (different streams) must not share either buffer. */
 long dx_attention_bwd_ws_floats(int B, int N, int H);
+long dx_attention_bwd_counters(int B, int H);
 enum { DX_ATTN_AUTO = 0, DX_ATTN_TWO_PASS = 1, DX_ATTN_FUSED = 2 };
 int dx_attention_bwd(const void* qkv, const void* o, const void* d_o, int dtype, const float* lse,
-                     const int64_t* lengths, const int* order, void* dqkv, float* delta_ws, int B, int N, int H, int E,
-                     float p_drop, uint64_t seed, int algo, void* stream);
+                     const int64_t* lengths, const int* order, void* dqkv, float* delta_ws, int* counters, int B, int N, int H, int E,
+                     float p_drop, uint64_t seed, const DxStepScalars* step, int algo, void* stream);
 
 /* order[r] = index of the utterance with the r-th largest length (ties: lower index first), B <= 65536.  Host-side
  * analogue: the reference's collate sorts a batch by decreasing phoneme count (data_loader.py:246-250); the attention
@@ -277,14 +302,19 @@ int dx_add_inplace(float* dst, const float* src, long n, void* stream);         
 int dx_colsum(const void* x, int dtype, float* out, long rows, int C, void* stream); /* out[c] += sum_r x[r][c] (bias grads) */
 int dx_scale(float* x, long n, float s, void* stream);
 /* Layout helpers (the reference gets these from ATen views / copies around its modules):
- *   dx_transpose_last2: (B, R, C) -> (B, C, R) fp32 -- the mel batch arrives as (B, n_mel, T) (model.py:744), kernels want rows;
+ *   dx_transpose_last2: fp32 (B, R, C) -> (B, C, R) in y_dtype (DX_F32, or DX_BF16 = the rounding the first pre-net GEMM applies
+ *   at operand load) -- the mel batch arrives as (B, n_mel, T) (model.py:744), kernels want rows;
  *   dx_unstack / dx_stack: y (M, K) interleaved <-> K planes of M floats, K <= 4 -- the duration / energy / pitch heads share one
  *   projection (model.py:567-575);  planes = host array of K device pointers;
  *   dx_fill_zero: stream-ordered memset of a device buffer. */
-int dx_transpose_last2(const float* x, float* y, int B, int R, int C, void* stream);
+int dx_transpose_last2(const float* x, void* y, int y_dtype, int B, int R, int C, void* stream);
 int dx_unstack(const float* y, float* const* planes, long M, int K, void* stream);
 int dx_stack(float* y, const float* const* planes, long M, int K, void* stream);
 int dx_fill_zero(void* p, size_t bytes, void* stream);
+/* an empty single-thread launch: inside a stream capture, the first node recorded behind a fork decides which branch the graph
+ * executor keeps on the forking node's queue -- the capturing trainer records one on the launch stream right behind every fork to
+ * the weight-gradient stream (train.CapturedStep) */
+int dx_anchor(void* stream);
 
 /* ---- K11: Gaussian upsampling (GaussianUpsamplingModule.forward, model.py:608-662), fp32, integer prefix sums exact.
  * dx_gu_prepare : xp = enc + conv(energy) + conv(pitch); rin = xp + conv(dur_float); r_pre = w_range . rin + b_range;
@@ -319,7 +349,8 @@ int dx_loss_fwd_bwd(const float* dur, const float* energy, const float* pitch, c
                     float* d_pitch, float* d_mel, float* d_spk_logits, float* d_post_mult, float* terms,
                     int B, int L, int T, int n_mel, int n_spk_classes, int n_post, float w_spk, float w_post,
                     float w_dur, float w_energy, float w_pitch, float w_mel, float grad_scale,
-                    int d_mel_transposed /* write d_mel as (B, T, n_mel) */, void* stream);
+                    int d_mel_transposed /* write d_mel as (B, T, n_mel) */,
+                    const DxStepScalars* step /* NULL, or the step block: its w_speaker replaces w_spk */, void* stream);
 
 /* ---- K15: torch.optim.Adam as configured at train.py:299-301 (coupled L2, bias correction, amsgrad off) over a
  * flat fp32 buffer; clip_grad_norm_ (train.py:399) folded in: grad_norm_sq (device scalar from dx_sumsq) and
@@ -329,6 +360,7 @@ int dx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr,
                  float eps, float weight_decay, int step, const float* grad_norm_sq, float clip_thresh,
                  float* grad_norm_sq_accum /* NULL, or a device scalar that receives += sum(g^2) of this slice: the norm the
                  trainer logs (train.py:399 with an infinite threshold) without a pass of its own; per-section calls add up */,
+                 const DxStepScalars* scalars /* NULL, or the step block: its lr / bias corrections replace `lr` and `step` */,
                  void* stream);
 
 /* ---- K16: float -> integer frame durations on the device (DaftExprt.get_int_durations model.py:789-812 +

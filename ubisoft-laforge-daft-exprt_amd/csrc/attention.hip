@@ -38,6 +38,8 @@ struct AttnArgs {
   uint64_t seed;
   const int* order;        // launch rank -> utterance, longest first (dx_length_order); NULL = identity
   int B, gx;               // set by the launchers: utterances, tiles per (utterance, head) along the owned axis
+  const DxStepScalars* step;   // NULL, or the device-side step block whose salt is added to seed (captured steps)
+  int* counters;           // fused backward: B * H arrival counters (zero between launches)
 };
 
 // XCD-aware launch order.  Workgroups go to the 8 XCDs round-robin in flat index order, and every XCD has its own L2.  With the
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
   const float inv_keep = dx_drop_inv_keep8(th8);   // applied once, to the output row
   // dropout block counter of (q, 4 keys) = lane part + a scalar that follows the key tile (dx_common.h)
   const uint32_t NB = (uint32_t)(N + 3) >> 2;
-  const uint32_t ctr_lane = dx_opaque(((uint32_t)(q >> 2) * NB + g) * DX_CTR_MUL + dx_key32(a.seed, (uint32_t)(b * a.H + h)));
+  const uint32_t ctr_lane = dx_opaque(((uint32_t)(q >> 2) * NB + g) * DX_CTR_MUL + dx_key32(dx_seed_eff(a.seed, a.step), (uint32_t)(b * a.H + h)));
   const uint32_t rot_lane = 8u * (q & 3), mult_lane = dx_blk_mult(q & 3);
 
   constexpr bool AHEAD = sizeof(TC) == 2 && DX_ATTN_AHEAD;   // exact-fp32 mode: twice the registers per tile, loads stay in place
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? 4 : DX_ATTN_OCC6
     const uint32_t th8 = dx_drop_th8(a.p_drop);
     const float inv_keep = dx_drop_inv_keep8(th8);
     const uint32_t NB = (uint32_t)(N + 3) >> 2;
-    const uint32_t ctr_lane = dx_opaque(((uint32_t)(q >> 2) * NB + g) * DX_CTR_MUL + dx_key32(a.seed, (uint32_t)(b * a.H + h)));
+    const uint32_t ctr_lane = dx_opaque(((uint32_t)(q >> 2) * NB + g) * DX_CTR_MUL + dx_key32(dx_seed_eff(a.seed, a.step), (uint32_t)(b * a.H + h)));
     const uint32_t rot_lane = 8u * (q & 3), mult_lane = dx_blk_mult(q & 3);
 
     constexpr bool AHEAD = sizeof(TC) == 2;
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : (sizeof(TC) == 4 ? 1 : 2)) void
     // follows the query rows; the lane reads byte (key & 3) of each row word (dx_common.h)
     const uint32_t NB = (uint32_t)(N + 3) >> 2;
     const uint32_t ctr_q = NB * DX_CTR_MUL;   // one query block further
-    const uint32_t ctr_lane = dx_opaque(((uint32_t)(key >> 2) + g * NB) * DX_CTR_MUL + dx_key32(a.seed, (uint32_t)(b * a.H + h)));
+    const uint32_t ctr_lane = dx_opaque(((uint32_t)(key >> 2) + g * NB) * DX_CTR_MUL + dx_key32(dx_seed_eff(a.seed, a.step), (uint32_t)(b * a.H + h)));
     const uint32_t shl_lane = 24u - 8u * (key & 3);
     const float c2 = a.scale * LOG2E;
     const bool tile_k_valid = bx * QB + wq * 32 + 32 <= len;
@@ -759,11 +761,12 @@ __device__ __forceinline__ void dx_drop4x2(float* pm, const float* pr, float* x,
       : "v"(pr[0]), "v"(pr[1]), "v"(pr[2]), "v"(pr[3]), "v"(w), "v"(th8));
 }
 
-// workspace of the fused kernel behind the (B, H, N) floats of delta: B * H * 2 fp32 dQ partials of (N_pad x 16) + B * H arrival
-// counters (int, zero before the first call; every pair of arrivals leaves the parity it found)
+// workspace of the fused kernel behind the (B, H, N) floats of delta: B * H * 2 fp32 dQ partials of (N_pad x 16); nothing in it has to
+// survive a launch.  The B * H arrival counters live in a buffer of their own (`counters`): zero before the first launch, and the second
+// arrival of a pair puts its counter back to zero, so the same small buffer serves every shape and every later launch on the stream.
 __host__ __device__ static inline long fb_ws_floats(int B, int N, int H) {
   const long npad = (N + 31) & ~31;
-  return (long)B * H * 2 * npad * 16 + (long)B * H;
+  return (long)B * H * 2 * npad * 16;
 }
 
 __global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, float* ws) {   // grid: attn_grid(B, 2 H)
@@ -798,7 +801,7 @@ __global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, f
   const float* lse = a.lse + ((long)b * H + h) * N;
   const long npad = (N + 31) & ~31;
   float* part = ws + (((long)b * H + h) * 2 + half) * npad * 16;        // split utterances: this workgroup's dQ partial [query][d]
-  int* counter = reinterpret_cast<int*>(ws + (long)a.B * H * 2 * npad * 16) + (b * H + h);
+  int* counter = a.counters + (b * H + h);
   if (!half) {   // rows past the last live block: dQ | dK | dV are zero (this head's 16 columns of each)
     const frag_t z = zero8<TC>();
     const int nz = (N - rows_live) * 6;
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, f
   const uint32_t th8 = dx_drop_th8(a.p_drop);
   const float inv_keep = dx_drop_inv_keep8(th8);
   const uint32_t NB = (uint32_t)(N + 3) >> 2;
-  const uint32_t skey = dx_key32(a.seed, (uint32_t)(b * H + h));
+  const uint32_t skey = dx_key32(dx_seed_eff(a.seed, a.step), (uint32_t)(b * H + h));
 
   const int srow = tid >> 1, shf = (tid & 1) * 8;   // this thread's 16-byte piece of a 128-row stage
   frag_t qreg, doreg;
@@ -1001,7 +1004,10 @@ __global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, f
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int second = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1;
-    if (second) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (second) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // both arrivals are in: zero again for the next launch
+    }
     arrived = second;
   }
   __syncthreads();
@@ -1048,6 +1054,7 @@ int launch_bwd(const AttnArgs& a0, int B, int dh, float* delta, int algo, hipStr
     return DX_ERR_UNSUPPORTED;
   }
   if (can_fuse && (algo == DX_ATTN_FUSED || (algo == DX_ATTN_AUTO && fused_bwd_enabled()))) {
+    if (!a.counters) { dx_set_error("dx_attention_bwd: the fused kernel needs the arrival counters (dx_attention_bwd_counters(B, H) ints, zeroed once)"); return DX_ERR_ARG; }
     hipLaunchKernelGGL(attn_bwd_fused16_kernel, dim3(attn_grid(B, 2 * a.H)), dim3(FB_T), 0, s, a, delta + (long)B * a.H * a.N);
     DX_LAUNCH_CHECK();
     return DX_OK;
@@ -1087,12 +1094,13 @@ extern "C" int dx_length_order(const int64_t* lengths, int B, int* order, void* 
 }
 
 extern "C" int dx_attention_fwd(const void* qkv, int dtype, const int64_t* lengths, const int* order, void* o, float* lse, int B, int N,
-                                int H, int E, float p_drop, uint64_t seed, void* stream) {
+                                int H, int E, float p_drop, uint64_t seed, const DxStepScalars* step, void* stream) {
   DX_REQUIRE(qkv && lengths && o, DX_ERR_ARG, "dx_attention_fwd: null pointer");
   DX_REQUIRE(B > 0 && N > 0 && H > 0 && E % H == 0, DX_ERR_SHAPE, "dx_attention_fwd: bad shape B=%d N=%d H=%d E=%d", B, N, H, E);
   DX_REQUIRE(p_drop >= 0.f && p_drop < 1.f, DX_ERR_ARG, "dx_attention_fwd: dropout p out of [0,1)");
   const int dh = E / H;
   AttnArgs a{qkv, o, lse, nullptr, nullptr, nullptr, lengths, N, H, E, 1.f / sqrtf((float)dh), p_drop, seed, order};
+  a.step = step; a.counters = nullptr;
   if (dtype == DX_BF16) return launch_fwd<bf16_t>(a, B, dh, (hipStream_t)stream);
   if (dtype == DX_F32) return launch_fwd<float>(a, B, dh, (hipStream_t)stream);
   dx_set_error("dx_attention_fwd: bad dtype %d", dtype);
@@ -1104,15 +1112,18 @@ extern "C" long dx_attention_bwd_ws_floats(int B, int N, int H) {
   return (long)B * H * N + fb_ws_floats(B, N, H);
 }
 
+extern "C" long dx_attention_bwd_counters(int B, int H) { return (B <= 0 || H <= 0) ? 0 : (long)B * H; }
+
 extern "C" int dx_attention_bwd(const void* qkv, const void* o, const void* d_o, int dtype, const float* lse,
-                                const int64_t* lengths, const int* order, void* dqkv, float* delta_ws, int B, int N, int H, int E,
-                                float p_drop, uint64_t seed, int algo, void* stream) {
+                                const int64_t* lengths, const int* order, void* dqkv, float* delta_ws, int* counters, int B, int N, int H, int E,
+                                float p_drop, uint64_t seed, const DxStepScalars* step, int algo, void* stream) {
   DX_REQUIRE(qkv && o && d_o && lse && lengths && dqkv && delta_ws, DX_ERR_ARG, "dx_attention_bwd: null pointer");
   DX_REQUIRE(B > 0 && N > 0 && H > 0 && E % H == 0, DX_ERR_SHAPE, "dx_attention_bwd: bad shape");
   DX_REQUIRE(algo >= DX_ATTN_AUTO && algo <= DX_ATTN_FUSED, DX_ERR_ARG, "dx_attention_bwd: algo %d", algo);
   const int dh = E / H;
   AttnArgs a{qkv, const_cast<void*>(o), const_cast<float*>(lse), d_o, delta_ws, dqkv, lengths, N, H, E,
              1.f / sqrtf((float)dh), p_drop, seed, order};
+  a.step = step; a.counters = counters;
   if (dtype == DX_BF16) return launch_bwd<bf16_t>(a, B, dh, delta_ws, algo, (hipStream_t)stream);
   if (dtype == DX_F32) return launch_bwd<float>(a, B, dh, delta_ws, algo, (hipStream_t)stream);
   dx_set_error("dx_attention_bwd: bad dtype %d", dtype);

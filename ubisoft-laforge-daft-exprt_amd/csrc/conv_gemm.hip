@@ -43,6 +43,7 @@ struct LNEpi {
   float* dgamma; float* dbeta; float* dfilm; long lddf;
   const void* w2; void* y2;   // split-K kernel: y2 = y_lp . w2^T (+ b2), a 128 -> n2 k = 1 GEMM on the rows the epilogue has just produced
   const float* b2; int n2;    // (n2 = 128: output-projection data gradient behind the LayerNorm backward; 384: the next block's QKV projection)
+  const DxStepScalars* step;  // NULL, or the device-side step block whose salt is added to seed_pre (captured steps)
 };
 
 struct ConvArgs {
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
             for (int e = 0; e < 8; ++e) v[e] = rstd * (v[e] - s1 - xh[e] * s2);
             store8<float>(p.ln.y + offl, v);                      // ds, in place of the residual gradient
             if (p.ln.p_pre > 0.f) {
-              const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(p.ln.seed_pre, 0);
+              const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(dx_seed_eff(p.ln.seed_pre, p.ln.step), 0);
               const float sc = 1.f / (1.f - p.ln.p_pre);
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = dx_keep(key, (uint32_t)rowg * BN + cl + e, th) ? v[e] * sc : 0.f;
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1
           if (LN == 1) {        // fused LayerNorm: 16 lanes hold one complete 128-channel row
             const size_t rowg = (size_t)b * N + n, offl = rowg * BN + cl;
             if (p.ln.p_pre > 0.f) {
-              const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(p.ln.seed_pre, 0);
+              const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(dx_seed_eff(p.ln.seed_pre, p.ln.step), 0);
               const float sc = 1.f / (1.f - p.ln.p_pre);
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = dx_keep(key, (uint32_t)rowg * BN + cl + e, th) ? v[e] * sc : 0.f;
@@ -1407,7 +1408,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
             for (int e2 = 0; e2 < 8; ++e2) v[e2] = rstd * (v[e2] - s1 - xh[e2] * s2);
             store8<float>(p.ln.y + offl, v);                      // ds, in place of the residual gradient
             if (p.ln.p_pre > 0.f) {
-              const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(p.ln.seed_pre, 0);
+              const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(dx_seed_eff(p.ln.seed_pre, p.ln.step), 0);
               const float sc = 1.f / (1.f - p.ln.p_pre);
 #pragma unroll
               for (int e2 = 0; e2 < 8; ++e2) v[e2] = dx_keep(key, (uint32_t)rowg * BN + cl + e2, th) ? v[e2] * sc : 0.f;
@@ -1416,7 +1417,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
             if (gemm2) store8<bf16_t>(a2 + sr * A2_LD + cl, v);
           } else {              // fused LayerNorm: 16 lanes hold one complete 128-channel row
             if (p.ln.p_pre > 0.f) {
-              const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(p.ln.seed_pre, 0);
+              const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(dx_seed_eff(p.ln.seed_pre, p.ln.step), 0);
               const float sc = 1.f / (1.f - p.ln.p_pre);
 #pragma unroll
               for (int e2 = 0; e2 < 8; ++e2) v[e2] = dx_keep(key, (uint32_t)rowg * BN + cl + e2, th) ? v[e2] * sc : 0.f;
@@ -2724,7 +2725,7 @@ extern "C" int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_
                             const float* residual, const float* gamma, const float* beta, const float* film, long ldf,
                             const int64_t* lengths, float* y, void* y_lp, float* s_out, float* mean, float* rstd, int B, int N,
                             int Cin, int taps, float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, const void* w_frag,
-                            const void* w2_packed, const float* b2, void* y2, int n2, void* stream) {
+                            const void* w2_packed, const float* b2, void* y2, int n2, const DxStepScalars* step, void* stream) {
   DX_REQUIRE(x && w_packed && residual && gamma && beta && y, DX_ERR_ARG, "dx_conv1d_ln: null pointer");
   DX_REQUIRE(!w_frag || plan, DX_ERR_ARG, "dx_conv1d_ln: fragment-order weights go with a tile plan");
   if (int rc = plan_check("dx_conv1d_ln", plan, plan_tiles, lengths, x_dtype, w_dtype, ldx, Cin, taps, B, N)) return rc;
@@ -2735,7 +2736,7 @@ extern "C" int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_
   DX_REQUIRE(p_pre >= 0.f && p_pre < 1.f, DX_ERR_ARG, "dx_conv1d_ln: dropout p out of [0,1)");
   ConvArgs a{x, ldx, w_packed, bias, nullptr, BN, nullptr, lengths, lengths, N, Cin, BN, 0, B,
              LNEpi{gamma, beta, residual, film, ldf, y, y_lp, s_out, mean, rstd, p_pre, seed_pre, 1}};
-  a.plan = plan; a.plan_tiles = plan_tiles; a.w_frag = w_frag;
+  a.plan = plan; a.plan_tiles = plan_tiles; a.w_frag = w_frag; a.ln.step = step;
   if (y2) {   // second GEMM in the epilogue (the next block's QKV projection): only the split-K workgroups carry it (gate of launch_taps)
     DX_REQUIRE(w2_packed && (n2 == 128 || n2 == 384) && plan && w_frag && taps == 3 && Cin >= 256 && Cin % 128 == 0 && (long)B * N <= 256L * 256 &&
                w_dtype == DX_BF16 && x_dtype == DX_BF16, DX_ERR_UNSUPPORTED, "dx_conv1d_ln: y2 needs n2 in {128, 384} and the split-K path (bf16, "
@@ -2756,7 +2757,7 @@ extern "C" int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void*
                                const float* beta, const float* film, long ldf, const int64_t* lengths, void* dx_pre_lp,
                                float* dgamma, float* dbeta, float* dfilm, long lddf, int B, int N, int Cin, int taps,
                                float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, const void* w_frag, const void* w2_packed,
-                               void* y2, void* stream) {
+                               void* y2, const DxStepScalars* step, void* stream) {
   if (int rc = plan_check("dx_conv1d_lnbwd", plan, plan_tiles, lengths, x_dtype, w_dtype, ldx, Cin, taps, B, N, true)) return rc;
   DX_REQUIRE(!w_frag || plan, DX_ERR_ARG, "dx_conv1d_lnbwd: fragment-order weights go with a tile plan");
   DX_REQUIRE(x && w_packed && y_inout && s_in && mean && rstd && gamma && beta && lengths && dx_pre_lp && dgamma && dbeta,
@@ -2769,7 +2770,7 @@ extern "C" int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void*
   ConvArgs a{x, ldx, w_packed, nullptr, y_inout, BN, nullptr, lengths, lengths, N, Cin, BN, 0, B,
              LNEpi{gamma, beta, nullptr, film, ldf, y_inout, dx_pre_lp, const_cast<float*>(s_in), const_cast<float*>(mean),
                    const_cast<float*>(rstd), p_pre, seed_pre, 2, dgamma, dbeta, dfilm, lddf}};
-  a.plan = plan; a.plan_tiles = plan_tiles; a.w_frag = w_frag;
+  a.plan = plan; a.plan_tiles = plan_tiles; a.w_frag = w_frag; a.ln.step = step;
   if (y2) {   // second GEMM in the epilogue: only the split-K workgroups carry it (same gate as launch_taps)
     DX_REQUIRE(w2_packed && plan && w_frag && taps == 3 && Cin >= 256 && Cin % 128 == 0 && (long)B * N <= 256L * 256 && w_dtype == DX_BF16 &&
                x_dtype == DX_BF16, DX_ERR_UNSUPPORTED, "dx_conv1d_lnbwd: y2 needs the split-K path (bf16, taps = 3, plan + fragment-order weights, "

@@ -179,6 +179,13 @@ __host__ __device__ __forceinline__ uint32_t dx_mix32(uint32_t x) {
 __host__ __device__ __forceinline__ uint32_t dx_key32(uint64_t seed, uint32_t salt) {
   return dx_mix32((uint32_t)seed ^ dx_mix32((uint32_t)(seed >> 32) + 0x9E3779B9u * (salt + 1u)));
 }
+// The seed a launch draws its dropout mask from: the by-value seed, plus -- when the caller passes the device-side step block
+// (DxStepScalars, include/daft_exprt_hip.h) -- that block's salt, modulo 2^63.  A captured hipGraph replays fixed kernel
+// arguments, so whatever changes from one optimizer step to the next has to live in memory; seed_by_value + salt is the same
+// number the eager path passes by value (model._seed), hence the same mask bit for bit.
+__device__ __forceinline__ uint64_t dx_seed_eff(uint64_t seed, const DxStepScalars* step) {
+  return step ? ((seed + step->seed_salt) & 0x7fffffffffffffffULL) : seed;
+}
 // ---- attention-weight dropout: counter based, built from full-rate integer ops only (v_mul_u32_u24, v_alignbit; the 32-bit
 // v_mul_lo_u32 of dx_mix32 is quarter rate on CDNA and the attention kernels are VALU bound).  One 32-bit hash serves a
 // 4 x 4 block of (query, key) decisions:

@@ -24,6 +24,7 @@ struct LNArgs {
   void* y; void* y_lp; float* s_out; float* mean; float* rstd;   // y_lp: optional bf16 copy of y (MFMA operand of the next GEMM)
   int N; long rows;
   float p_pre, p_post; uint64_t seed_pre, seed_post;
+  const DxStepScalars* step;   // NULL, or the device-side step block whose salt is added to both seeds
 };
 
 template <int C>
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
   if (row >= a.rows) return;
   const int b = (int)(row / a.N), n = (int)(row - (long)b * a.N);
   const TI* x = reinterpret_cast<const TI*>(a.x) + row * C;
-  const uint32_t key_pre = dx_key32(a.seed_pre, 0), key_post = dx_key32(a.seed_post, 1);
+  const uint32_t key_pre = dx_key32(dx_seed_eff(a.seed_pre, a.step), 0), key_post = dx_key32(dx_seed_eff(a.seed_post, a.step), 1);
   if (a.skip && n >= (int)a.skip[b] + 2) {   // rows past length + conv halo never reach a valid output: zeros, no reads
     TO* y0 = reinterpret_cast<TO*>(a.y) + row * C;
     float z[L::V];
@@ -166,6 +167,7 @@ struct LNBwdArgs {
   int relu_input;            // s = relu(conv): the returned ds is additionally gated by (s > 0)
   int debug;                 // DX_LN_DEBUG: 1 = skip the final atomics (ablation only)
   float* ws;                 // optional (B * chunks, 4, C) partial sums -> finished by ln_bwd_finish_kernel (no atomics)
+  const DxStepScalars* step; // NULL, or the device-side step block whose salt is added to both seeds
 };
 
 // raw (unconverted) 4-element row segment: the prefetched next row stays in its storage type
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256, C >= 1024 ? (FILM ? 1 : 3) : 4) void ln_bwd_ke
   const int n_end = min(a.N, n_begin + a.rows_per_block);
   const int len = a.lengths ? (int)a.lengths[b] : a.N;
   const uint32_t th_pre = drop_thresh(a.p_pre), th_post = drop_thresh(a.p_post);
-  const uint32_t key_pre = dx_key32(a.seed_pre, 0), key_post = dx_key32(a.seed_post, 1);
+  const uint32_t key_pre = dx_key32(dx_seed_eff(a.seed_pre, a.step), 0), key_post = dx_key32(dx_seed_eff(a.seed_post, a.step), 1);
   const float sc_pre = a.p_pre > 0.f ? 1.f / (1.f - a.p_pre) : 1.f;
   const float sc_post = a.p_post > 0.f ? 1.f / (1.f - a.p_post) : 1.f;
   const int nskip = a.skip ? (int)a.skip[b] + 2 : a.N;
@@ -408,12 +410,12 @@ int launch_bwd(const LNBwdArgs& a, int C, hipStream_t s) {
 extern "C" int dx_layernorm_fwd(const void* x, int x_dtype, const float* residual, const float* gamma, const float* beta,
                                 const float* film, long ldf, const int64_t* lengths, const int64_t* skip_lengths, void* y,
                                 int y_dtype, void* y_lp, float* s_out, float* mean, float* rstd, int B, int N, int C, float p_pre, uint64_t seed_pre,
-                                float p_post, uint64_t seed_post, void* stream) {
+                                float p_post, uint64_t seed_post, const DxStepScalars* step, void* stream) {
   DX_REQUIRE(x && gamma && beta && y, DX_ERR_ARG, "dx_layernorm_fwd: null pointer");
   DX_REQUIRE(B > 0 && N > 0, DX_ERR_SHAPE, "dx_layernorm_fwd: empty shape");
   DX_REQUIRE((mean == nullptr) == (rstd == nullptr), DX_ERR_ARG, "dx_layernorm_fwd: mean and rstd come together");
   DX_REQUIRE(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, DX_ERR_ARG, "dx_layernorm_fwd: dropout p out of [0,1)");
-  LNArgs a{x, residual, gamma, beta, film, ldf, lengths, skip_lengths, y, y_lp, s_out, mean, rstd, N, (long)B * N, p_pre, p_post, seed_pre, seed_post};
+  LNArgs a{x, residual, gamma, beta, film, ldf, lengths, skip_lengths, y, y_lp, s_out, mean, rstd, N, (long)B * N, p_pre, p_post, seed_pre, seed_post, step};
   hipStream_t s = (hipStream_t)stream;
   if (x_dtype == DX_F32 && y_dtype == DX_F32) return launch_fwd<float, float>(a, C, s);
   if (x_dtype == DX_BF16 && y_dtype == DX_BF16) return launch_fwd<bf16_t, bf16_t>(a, C, s);
@@ -427,7 +429,7 @@ extern "C" int dx_layernorm_bwd(const void* dy, int dy_dtype, const void* s_in, 
                                 const float* rstd, const float* gamma, const float* beta, const float* film, long ldf,
                                 const int64_t* lengths, const int64_t* skip_lengths, void* ds, void* dx_pre, void* dx_pre_lp,
                                 int d_dtype, float* dgamma, float* dbeta, float* dfilm, long lddf, int B, int N, int C, float p_pre, uint64_t seed_pre,
-                                float p_post, uint64_t seed_post, int relu_input, float* ws, void* stream) {
+                                float p_post, uint64_t seed_post, int relu_input, float* ws, const DxStepScalars* step, void* stream) {
   DX_REQUIRE(dy && s_in && mean && rstd && gamma && beta && ds && dgamma && dbeta, DX_ERR_ARG, "dx_layernorm_bwd: null pointer");
   DX_REQUIRE(B > 0 && N > 0, DX_ERR_SHAPE, "dx_layernorm_bwd: empty shape");
   DX_REQUIRE((film == nullptr) == (dfilm == nullptr), DX_ERR_ARG, "dx_layernorm_bwd: film and dfilm come together");
@@ -437,7 +439,7 @@ extern "C" int dx_layernorm_bwd(const void* dy, int dy_dtype, const void* s_in, 
   int rpb = 32;
   while (rpb < 1024 && (long)dx_cdiv(N, rpb) * B > maxblk) rpb *= 2;
   LNBwdArgs a{dy, s_in, mean, rstd, gamma, beta, film, ldf, lengths, skip_lengths, ds, dx_pre, dx_pre_lp, dgamma, dbeta, dfilm, lddf, N, B, rpb,
-              p_pre, p_post, seed_pre, seed_post, relu_input, dbg, ws};
+              p_pre, p_post, seed_pre, seed_post, relu_input, dbg, ws, step};
   hipStream_t s = (hipStream_t)stream;
   if (s_dtype == DX_F32 && dy_dtype == DX_F32 && d_dtype == DX_F32) return launch_bwd<float, float, float>(a, C, s);
   if (s_dtype == DX_BF16 && dy_dtype == DX_BF16 && d_dtype == DX_BF16) return launch_bwd<bf16_t, bf16_t, bf16_t>(a, C, s);

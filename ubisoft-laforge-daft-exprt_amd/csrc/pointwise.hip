@@ -368,12 +368,13 @@ __global__ __launch_bounds__(256) void linear_rows_bwd_dw_kernel(const float* __
 // (B, R, C) -> (B, C, R) through a 32 x 33 LDS tile: coalesced on both sides.  The reference hands the mel batch over as
 // (B, n_mel, T) (model.py:744) while every kernel here wants channel-last rows; the loss gradient of the autograd bridge
 // comes back the same way.
-__global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int C) {
+template <typename TY>
+__global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __restrict__ x, TY* __restrict__ y, int R, int C) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const float* xb = x + (size_t)b * R * C;
-  float* yb = y + (size_t)b * R * C;
+  TY* yb = y + (size_t)b * R * C;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = r0 + ty + 8 * i, c = c0 + tx;
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __res
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = c0 + ty + 8 * i, r = r0 + tx;
-    if (r < R && c < C) yb[(size_t)c * R + r] = tile[tx][ty + 8 * i];
+    if (r < R && c < C) yb[(size_t)c * R + r] = (TY)tile[tx][ty + 8 * i];
   }
 }
 // K interleaved planes <-> K separate planes: y (M, K) <-> a_k (M)   (K <= 4: the three prosody heads share one projection)
@@ -509,7 +510,7 @@ extern "C" int dx_linear_small_bwd(const float* dy, const float* y, const float*
     // few outputs (M * K small): short chains of 16 output features per thread, partial sums meet in atomics (a thread that walks
     // 64+ features is a chain of dependent global round trips: 25 us for a 48 x 128 x 128 layer)
     const int chunks = (O > 16 && M * K < (1L << 18)) ? dx_cdiv(O, 16) : 1;
-    if (chunks > 1) hipMemsetAsync(dx, 0, (size_t)M * K * sizeof(float), s);
+    if (chunks > 1) { if (int rc = dx_fill_zero(dx, (size_t)M * K * sizeof(float), s)) return rc; }
     hipLaunchKernelGGL(linear_small_bwd_dx_kernel, dim3(grid_for(M * K), chunks), dim3(256), 0, s, dy, y, w, dx, mask_lengths, N, M, K, O,
                        relu, dx_scale, dx_cdiv(O, chunks));
   }
@@ -559,9 +560,12 @@ extern "C" int dx_gather_add_bwd(const float* dz, const int64_t* ids, float* dta
   return DX_OK;
 }
 
-extern "C" int dx_transpose_last2(const float* x, float* y, int B, int R, int C, void* stream) {
+extern "C" int dx_transpose_last2(const float* x, void* y, int y_dtype, int B, int R, int C, void* stream) {
   DX_REQUIRE(x && y && B > 0 && R > 0 && C > 0, DX_ERR_ARG, "dx_transpose_last2: bad arguments");
-  hipLaunchKernelGGL(transpose_last2_kernel, dim3(dx_cdiv(C, 32), dx_cdiv(R, 32), B), dim3(256), 0, (hipStream_t)stream, x, y, R, C);
+  DX_REQUIRE(y_dtype == DX_F32 || y_dtype == DX_BF16, DX_ERR_DTYPE, "dx_transpose_last2: y dtype %d", y_dtype);
+  const dim3 grid(dx_cdiv(C, 32), dx_cdiv(R, 32), B);
+  if (y_dtype == DX_F32) hipLaunchKernelGGL(transpose_last2_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, static_cast<float*>(y), R, C);
+  else hipLaunchKernelGGL(transpose_last2_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, static_cast<bf16_t*>(y), R, C);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
@@ -584,9 +588,34 @@ extern "C" int dx_stack(float* y, const float* const* planes, long M, int K, voi
   return DX_OK;
 }
 
+// zero fill with 16-byte stores (the head up to the first 16-byte boundary and the tail byte by byte from workgroup 0); a kernel of
+// this library rather than hipMemsetAsync so that every dispatch of a step is one of ours (and a graph capture records a kernel node)
+__global__ __launch_bounds__(256) void fill_zero_kernel(unsigned char* __restrict__ p, size_t bytes) {
+  size_t head = (16 - ((uintptr_t)p & 15)) & 15;
+  if (head > bytes) head = bytes;
+  const size_t nvec = (bytes - head) / 16;
+  uint4* v = reinterpret_cast<uint4*>(p + head);
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = blockIdx.x * 256UL + threadIdx.x; i < nvec; i += gridDim.x * 256UL) v[i] = z;
+  if (blockIdx.x == 0) {
+    for (size_t i = threadIdx.x; i < head; i += 256) p[i] = 0;
+    for (size_t i = head + nvec * 16 + threadIdx.x; i < bytes; i += 256) p[i] = 0;
+  }
+}
+
+__global__ void anchor_kernel() {}
+extern "C" int dx_anchor(void* stream) {
+  hipLaunchKernelGGL(anchor_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
 extern "C" int dx_fill_zero(void* p, size_t bytes, void* stream) {
   DX_REQUIRE(p || bytes == 0, DX_ERR_ARG, "dx_fill_zero: null pointer");
   if (bytes == 0) return DX_OK;
-  if (hipMemsetAsync(p, 0, bytes, (hipStream_t)stream) != hipSuccess) { dx_set_error("dx_fill_zero: hipMemsetAsync failed"); return DX_ERR_LAUNCH; }
+  size_t blocks = (bytes / 16 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, static_cast<unsigned char*>(p), bytes);
+  DX_LAUNCH_CHECK();
   return DX_OK;
 }

@@ -102,8 +102,11 @@ __global__ __launch_bounds__(256) void mel_loss_t_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ ids,
                                                         float* __restrict__ dlogits, int B, int S, float w_spk,
                                                         const float* __restrict__ post, float* __restrict__ dpost, int npost,
-                                                        float w_post, float* terms, float gscale) {
+                                                        float w_post, float* terms, float gscale, const DxStepScalars* step) {
+  // FIRST launch of dx_loss_fwd_bwd: writes terms[0..1] and zeroes the accumulators terms[2..7] of the kernels behind it (this
+  // replaces a hipMemsetAsync = one more dispatch per step)
   __shared__ float red[4];
+  if (step) w_spk = step->w_speaker;   // captured steps: the adversarial weight of this iteration lives in device memory
   float ce = 0.f;
   for (int b = threadIdx.x; b < B; b += 256) {
     const float* z = logits + (long)b * S;
@@ -126,6 +129,8 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict_
   if (threadIdx.x == 0) {
     terms[0] = w_spk * ce / (float)B;
     terms[1] = post ? w_post * nrm : 0.f;
+#pragma unroll
+    for (int i = 2; i < 8; ++i) terms[i] = 0.f;
   }
 }
 __global__ void loss_total_kernel(float* terms) {
@@ -163,8 +168,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
                                                    float wd, float bc1, float bc2_sqrt, const float* gnorm_sq, float clip,
-                                                   float* gnorm_accum) {
+                                                   float* gnorm_accum, const DxStepScalars* sc) {
   __shared__ float red[4];
+  if (sc) { lr = sc->lr; bc1 = sc->bc1; bc2_sqrt = sc->bc2_sqrt; }   // captured steps: this iteration's scalars live in device memory
   float coef = 1.f;
   if (gnorm_sq && clip < INFINITY) coef = fminf(1.f, clip / (sqrtf(*gnorm_sq) + 1e-6f));  // clip_grad_norm_
   const float step = lr / bc1;
@@ -301,12 +307,13 @@ extern "C" int dx_loss_fwd_bwd(const float* dur, const float* energy, const floa
                                float* d_pitch, float* d_mel, float* d_spk_logits, float* d_post_mult, float* terms,
                                int B, int L, int T, int n_mel, int n_spk_classes, int n_post, float w_spk, float w_post,
                                float w_dur, float w_energy, float w_pitch, float w_mel, float grad_scale,
-                               int d_mel_transposed, void* stream) {
+                               int d_mel_transposed, const DxStepScalars* step, void* stream) {
   DX_REQUIRE(dur && energy && pitch && dur_t && energy_t && pitch_t && in_lengths && mel && mel_t && out_lengths && spk_logits &&
              spk_ids && terms, DX_ERR_ARG, "dx_loss_fwd_bwd: null pointer");
   DX_REQUIRE(B > 0 && L > 0 && T > 0, DX_ERR_SHAPE, "dx_loss_fwd_bwd: empty shape");
   hipStream_t s = (hipStream_t)stream;
-  hipMemsetAsync(terms, 0, 8 * sizeof(float), s);
+  hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(256), 0, s, spk_logits, spk_ids, d_spk_logits, B, n_spk_classes, w_spk,
+                     post_mult, d_post_mult, n_post, w_post, terms, grad_scale, step);
   SeqLossArgs a{{dur, energy, pitch}, {dur_t, energy_t, pitch_t}, {d_dur, d_energy, d_pitch}, {w_dur, w_energy, w_pitch},
                 in_lengths, terms, B, L, grad_scale};
   hipLaunchKernelGGL(seq_loss_kernel, dim3(B, 3), dim3(256), 0, s, a);
@@ -316,8 +323,6 @@ extern "C" int dx_loss_fwd_bwd(const float* dur, const float* energy, const floa
     hipLaunchKernelGGL(mel_loss_t_kernel, dim3(dx_cdiv(T, MT_T), B), dim3(256), 0, s, mel, mel_t, d_mel, out_lengths, terms, B, n_mel, T, w_mel, grad_scale);
   else
     hipLaunchKernelGGL(mel_loss_kernel, dim3(chunks, B), dim3(256), 0, s, mel, mel_t, d_mel, out_lengths, terms, B, n_mel, T, w_mel, grad_scale, d_mel_transposed);
-  hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(256), 0, s, spk_logits, spk_ids, d_spk_logits, B, n_spk_classes, w_spk,
-                     post_mult, d_post_mult, n_post, w_post, terms, grad_scale);
   hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, s, terms);
   DX_LAUNCH_CHECK();
   return DX_OK;
@@ -326,7 +331,7 @@ extern "C" int dx_loss_fwd_bwd(const float* dur, const float* energy, const floa
 extern "C" int dx_sumsq(const float* x, long n, float* out, void* stream) {
   DX_REQUIRE(x && out && n >= 0, DX_ERR_ARG, "dx_sumsq: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  hipMemsetAsync(out, 0, sizeof(float), s);
+  if (int rc = dx_fill_zero(out, sizeof(float), s)) return rc;
   if (n) hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 8 + 1, 1024)), dim3(256), 0, s, x, n, out);
   DX_LAUNCH_CHECK();
   return DX_OK;
@@ -334,11 +339,26 @@ extern "C" int dx_sumsq(const float* x, long n, float* out, void* stream) {
 
 extern "C" int dx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                             float eps, float weight_decay, int step, const float* grad_norm_sq, float clip_thresh,
-                            float* grad_norm_sq_accum, void* stream) {
-  DX_REQUIRE(p && g && m && v && n > 0 && step >= 1, DX_ERR_ARG, "dx_adam_step: bad arguments");
+                            float* grad_norm_sq_accum, const DxStepScalars* scalars, void* stream) {
+  DX_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || scalars), DX_ERR_ARG, "dx_adam_step: bad arguments");
+  if (step < 1) step = 1;   // (unused when `scalars` carries the bias corrections)
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, (float)bc1, (float)sqrt(bc2), grad_norm_sq, clip_thresh, grad_norm_sq_accum);
+                     weight_decay, (float)bc1, (float)sqrt(bc2), grad_norm_sq, clip_thresh, grad_norm_sq_accum, scalars);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
+// ---- the device-side step block (DxStepScalars): one single-thread launch per optimizer step, in front of the (captured) step
+__global__ void step_scalars_kernel(DxStepScalars* out, uint64_t salt, float lr, float bc1, float bc2_sqrt, float w_speaker, int step) {
+  out->seed_salt = salt; out->lr = lr; out->bc1 = bc1; out->bc2_sqrt = bc2_sqrt; out->w_speaker = w_speaker; out->step = step;
+}
+
+extern "C" int dx_step_scalars_set(DxStepScalars* dev, uint64_t seed_salt, float lr, float beta1, float beta2, int step, float w_speaker,
+                                   void* stream) {
+  DX_REQUIRE(dev && step >= 1, DX_ERR_ARG, "dx_step_scalars_set: bad arguments");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dev, seed_salt, lr, (float)bc1, (float)sqrt(bc2), w_speaker, step);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }

@@ -58,9 +58,16 @@ def lib():
     return _lib
 
 
+AFTER_LAUNCH = None     # one-shot callback run after the next entry point returns (model._flush_wgrads, capturing only)
+
+
 def check(rc):
+    global AFTER_LAUNCH
     if rc != 0:
         raise RuntimeError(f'libdaftexprt_hip error {rc}: {lib().dx_last_error().decode()}')
+    if AFTER_LAUNCH is not None:
+        cb, AFTER_LAUNCH = AFTER_LAUNCH, None
+        cb()
 
 
 def ptr(t):

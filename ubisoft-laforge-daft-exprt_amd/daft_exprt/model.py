@@ -128,6 +128,7 @@ def _init_tensor(shape, init, gen):
     return u / math.sqrt(float(arg))   # torch default Linear / Conv1d bias and kaiming(a=sqrt 5) weight bound
 
 
+_CAPTURE_ORDER = __import__('os').environ.get('DX_CAPTURE_ORDER', 'defer')   # defer | anchor | none: see _flush_wgrads
 _SKIP_WGRAD = bool(int(__import__('os').environ.get('DX_SKIP_WGRAD', '0')))
 _BATCH_PREP = bool(int(__import__('os').environ.get('DX_BATCH_PREP', '1')))   # 0: tile plans / launch orders by their own (lazy) launches (A/B switch)
 _MEL_BF16 = bool(int(__import__('os').environ.get('DX_MEL_BF16', '1')))   # 0: the first pre-net conv and its weight gradient read the fp32 mel rows (A/B switch)
@@ -204,6 +205,7 @@ class DaftExprt(nn.Module):
         self._wgrad_defer_rows = int(__import__('os').environ.get('DX_WGRAD_DEFER_ROWS', '0'))   # see _block_done (0: never defer; 16384 measured 7.99 vs 7.79 ms)
         self._wgrad_ws = None
         self._hop = None
+        self._side_deferred = None
         self.fuse_ln_backward = bool(int(__import__('os').environ.get('DX_FUSE_LN_BWD', '1')))   # see _fft_block_bwd
         self.balanced_tiles = bool(int(__import__('os').environ.get('DX_BALANCED_TILES', '1')))   # see _plan
         self._plans = {}
@@ -211,7 +213,7 @@ class DaftExprt(nn.Module):
         self._plan_min_rows = int(__import__('os').environ.get('DX_PLAN_MIN_ROWS', '0'))
         self._plan_small_rows = int(__import__('os').environ.get('DX_PLAN_SMALL_ROWS', '0'))   # > 0: a batch of fewer than 256 x this many padded rows gets B * N / this tiles (measured at the phoneme level: 96 -> +0.03 ms, 128 / 192 -> +0.17 ms per step: a workgroup's chunk loop is bound by its own latency chain, not by the number of workgroups pulling weights)
         self._plan_k1 = bool(int(__import__('os').environ.get('DX_PLAN_K1', '0')))   # balanced tiles also for the k = 1 QKV data gradient + LayerNorm backward (measured: 8.78 vs 8.74 ms)
-        self._step_id, self._site, self._rank = 0, 0, 0
+        self._step_id, self._site, self._rank, self._capture_step0 = 0, 0, 0, 0
         self._trace = None    # tests set this to a list: every stage appends (kind, names, input, film, lengths, output)
         self._trace_bwd = None   # likewise for the backward pass: (kind, saved, saved_below, gradient in, gradient out)
         self._pos = None
@@ -448,9 +450,18 @@ class DaftExprt(nn.Module):
         self._rank = int(rank)
 
     def _seed(self):
+        ''' dropout seed of the next site of this forward pass: a function of (hparams seed, step, site, rank).  While a step is being
+            captured (`ops.STEP_PTR` set) the absolute step stays out of the by-value seed -- only the micro-batch's offset from the
+            capture's first one goes in -- and the kernels add `step_salt()` from the device-side step block: same sum mod 2^63, so
+            a replayed step draws the masks the eager step with the same step id draws. '''
         self._site += 1
-        return (int(self.hp.seed) * 0x9E3779B1 + self._step_id * 0x85EBCA77 + self._site * 0xC2B2AE3D +
+        step = self._step_id if ops.STEP_PTR is None else self._step_id - self._capture_step0
+        return (int(self.hp.seed) * 0x9E3779B1 + step * 0x85EBCA77 + self._site * 0xC2B2AE3D +
                 self._rank * 0x27D4EB2F165667C5) & _MASK63
+
+    def step_salt(self, step_id=None):
+        ''' the step's share of every dropout seed, for the device-side step block (see `_seed`) '''
+        return ((self._step_id if step_id is None else step_id) * 0x85EBCA77) & _MASK63
 
     # ------------------------------------------------------------------ reference surface
     def parse_batch(self, gpu, batch):
@@ -566,10 +577,10 @@ class DaftExprt(nn.Module):
         P, hp, cfg, pre = self._P, self.hp, self.hp.prosody_encoder, 'prosody_encoder'
         p_conv = cfg['conv_dropout'] if train else 0.
         s = _Saved()
-        x = ops.transpose_last2(mel_specs.float().contiguous())   # (B, T, n_mel) channel-last rows (no-op casts on the step path: parse_batch normalises)
-        if self.cd == torch.bfloat16 and _MEL_BF16:
-            x = x.to(torch.bfloat16)                     # = the rounding the first conv applies at operand load; its weight gradient (the
-            # last launch of the backward pass, nothing left to hide it under) then runs on the LDS-DMA ring kernel
+        # (B, T, n_mel) channel-last rows (no-op casts on the step path: parse_batch normalises); in bf16 mode the transpose emits bf16
+        # = the rounding the first conv applies at operand load; its weight gradient (the last launch of the backward pass, nothing
+        # left to hide it under) then runs on the LDS-DMA ring kernel
+        x = ops.transpose_last2(mel_specs.float().contiguous(), torch.bfloat16 if (self.cd == torch.bfloat16 and _MEL_BF16) else torch.float32)
         wide = self.cd
         l1, s.c1 = self._conv_ln_fwd(W, f'{pre}.convs.0', f'{pre}.convs.2', x, p_conv, wide, save, skip=output_lengths)
         l2, s.c2 = self._conv_ln_fwd(W, f'{pre}.convs.4', f'{pre}.convs.6', l1, p_conv, wide, save, skip=output_lengths)
@@ -731,6 +742,28 @@ class DaftExprt(nn.Module):
         # `with torch.cuda.stream(side)` block per launch cost 15 us of host time
         self._hop.record()
         side.wait_event(self._hop)
+        if ops.STEP_PTR is not None and _CAPTURE_ORDER == 'defer':
+            # CAPTURING.  The graph executor keeps the FIRST node recorded behind a fork on the forking node's hardware queue and moves
+            # the others to another one: with the weight gradients recorded first, the data-gradient chain hopped queues at every
+            # fork and queued up behind weight-gradient kernels (8.57 vs 7.97 ms per replayed step).  So the side-stream launches of
+            # this flush are recorded right AFTER the next launch on the launch stream (their dependencies are those of the event
+            # hop above either way)
+            self._issue_deferred()
+            self._side_deferred = pend
+            ops.H.AFTER_LAUNCH = self._issue_deferred
+            return
+        if ops.STEP_PTR is not None and _CAPTURE_ORDER == 'anchor':   # the same with an empty launch as the first node (dx_anchor)
+            ops.H.check(ops.H.lib().dx_anchor(ops.H.stream()))
+        self._issue_side(pend)
+
+    def _issue_deferred(self):
+        pend, self._side_deferred = self._side_deferred, None
+        ops.H.AFTER_LAUNCH = None
+        if pend:
+            self._issue_side(pend)
+
+    def _issue_side(self, pend):
+        side = self._side_stream
         need = max(ops.wgrad_ws_floats(dy.shape[0], dy.shape[1], x.shape[2], dy.shape[2], dw.shape[2] if dw.dim() == 3 else 1)
                    for dy, x, dw, db, lengths in pend)
         if self._wgrad_ws is None or self._wgrad_ws.numel() < need:
@@ -873,6 +906,8 @@ class DaftExprt(nn.Module):
                 both; only the end of the backward pass joins the side stream into the main one (optimizer next). '''
             side = self._side_stream
             self._flush_wgrads()
+            if section_done is not None or last:
+                self._issue_deferred()                # (capturing: nothing may stay queued across a hook or the final join)
             if section_done is not None:
                 if side is not None:
                     side.wait_stream(torch.cuda.current_stream())

@@ -11,6 +11,11 @@ _INF = float('inf')
 DETERMINISTIC_LN = False
 WGRAD_WORKSPACE = bool(int(os.environ.get('DX_WGRAD_WORKSPACE', '1')))   # 0: fp32 atomics on dW instead of partial tiles + reduce
 
+# Device pointer of the step block (DxStepScalars, include/daft_exprt_hip.h) while a step is being CAPTURED into a hipGraph
+# (`train.CapturedStep`): the dropout kernels add its salt to their by-value seeds, Adam and the loss read this iteration's learning
+# rate / bias corrections / adversarial weight from it.  None = eager launches, every scalar by value.
+STEP_PTR = None
+
 # Optional per-kernel timing probe used by bench.py: {family: [(start_event, end_event, padded_flops, N), ...]}.
 # Events are recorded on torch's current stream, which is the stream every kernel is launched on.
 PROBE = None
@@ -147,7 +152,7 @@ def conv1d_ln(x, w_packed, bias, residual, gamma, beta, lengths, film=None, save
                                      H.ptr(gamma), H.ptr(beta), H.ptr(film), film.stride(0) if film is not None else 0, H.ptr(lengths),
                                      H.ptr(y), H.ptr(y_lp), H.ptr(s_out), H.ptr(mean), H.ptr(rstd), B, N, Cin, taps, float(p_pre),
                                      int(seed_pre), *pargs, H.ptr(w2_packed if y2 is not None else None),
-                                     H.ptr(b2 if y2 is not None else None), H.ptr(y2), n2, H.stream()))
+                                     H.ptr(b2 if y2 is not None else None), H.ptr(y2), n2, STEP_PTR, H.stream()))
     if w2_packed is not None:
         return y, y_lp, s_out, mean, rstd, y2
     return y, y_lp, s_out, mean, rstd
@@ -179,7 +184,7 @@ def conv1d_lnbwd(x, w_packed, y_inout, s_in, mean, rstd, gamma, beta, lengths, d
                                         H.ptr(mean), H.ptr(rstd), H.ptr(gamma), H.ptr(beta), H.ptr(film), ldf, H.ptr(lengths),
                                         H.ptr(dx_lp), H.ptr(dgamma), H.ptr(dbeta), H.ptr(dfilm), lddf, B, N, Cin, taps,
                                         float(p_pre), int(seed_pre), *pargs, H.ptr(w2_packed if y2 is not None else None), H.ptr(y2),
-                                        H.stream()))
+                                        STEP_PTR, H.stream()))
     if w2_packed is None:
         return dx_lp
     if y2 is None:
@@ -326,7 +331,7 @@ def layernorm_fwd(x, gamma, beta, residual=None, film=None, lengths=None, out_dt
     ldf = film.stride(0) if film is not None else 0
     H.check(H.lib().dx_layernorm_fwd(H.ptr(x), H.dt(x), H.ptr(residual), H.ptr(gamma), H.ptr(beta), H.ptr(film), ldf,
                                      H.ptr(lengths), H.ptr(skip_lengths), H.ptr(y), H.dt(y), H.ptr(y_lp), H.ptr(s_out), H.ptr(mean), H.ptr(rstd), B, N, C,
-                                     float(p_pre), int(seed_pre), float(p_post), int(seed_post), H.stream()))
+                                     float(p_pre), int(seed_pre), float(p_post), int(seed_post), STEP_PTR, H.stream()))
     if lp_copy:
         return y, y_lp, s_out, mean, rstd
     return y, s_out, mean, rstd
@@ -350,7 +355,7 @@ def layernorm_bwd(dy, s_in, mean, rstd, gamma, beta, dgamma, dbeta, film=None, d
     H.check(H.lib().dx_layernorm_bwd(H.ptr(dy), H.dt(dy), H.ptr(s_in), H.dt(s_in), H.ptr(mean), H.ptr(rstd), H.ptr(gamma),
                                      H.ptr(beta), H.ptr(film), ldf, H.ptr(lengths), H.ptr(skip_lengths), H.ptr(ds), H.ptr(dx_pre), H.ptr(dx_lp), H.dt(ds),
                                      H.ptr(dgamma), H.ptr(dbeta), H.ptr(dfilm), lddf, B, N, C, float(p_pre), int(seed_pre),
-                                     float(p_post), int(seed_post), int(relu_input), H.ptr(ws), H.stream()))
+                                     float(p_post), int(seed_post), int(relu_input), H.ptr(ws), STEP_PTR, H.stream()))
     if lp_only:
         return ds, dx_lp
     return ds, (dx_pre if dx_pre is not None else ds)
@@ -371,24 +376,31 @@ def attention_fwd(qkv, lengths, nb_heads, p_drop=0., seed=0, need_lse=True, orde
     o = torch.empty((B, N, E), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, nb_heads, N), dtype=torch.float32, device=qkv.device) if need_lse else None
     H.check(H.lib().dx_attention_fwd(H.ptr(qkv), H.dt(qkv), H.ptr(lengths), H.ptr(order), H.ptr(o), H.ptr(lse), B, N, nb_heads, E,
-                                     float(p_drop), int(seed), H.stream()))
+                                     float(p_drop), int(seed), STEP_PTR, H.stream()))
     return o, lse
 
 
 ATTN_AUTO, ATTN_TWO_PASS, ATTN_FUSED = 0, 1, 2
-_ATTN_WS = {}
+_ATTN_WS = {}        # (device, raw stream) -> [scratch floats (grow-only), arrival counters (int32, zeroed once)]
+ATTN_WS_OWNER = None   # a graph capture in progress sets this to a dict of its own: its launches must not share (or outlive) the eager buffers
 
 
 def _attn_workspace(B, N, nb_heads, device):
-    ''' backward workspace (dx_attention_bwd_ws_floats), kept per (device, stream, shape): its arrival counters are zeroed once and
-        left valid by every call.  Calls on one stream run in order, so they can share it. '''
-    key = (device, torch.cuda.current_stream(device).cuda_stream, B, N, nb_heads)
-    ws = _ATTN_WS.get(key)
-    if ws is None:
-        if len(_ATTN_WS) > 16:
-            _ATTN_WS.clear()
-        ws = _ATTN_WS[key] = torch.zeros((H.lib().dx_attention_bwd_ws_floats(B, N, nb_heads),), dtype=torch.float32, device=device)
-    return ws
+    ''' (scratch, counters) of dx_attention_bwd for the current stream.  The scratch (delta + the fused kernel's dQ partials, ~50 MB at
+        B = 48 / T = 1000) needs no initialisation and nothing in it survives a call, so ONE grow-only buffer per stream serves every
+        batch shape (real data has a new N every batch); the arrival counters sit in a small buffer of their own, zeroed once -- every
+        launch leaves the counters it used at zero.  Calls on one stream run in order, so they can share both. '''
+    table = _ATTN_WS if ATTN_WS_OWNER is None else ATTN_WS_OWNER
+    key = (device, H.stream())
+    need, need_c = H.lib().dx_attention_bwd_ws_floats(B, N, nb_heads), H.lib().dx_attention_bwd_counters(B, nb_heads)
+    ent = table.get(key)
+    if ent is None:
+        ent = table[key] = [None, None]
+    if ent[0] is None or ent[0].numel() < need:
+        ent[0] = torch.empty((max(need, 1 << 20),), dtype=torch.float32, device=device)
+    if ent[1] is None or ent[1].numel() < need_c:
+        ent[1] = zeros((max(need_c, 4096),), device, dtype=torch.int32)
+    return ent[0], ent[1]
 
 
 def attention_bwd(qkv, o, d_o, lse, lengths, nb_heads, p_drop=0., seed=0, order=None, algo=ATTN_AUTO):
@@ -396,9 +408,9 @@ def attention_bwd(qkv, o, d_o, lse, lengths, nb_heads, p_drop=0., seed=0, order=
     E = E3 // 3
     assert d_o.is_contiguous() and d_o.dtype == qkv.dtype
     dqkv = torch.empty_like(qkv)
-    delta = _attn_workspace(B, N, nb_heads, qkv.device)
+    ws, counters = _attn_workspace(B, N, nb_heads, qkv.device)
     H.check(H.lib().dx_attention_bwd(H.ptr(qkv), H.ptr(o), H.ptr(d_o), H.dt(qkv), H.ptr(lse), H.ptr(lengths), H.ptr(order), H.ptr(dqkv),
-                                     H.ptr(delta), B, N, nb_heads, E, float(p_drop), int(seed), int(algo), H.stream()))
+                                     H.ptr(ws), H.ptr(counters), B, N, nb_heads, E, float(p_drop), int(seed), STEP_PTR, int(algo), H.stream()))
     return dqkv
 
 
@@ -506,12 +518,12 @@ def add_(dst, src):
     return dst
 
 
-def transpose_last2(x):
-    ''' (B, R, C) fp32 -> (B, C, R), contiguous '''
+def transpose_last2(x, out_dtype=torch.float32):
+    ''' (B, R, C) fp32 -> (B, C, R) in out_dtype (fp32 / bf16), contiguous '''
     B, R, C = x.shape
     assert x.is_contiguous() and x.dtype == torch.float32
-    y = torch.empty((B, C, R), dtype=torch.float32, device=x.device)
-    H.check(H.lib().dx_transpose_last2(H.ptr(x), H.ptr(y), B, R, C, H.stream()))
+    y = torch.empty((B, C, R), dtype=out_dtype, device=x.device)
+    H.check(H.lib().dx_transpose_last2(H.ptr(x), H.ptr(y), H.dt(y), B, R, C, H.stream()))
     return y
 
 
@@ -607,7 +619,7 @@ def loss_fwd_bwd(dur, energy, pitch, dur_t, energy_t, pitch_t, in_lengths, mel, 
                                     H.ptr(g.get('d_pitch')), H.ptr(g.get('d_mel')), H.ptr(g.get('d_spk')), H.ptr(d_post_mult),
                                     H.ptr(terms), B, L, T, n_mel, spk_logits.shape[1],
                                     post_mult.numel() if post_mult is not None else 0, *[float(w) for w in weights],
-                                    float(grad_scale), int(d_mel_transposed), H.stream()))
+                                    float(grad_scale), int(d_mel_transposed), STEP_PTR, H.stream()))
     return terms
 
 
@@ -618,9 +630,16 @@ def sumsq(x, out=None):
 
 
 def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, grad_norm_sq=None, clip_thresh=_INF, norm_accum=None):
+    ''' with ops.STEP_PTR set (captured step) lr and the bias corrections come from the device-side step block '''
     H.check(H.lib().dx_adam_step(H.ptr(p), H.ptr(g), H.ptr(m), H.ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
                                  float(eps), float(weight_decay), int(step), H.ptr(grad_norm_sq), float(clip_thresh),
-                                 H.ptr(norm_accum), H.stream()))
+                                 H.ptr(norm_accum), STEP_PTR, H.stream()))
+
+
+def step_scalars_set(block, seed_salt, lr, betas, step, w_speaker):
+    ''' fill the device-side step block (a 48-byte uint8 tensor) for the step about to be replayed (dx_step_scalars_set) '''
+    H.check(H.lib().dx_step_scalars_set(H.ptr(block), int(seed_salt), float(lr), float(betas[0]), float(betas[1]), int(step),
+                                        float(w_speaker), H.stream()))
 
 
 def scale_(x, s):

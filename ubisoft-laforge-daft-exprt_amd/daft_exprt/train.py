@@ -32,6 +32,7 @@ from daft_exprt.data_loader import DaftExprtDataCollate, SyntheticUtterances, pr
 from daft_exprt.hparams import HyperParams
 from daft_exprt.loss import DaftExprtLoss, KEYS
 from daft_exprt.model import DaftExprt
+from daft_exprt import ops
 from daft_exprt.optim import FusedAdam
 from daft_exprt.parallel import GradReducer
 
@@ -113,9 +114,20 @@ class Trainer(object):
         # the last all-reduce); on ONE GPU the slice updates only compete with the backward kernels for HBM (measured 8.29 vs 8.08 ms
         # per step), so the whole-buffer step (one launch, gradient norm summed on the way) stays the default there
         mode = os.environ.get('DX_SECTIONED_ADAM', 'auto')
-        self.sectioned = (world_size > 1) if mode == 'auto' else bool(int(mode))
+        assert self.reducer.world == world_size, f'Trainer(world_size={world_size}) inside a process group of {self.reducer.world} ranks'
+        # the per-bucket update orders itself behind the collective through `work.wait()`, which is a STREAM wait only with RCCL
+        # (backend "nccl"); gloo's wait blocks the host inside the backward hook and would stall kernel issue for the rest of the
+        # backward pass, so any other backend keeps the whole-buffer step
+        stream_ordered = world_size > 1 and dist.is_initialized() and dist.get_backend() == 'nccl' and \
+            not int(os.environ.get('TORCH_NCCL_BLOCKING_WAIT', '0') or 0)
+        self.sectioned = stream_ordered if mode == 'auto' else bool(int(mode))
         self._opt_stream = self._sec_event = None
         self._done = set()
+        # whole-step hipGraphs, keyed on the addresses and shapes of the step's input tensors (`CapturedStep`): one rank only -- a
+        # captured RCCL collective is untested here -- and only with the whole-buffer optimizer
+        use_graph = os.environ.get('DX_STEP_GRAPH', 'auto')
+        self.captured = CapturedStep(self) if (world_size == 1 and (use_graph == 'auto' or bool(int(use_graph))) and use_graph != '0'
+                                               and model.flat_parameters().is_cuda) else None
 
     def _section_done(self, name):
         ''' backward hook (runs with the weight-gradient side stream current, after it has caught up with the compute stream):
@@ -135,7 +147,15 @@ class Trainer(object):
 
     def step(self, micro_batches, iteration):
         ''' micro_batches: list of (inputs, targets) already on the device (len = accumulation_steps).
-            Returns (terms (8,) device tensor summed over micro-batches / accumulation_steps, grad_norm_sq device scalar). '''
+            Returns (terms (8,) device tensor summed over micro-batches / accumulation_steps, grad_norm_sq device scalar).
+            The tensors may live in buffers a later call overwrites (captured steps reuse theirs): consume them -- or enqueue the
+            copy that does -- before the next call. '''
+        if self.captured is not None and self.world == 1 and not self.sectioned:
+            return self.captured.step(micro_batches, iteration)
+        return self.step_eager(micro_batches, iteration)
+
+    def step_eager(self, micro_batches, iteration):
+        ''' the step as individual launches (also what a capture records) '''
         hp, model = self.hp, self.model
         accum = len(micro_batches)
         lr = update_learning_rate(hp, iteration)
@@ -153,7 +173,7 @@ class Trainer(object):
             last = k == accum - 1
             hook = self._section_done if (last and (self.world > 1 or self._sectioned_now)) else None
             terms = model.forward_backward(inputs, targets, weights, grad_scale=scale, section_done=hook)
-            total = terms if total is None else total + terms
+            total = terms if total is None else ops.add_(total, terms)
         main = torch.cuda.current_stream()
         if self._sectioned_now:
             assert self._done == set(sec for sec, _, _ in self.reducer.buckets), 'a gradient bucket was never reported'
@@ -164,8 +184,129 @@ class Trainer(object):
             self.reducer.wait()
             gnorm_sq = self.optimizer.step()
         model.zero_grad()
-        self.terms = total / accum
+        if accum > 1:
+            ops.scale_(total, 1. / accum)
+        self.terms = total
         return self.terms, gnorm_sq
+
+
+class CapturedStep(object):
+    ''' `Trainer.step` as ONE hipGraph launch per optimizer step.
+
+        A step is ~330 C-ABI calls from Python (~3.3 ms of host time at B = 48, ~10 ms for the reference's 16 x 3 schedule, whose
+        kernels are a third the size): the phoneme-level stretches of a B = 48 step and the WHOLE 16 x 3 step are host-bound.  A
+        captured step costs the host one small launch (the step block) + one graph launch.
+
+        What makes the step capturable: every per-step scalar lives in device memory (`DxStepScalars`: dropout salt, learning
+        rate, Adam's bias corrections, the adversarial loss weight -- `ops.STEP_PTR`), there is no host sync inside the step, the
+        side-stream weight gradients fork from and join the launch stream inside the step, and every buffer the step allocates
+        comes from the graph's private pool.  A graph is keyed on the ADDRESSES and shapes of the step's input tensors (it reads
+        them in place: no staging copies) and on the accumulation count; a key is captured the second time it is seen, so ragged
+        real data -- a new (L_max, T_max) almost every batch -- simply stays on the eager path, while resident batches and
+        fixed-shape loaders (whose batches cycle through a few allocator blocks) replay.  At most `max_graphs` graphs are kept, each
+        owning its activations (~4 GB at B = 48, T = 1000); a full cache only gives up its least recently replayed graph when that
+        graph has been idle for 4 x max_graphs steps (a round-robin over more keys than slots would otherwise re-capture every step).
+
+        Replays are bit-identical to eager steps with the same step ids (`tests/test_gpu_captured_step.py`). '''
+    def __init__(self, trainer, max_graphs=None, capture_after=2):
+        self.tr = trainer
+        self.max_graphs = int(os.environ.get('DX_STEP_GRAPH_MAX', '8')) if max_graphs is None else max_graphs
+        self.capture_after = capture_after
+        self.cache, self.seen = {}, {}
+        self.block = None            # DxStepScalars on the device
+        self.replays = self.captures = self.eager_steps = self.ticks = 0
+        self.broken = None
+
+    @staticmethod
+    def key(micro_batches):
+        return tuple((t.data_ptr(), tuple(t.shape)) for inputs, _ in micro_batches for t in inputs)
+
+    def step(self, micro_batches, iteration):
+        tr = self.tr
+        self.ticks += 1
+        if self.broken is not None or ops.PROBE is not None or tr.model._trace is not None or tr.model._trace_bwd is not None:
+            self.eager_steps += 1
+            return tr.step_eager(micro_batches, iteration)
+        key = self.key(micro_batches)
+        ent = self.cache.get(key)
+        if ent is None:
+            n = self.seen[key] = self.seen.get(key, 0) + 1
+            if len(self.seen) > 4096:
+                self.seen = {key: n}
+            full = len(self.cache) >= self.max_graphs
+            if n < self.capture_after or (full and self.ticks - min(e['tick'] for e in self.cache.values()) < 4 * self.max_graphs):
+                self.eager_steps += 1
+                return tr.step_eager(micro_batches, iteration)
+            ent = self._capture(key, micro_batches, iteration)
+            if ent is None:
+                self.eager_steps += 1
+                return tr.step_eager(micro_batches, iteration)
+        return self._replay(ent, len(micro_batches), iteration)
+
+    def _scalars(self, iteration):
+        ''' this iteration's scalars into the step block (one single-thread launch in front of the graph) '''
+        tr = self.tr
+        opt, model = tr.optimizer, tr.model
+        lr = update_learning_rate(tr.hp, iteration)
+        opt.param_groups[0]['lr'] = lr
+        opt.step_count += 1
+        ops.step_scalars_set(self.block, model.step_salt(), lr, opt.param_groups[0]['betas'], opt.step_count,
+                             tr.criterion.weights(iteration)[0])
+
+    def _replay(self, ent, accum, iteration):
+        tr = self.tr
+        self._scalars(iteration)
+        tr.model._step_id += accum             # what the captured forward passes would have counted
+        ent['graph'].replay()
+        tr.model.mark_updated()                # the parameters changed on the device: an eager call that follows re-packs its operand copies
+        self.replays += 1
+        ent['tick'] = self.ticks
+        tr.terms, tr.model.last_outputs = ent['terms'], ent['outputs']
+        return ent['terms'], ent['gnorm_sq']
+
+    def prepare(self, micro_batches, iteration=1):
+        ''' set-up call: make the graph of this step exist NOW (an eager step first, so that every kernel is loaded and the host-side
+            caches are built -- a capture executes nothing -- then the capture), instead of on the second time `step` sees the key.
+            Returns True when a graph for the key is cached afterwards. '''
+        key = self.key(micro_batches)
+        if key not in self.cache and self.broken is None and len(self.cache) < self.max_graphs:
+            self.tr.step_eager(micro_batches, iteration)
+            self._capture(key, micro_batches, iteration)
+        return key in self.cache
+
+    def _capture(self, key, micro_batches, iteration):
+        tr = self.tr
+        model, opt = tr.model, tr.optimizer
+        dev = model.flat_parameters().device
+        if self.block is None:
+            self.block = torch.zeros(48, dtype=torch.uint8, device=dev)
+        while len(self.cache) >= self.max_graphs:           # least recently replayed graph (and its pool) goes
+            del self.cache[min(self.cache, key=lambda k: self.cache[k]['tick'])]
+        # host-side state the captured launches advance WITHOUT executing: put back afterwards
+        step_id, step_count, lr = model._step_id, opt.step_count, opt.param_groups[0]['lr']
+        eager_ws, model._wgrad_ws = model._wgrad_ws, None    # the graph gets scratch of its own (it must outlive every replay)
+        own_ws = {}
+        model.mark_updated()                                  # the graph always begins by re-packing the operand copies
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(dev)
+        try:
+            ops.STEP_PTR, ops.ATTN_WS_OWNER, model._capture_step0 = self.block.data_ptr(), own_ws, step_id
+            with torch.cuda.graph(graph):
+                terms, gnorm_sq = tr.step_eager(micro_batches, iteration)
+        except Exception as e:   # noqa: BLE001 -- a capture that cannot be recorded must not take the training run down
+            self.broken = f'{type(e).__name__}: {e}'
+            _logger.warning(f'step capture failed, staying on eager launches: {self.broken}')
+            torch.cuda.synchronize(dev)
+            return None
+        finally:
+            ops.STEP_PTR, ops.ATTN_WS_OWNER, ops.H.AFTER_LAUNCH, model._side_deferred = None, None, None, None
+            graph_ws, model._wgrad_ws = model._wgrad_ws, eager_ws
+            model._step_id, opt.step_count, opt.param_groups[0]['lr'] = step_id, step_count, lr
+            model.mark_updated()
+        self.captures += 1
+        ent = self.cache[key] = {'graph': graph, 'terms': terms, 'gnorm_sq': gnorm_sq, 'tick': self.ticks, 'outputs': model.last_outputs,
+                                 'keep': (own_ws, graph_ws, [t for mb in micro_batches for t in mb[0]])}
+        return ent
 
 
 def validate(gpu, model, criterion, val_loader, hparams):
@@ -198,10 +339,13 @@ def _loaders(hparams, rank, world, distributed):
     ds = SyntheticUtterances(hparams, n_items, seed=hparams.seed, force_first_full=False)
     idx = list(range(rank, n_items, world))   # DistributedSampler(shuffle=False) striding (data_loader.py:232)
     subset = torch.utils.data.Subset(ds, idx)
-    workers = int(getattr(hparams, 'synthetic_workers', 16))   # an utterance costs ~2 ms of numpy (100 ms per batch of 48): 16 processes feed an 8 ms step
+    # an utterance costs ~2 ms of numpy (100 ms per batch of 48): 16 processes feed an 8 ms step; with several ranks on one host the
+    # ranks share its cores.  The workers come from a fork SERVER: forking a process that already holds HIP / RCCL threads is fragile
+    workers = int(getattr(hparams, 'synthetic_workers', max(1, min(16, (os.cpu_count() or 16) // max(1, world)))))
     return torch.utils.data.DataLoader(subset, batch_size=hparams.batch_size, shuffle=False, drop_last=True, collate_fn=collate,
                                        num_workers=workers, pin_memory=True, persistent_workers=workers > 0,
-                                       prefetch_factor=4 if workers > 0 else None), None
+                                       prefetch_factor=4 if workers > 0 else None,
+                                       multiprocessing_context='forkserver' if workers > 0 else None), None
 
 
 def train(gpu, hparams, log_file):
@@ -258,10 +402,11 @@ def train(gpu, hparams, log_file):
         stats_ready.synchronize()            # waits for the END OF THE PREVIOUS step only
         values = stats_host.tolist()
         tot_loss, grad_norm = values[7], values[8]
+        duration = now - start               # host-enqueue interval of the iteration (the device runs one step behind the host)
+        start = now
         if not math.isfinite(tot_loss):
             return False
         if rank == 0:
-            duration = now - start
             total_time += duration
             _logger.info(f'Train loss [{it_p}]: {tot_loss:.6f} Grad Norm {grad_norm:.6f} {duration:.2f}s/it (LR {lr_p:.6f})')
             with open(metrics_path, 'a') as f:   # scalar names of DaftExprtLogger.log_training (logger.py:26-32)
@@ -270,7 +415,6 @@ def train(gpu, hparams, log_file):
                        'DaftExprt.training/loss': tot_loss, 'valid_frames': frames_p}
                 rec.update({f'DaftExprt.training/{k}': v for k, v in zip(KEYS, values[:7])})
                 f.write(json.dumps(rec) + '\n')
-        start = now
         return True
 
     copy_stream = torch.cuda.Stream(device=gpu)
