@@ -3,6 +3,9 @@
 One object per source under csrc/ (compiled in parallel, rebuilt only when the source or a
 header is newer), linked into csrc/libdaftexprt_hip.so -- kept IN-TREE so that it travels to
 the GPU box with the repo snapshot.
+
+A/B builds: `DX_BUILD_TAG=ldt40 DX_EXTRA_HIPCC_FLAGS=-DDX_FB_LDT=40 python build_hip.py` writes csrc/*.ldt40.o and
+csrc/libdaftexprt_hip.ldt40.so next to the default build; run with DX_HIP_LIB=<that .so>.
 """
 import os
 import subprocess
@@ -12,7 +15,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
-LIB = os.path.join(CSRC, 'libdaftexprt_hip.so')
+TAG = os.environ.get('DX_BUILD_TAG', '')
+SUFFIX = f'.{TAG}' if TAG else ''
+LIB = os.path.join(CSRC, f'libdaftexprt_hip{SUFFIX}.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-Wno-unused-result'] + \
     os.environ.get('DX_EXTRA_HIPCC_FLAGS', '').split()
@@ -29,7 +34,7 @@ def _headers_mtime():
 
 
 def _compile(src):
-    obj = os.path.join(CSRC, os.path.splitext(src)[0] + '.o')
+    obj = os.path.join(CSRC, os.path.splitext(src)[0] + SUFFIX + '.o')
     path = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), _headers_mtime()):
         return obj, False

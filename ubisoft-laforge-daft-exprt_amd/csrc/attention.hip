@@ -725,7 +725,13 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : (sizeof(TC) == 4 ? 1 : 2)) void
 //     and writes dQ -- two terms, so the sum does not depend on who arrives first.
 // N <= 1024; longer batches take the two-pass kernels.
 constexpr int FB_W = 4, FB_T = FB_W * 64, FB_KB = 4, FB_QT = 128, FB_KEYS = FB_W * FB_KB * 32, FB_MAXN = 2 * FB_KEYS;
-constexpr int FB_LDK = 24, FB_LDT = 40;
+#ifndef DX_FB_LDT
+#define DX_FB_LDT 36
+#endif
+// FB_LDT: row stride of the wave-private [query][key] tiles.  36 elements = 18 banks: the 32 rows of a 64-bit tile store start on 32
+// distinct even banks and the 4 rows x 32 bytes of one 16-lane transposed read fall on 32 distinct banks; 40 (20 banks) made rows r
+// and r + 16 collide on the stores and rows 0 and 3 of every transposed read overlap
+constexpr int FB_LDK = 24, FB_LDT = DX_FB_LDT;
 
 __device__ __forceinline__ f32x4 dx_mma16(f32x4 acc, const bf16x8& a, const bf16x8& b) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);

@@ -143,7 +143,9 @@ __device__ unsigned long long dx_cg_chunk[2 * 64 * 4];   // workgroup 40, loader
 #define CG_CHUNK(who, k, i)
 #endif
 template <typename TA, typename TC, typename TO, typename TG, int TAPS, int MI, int BK, int LNM = 0, int RING = 0>
-__global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : (MI == 1 ? DX_CONV_WPS_NARROW : DX_CONV_WPS)) void conv_gemm_kernel(ConvArgs p) {
+// (fp32 activations feeding bf16 MFMAs at k = 3 -- instantiations off the bf16 step path, the LayerNorm kernels hand the GEMMs bf16 copies --
+// prefetch their K chunk as raw fp32: one wave per SIMD less than the bf16-input form instead of 28-52 bytes of scratch)
+__global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof(TA) == 4 && sizeof(TC) == 2 && TAPS == 3) ? (MI == 1 ? DX_CONV_WPS_NARROW - 1 : 1) : (MI == 1 ? DX_CONV_WPS_NARROW : DX_CONV_WPS))) void conv_gemm_kernel(ConvArgs p) {
   constexpr int LN = LNM == 3 ? 2 : LNM;
   constexpr bool LNFILM = LNM == 2;
   constexpr int BM = 64 * MI, KC = BK / 8;   // KC = 8-element chunks per row of a K chunk

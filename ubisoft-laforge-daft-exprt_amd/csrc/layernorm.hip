@@ -179,7 +179,8 @@ template <typename T, int V> struct RawVec { typedef T type __attribute__((ext_v
 // C = 1024 gamma / beta are re-read per row (L1-resident, 8 KB) instead of living in 32 registers -- the first version
 // held everything in fp32 registers: 292 VGPRs, one wave per SIMD, 1.5 TB/s.
 template <typename TI, typename TG, typename TD, int C, bool FILM>
-__global__ __launch_bounds__(256, C >= 1024 ? (FILM ? 1 : 3) : 4) void ln_bwd_kernel(LNBwdArgs a) {
+// (fp32 rows at C = 1024 -- the exact-parity mode -- prefetch twice the registers: 2 waves per SIMD instead of 3, no scratch)
+__global__ __launch_bounds__(256, C >= 1024 ? (FILM ? 1 : ((sizeof(TI) == 4 || sizeof(TG) == 4) ? 2 : 3)) : 4) void ln_bwd_kernel(LNBwdArgs a) {
   typedef Lay<C> L;
   constexpr bool REG_PARAMS = C <= 256;
   constexpr int NRED = FILM ? 4 : 2;

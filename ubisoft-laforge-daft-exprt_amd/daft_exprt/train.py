@@ -125,9 +125,13 @@ class Trainer(object):
         self._done = set()
         # whole-step hipGraphs, keyed on the addresses and shapes of the step's input tensors (`CapturedStep`): one rank only -- a
         # captured RCCL collective is untested here -- and only with the whole-buffer optimizer
+        # DX_STEP_GRAPH: 1 = every repeating step is captured, 0 = never, auto (default) = only steps small enough to be bound by the
+        # host's launch rate (`CapturedStep.AUTO_ROWS`): measured on MI355X / ROCm 7.0 a replay TIES the eager step from B = 16 up
+        # (7.73 vs 7.69 ms at B = 48, 13.2 vs 13.0 ms for 16 x 3) -- the dispatch boundaries cost the same ~2 us on the GPU side whether
+        # the host or the graph executor feeds them -- and wins below (3.88 vs 4.05 ms at B = 8)
         use_graph = os.environ.get('DX_STEP_GRAPH', 'auto')
-        self.captured = CapturedStep(self) if (world_size == 1 and (use_graph == 'auto' or bool(int(use_graph))) and use_graph != '0'
-                                               and model.flat_parameters().is_cuda) else None
+        self.captured = CapturedStep(self, auto=(use_graph == 'auto')) if (world_size == 1 and use_graph != '0' and
+                                                                           model.flat_parameters().is_cuda) else None
 
     def _section_done(self, name):
         ''' backward hook (runs with the weight-gradient side stream current, after it has caught up with the compute stream):
@@ -208,8 +212,10 @@ class CapturedStep(object):
         graph has been idle for 4 x max_graphs steps (a round-robin over more keys than slots would otherwise re-capture every step).
 
         Replays are bit-identical to eager steps with the same step ids (`tests/test_gpu_captured_step.py`). '''
-    def __init__(self, trainer, max_graphs=None, capture_after=2):
-        self.tr = trainer
+    AUTO_ROWS = 12288     # auto mode: capture only while B x T_max of every micro-batch is below this many frame rows
+
+    def __init__(self, trainer, max_graphs=None, capture_after=2, auto=False):
+        self.tr, self.auto = trainer, auto
         self.max_graphs = int(os.environ.get('DX_STEP_GRAPH_MAX', '8')) if max_graphs is None else max_graphs
         self.capture_after = capture_after
         self.cache, self.seen = {}, {}
@@ -224,7 +230,8 @@ class CapturedStep(object):
     def step(self, micro_batches, iteration):
         tr = self.tr
         self.ticks += 1
-        if self.broken is not None or ops.PROBE is not None or tr.model._trace is not None or tr.model._trace_bwd is not None:
+        if self.broken is not None or ops.PROBE is not None or tr.model._trace is not None or tr.model._trace_bwd is not None or \
+                (self.auto and max(mb[0][8].shape[0] * mb[0][8].shape[2] for mb in micro_batches) >= self.AUTO_ROWS):
             self.eager_steps += 1
             return tr.step_eager(micro_batches, iteration)
         key = self.key(micro_batches)
