@@ -91,3 +91,81 @@ def test_sectioned_and_whole_buffer_optimizer_agree(monkeypatch):
     p_a, gn_a, st_a = _run(monkeypatch, 0, False, True)
     p_b, gn_b, st_b = _run(monkeypatch, 0, False, False)
     _same(p_a, p_b, st_a, st_b, gn_a, gn_b)
+
+
+def _run_snapshots(monkeypatch, producer_delay, sync, sectioned, steps=2):
+    ''' world-size-2 semantics over a STREAM-ORDERED fake backend: the collective is work on its own stream that starts when the stream
+        it was issued from reaches the call (NCCL / RCCL's contract; gloo synchronises on the host and hides a missing dependency).
+        Every collective takes a SNAPSHOT of its bucket at the moment it executes.  `producer_delay` (cycles) makes the bucket's
+        PRODUCERS late: a device-side sleep in front of every batch of weight-gradient launches on the side stream and in front of the
+        data-gradient chain on the launch stream -- a collective (or a slice update) that is not ordered behind BOTH streams then
+        snapshots a bucket that is still being written. '''
+    from daft_exprt import parallel
+    from daft_exprt.data_loader import synthetic_batch
+    from daft_exprt.model import DaftExprt
+    from daft_exprt.train import Trainer
+    from tests.util import make_hparams
+    comm = torch.cuda.Stream(device=DEV)
+    snaps = []
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(comm):
+            comm.wait_event(ready)
+            snaps.append(t.clone())                # what a real all-reduce would have sent
+            t.mul_(-1.)                            # (sign flip: Adam is blind to a gradient scale, not to its sign)
+            done = torch.cuda.Event()
+            done.record(comm)
+        if sync:
+            torch.cuda.synchronize()
+        return _Work(done)
+
+    monkeypatch.setattr(parallel.dist, 'all_reduce', fake_all_reduce)
+    monkeypatch.setenv('DX_SECTIONED_ADAM', '1' if sectioned else '0')
+    if producer_delay:
+        orig_issue, orig_flush = DaftExprt._issue_side, DaftExprt._flush_wgrads
+
+        def late_issue(self, pend):
+            with torch.cuda.stream(self._side_stream):
+                torch.cuda._sleep(producer_delay)              # the weight gradients of this block start late
+            return orig_issue(self, pend)
+
+        def late_flush(self):
+            if self._wgrad_pending:
+                torch.cuda._sleep(producer_delay // 4)         # ... and the data-gradient chain is held up as well
+            return orig_flush(self)
+        monkeypatch.setattr(DaftExprt, '_issue_side', late_issue)
+        monkeypatch.setattr(DaftExprt, '_flush_wgrads', late_flush)
+    hp = make_hparams(compute_dtype='bf16', batch_size=4, accumulation_steps=2)
+    torch.manual_seed(7)
+    model = DaftExprt(hp).to(DEV).train()
+    trainer = Trainer(model, hp, 1)
+    trainer.world = trainer.reducer.world = 2
+    for it in range(steps):
+        micro = []
+        for k in range(2):
+            cb = synthetic_batch(hp, 4, seed=50 + 10 * it + k, t_max=200, force_first_full=True, l_range=(6, 30))
+            inputs, targets, _ = model.parse_batch(DEV, cb)
+            micro.append((inputs, targets))
+        if sync:
+            torch.cuda.synchronize()
+        trainer.step(micro, 20000 + it)
+    torch.cuda.synchronize()
+    return snaps, model.flat_parameters().clone(), [n for n, _, _ in trainer.reducer.buckets]
+
+
+@pytest.mark.parametrize('sectioned', [True, False])
+def test_collective_reads_a_bucket_only_after_every_producer(monkeypatch, sectioned):
+    ''' canary for the PRODUCER side of the overlap: with the weight-gradient stream and the launch stream both running late, what
+        each collective reads must still be the finished bucket -- compared with the same step run under full synchronisation '''
+    ref, p_ref, names = _run_snapshots(monkeypatch, 0, True, sectioned)
+    late, p_late, _ = _run_snapshots(monkeypatch, 3_000_000, False, sectioned)        # ~1.5 ms per delay at 2 GHz, ~25 delays per step
+    assert len(ref) == len(late) == 2 * len(names)
+    for i, (a, b) in enumerate(zip(ref[:len(names)], late[:len(names)])):              # step 1: identical parameters in both runs
+        assert a.shape == b.shape
+        err = float((a - b).norm()) / (float(a.norm()) + 1e-30)
+        assert err <= 1e-3, f'bucket "{names[i]}" was read {err:.3f} away from its finished value: a producer was still writing it'
+    moved = ((p_ref - p_late).abs() > 1e-5).float().mean()
+    assert float(moved) < 0.2, float(moved)
