@@ -50,8 +50,9 @@ def bench_wgrad():
     B, N = 48, 1000
     lens = torch.randint(250, 1001, (B,), device=dev)
     lens[0] = N
-    for (cin, cout, taps, dyd, xd) in [(128, 1024, 3, torch.bfloat16, torch.float32), (1024, 128, 3, torch.float32, torch.bfloat16),
-                                       (1024, 1024, 3, torch.bfloat16, torch.bfloat16), (128, 384, 1, torch.bfloat16, torch.float32)]:
+    bf = torch.bfloat16
+    for (cin, cout, taps, dyd, xd) in [(128, 1024, 3, bf, bf), (1024, 128, 3, bf, bf), (1024, 1024, 3, bf, bf), (256, 256, 3, bf, bf), (128, 384, 1, bf, bf),
+                                       (128, 128, 1, bf, bf), (128, 1024, 3, bf, torch.float32)]:
         x = torch.randn(B, N, cin, device=dev).to(xd)
         dy = torch.randn(B, N, cout, device=dev).to(dyd)
         dw = torch.zeros(cout, cin, taps, device=dev) if taps > 1 else torch.zeros(cout, cin, device=dev)

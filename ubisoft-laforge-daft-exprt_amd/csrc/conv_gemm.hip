@@ -2160,6 +2160,9 @@ constexpr int WGR_THREADS = 768, WGR_RING = 4;
 #ifndef WGR_XCD_BLOCKS
 #define WGR_XCD_BLOCKS 1
 #endif
+#ifndef WGR_TAP_SHIFT
+#define WGR_TAP_SHIFT 1   // 0: every tap operand by its own transposed LDS read (A/B build)
+#endif
 template <int TAPS>
 __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradArgs p) {
   constexpr int HALO = TAPS / 2, XROWS = WG_P + TAPS - 1;
@@ -2306,6 +2309,46 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
     const bf16_t* A = ring + buf * ITEM_EL;
     const bf16_t* Xs = A + A_PIECES * 512;
     if (!(p.debug & 2)) {
+      if constexpr (TAPS == 3 && WGR_TAP_SHIFT) {
+        // The three tap operands of a k-step are the SAME 8-position window of the X tile moved by 0 / 1 / 2 rows, and a lane holds its
+        // 8 positions as 4 dwords: tap 2 is a register renaming plus one dword of the next 8-position block, tap 1 a 16-bit funnel
+        // shift over the same five dwords.  The next block's first dword sits in the other half-wave (g = 0: lane + 32, same k-step;
+        // g = 1: lane - 32, next k-step) -- one v_permlane32_swap + one select.  One transposed read pair per k-step instead of three:
+        // 0.54 instead of 0.83 KB of LDS reads per MFMA (the kernel is LDS-bound: 2500 cycles per item for 1546 cycles of MFMA work).
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+        bf16x8 a[2][2];
+        u32x4 f[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[0][i] = tr8(A, offA[i], 0);
+        f[0] = __builtin_bit_cast(u32x4, tr8(Xs, offX[0], 0));
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          if (ks + 1 < NKS) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[(ks + 1) & 1][i] = tr8(A, offA[i], ks + 1);
+            f[(ks + 1) & 1] = __builtin_bit_cast(u32x4, tr8(Xs, offX[0], ks + 1));
+          } else {   // rows 64 .. 67 of the haloed tile (64, 65 are its last two rows; the piece they sit in is 4 rows tall)
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Xs + offX[0] + NKS * 16 * 128 - g * 8 * 128));   // (both half-waves read rows 64 + lj: only lanes 0 - 31 are consumed)
+            const u32x2v lo2 = __builtin_bit_cast(u32x2v, lo);
+            f[(ks + 1) & 1] = u32x4{lo2[0], lo2[1], 0u, 0u};
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const u32x4 c = f[ks & 1];
+          const u32x2v sw = __builtin_amdgcn_permlane32_swap(c[0], f[(ks + 1) & 1][0], false, false);
+          const uint32_t n0 = g ? sw[0] : sw[1];        // first two positions of the next 8-position block of this lane's channel
+          const u32x4 t1 = {__builtin_amdgcn_alignbit(c[1], c[0], 16), __builtin_amdgcn_alignbit(c[2], c[1], 16),
+                            __builtin_amdgcn_alignbit(c[3], c[2], 16), __builtin_amdgcn_alignbit(n0, c[3], 16)};
+          const u32x4 t2 = {c[1], c[2], c[3], n0};
+          const bf16x8 bx0 = __builtin_bit_cast(bf16x8, c), bx1 = __builtin_bit_cast(bf16x8, t1), bx2 = __builtin_bit_cast(bf16x8, t2);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) dx_mma(acc[0][i], a[ks & 1][i], bx0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) dx_mma(acc[1][i], a[ks & 1][i], bx1);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) dx_mma(acc[2][i], a[ks & 1][i], bx2);
+        }
+      } else {
       bf16x8 a[2][2], bx[2][TAPS];
 #pragma unroll
       for (int i = 0; i < 2; ++i) a[0][i] = tr8(A, offA[i], 0);
@@ -2324,6 +2367,7 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
         for (int t = 0; t < TAPS; ++t)
 #pragma unroll
           for (int i = 0; i < 2; ++i) dx_mma(acc[t][i], a[ks & 1][i], bx[ks & 1][t]);
+      }
       }
     }
     buf = buf + 1 == WGR_RING ? 0 : buf + 1;
