@@ -363,6 +363,23 @@ int dx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr,
                  const DxStepScalars* scalars /* NULL, or the step block: its lr / bias corrections replace `lr` and `step` */,
                  void* stream);
 
+/* dx_adam_step over the whole flat buffer FUSED with the refresh of the MFMA operand copies of the GEMM weights (what
+ * dx_pack_conv_weights_batched + dx_pack_frag_major_batched do after every optimizer step): one launch, the weights are read once.
+ * bricks_dev: DEVICE array of n_weights records {long off; void* fwd; void* tr; void* frag_fwd; void* frag_tr; int Cout, Cin, taps,
+ * pad; long begin;} (dx_adam_pack_desc_size() bytes): off = offset of the fp32 weight (Cout, Cin, taps) in p / g / m / v; fwd =
+ * [taps][Cout][Cin], tr = [taps][Cin][Cout] with flipped taps (dx_pack_conv_weight layouts), frag_* = dx_pack_frag_major of those
+ * (bf16, taps = 3, Cout and Cin multiples of 32), any of them NULL; begin = running count of 32 x 32 bricks, total_bricks their sum.
+ * flats_dev: DEVICE array of n_flats records {long off, n, begin;} (dx_adam_flat_desc_size() bytes) covering every parameter that is
+ * not a GEMM weight; begin = running count of dx_adam_flat_block()-element blocks, total_flat_blocks their sum.  out_dtype = dtype of
+ * the copies (DX_BF16 / DX_F32).  Same arithmetic per element as dx_adam_step with an infinite clipping threshold; grad_norm_sq_accum
+ * and scalars as there. */
+int dx_adam_pack_desc_size(void);
+int dx_adam_flat_desc_size(void);
+int dx_adam_flat_block(void);
+int dx_adam_pack_step(float* p, const float* g, float* m, float* v, const void* bricks_dev, int n_weights, long total_bricks,
+                      const void* flats_dev, int n_flats, long total_flat_blocks, int out_dtype, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int step, float* grad_norm_sq_accum, const DxStepScalars* scalars, void* stream);
+
 /* ---- K16: float -> integer frame durations on the device (DaftExprt.get_int_durations model.py:789-812 +
  * duration_to_integer extract_features.py:69-111): optional dur_factors multiply (model.py:891), in-place
  * thresholding at filter_length / sampling_rate / 2, fp64 cumulative times, sample/frame counting in integers.

@@ -186,6 +186,7 @@ class DaftExprt(nn.Module):
         assert [n for n, _ in self.named_parameters()] == [n for n, _, _ in self._table]
         self._flat = self._gflat = None
         self._packed, self._packed_version, self._param_version = {}, -1, 0
+        self._adam_table = None
         self._pack_stream, self._packs_pending = None, False
         # True (default, always safe): re-pack the bf16 weight copies on every call (one batched kernel, ~40 us).  False: re-pack only
         # when the parameters changed through torch -- `_weights` watches the version counters of the GEMM weights, so
@@ -247,6 +248,7 @@ class DaftExprt(nn.Module):
         self._flat, self._gflat = flat, gflat
         self._pos = None
         self._packed = {}
+        self._adam_table = None
         self._pack_stream, self._packs_pending = None, False   # (a new device after .to(): new stream)
         self.mark_updated()
 
@@ -381,6 +383,35 @@ class DaftExprt(nn.Module):
             self._pack_ev1.record(side)
             self._packs_pending = True
         return self._packed
+
+    def adam_pack_table(self):
+        ''' the tables of `ops.adam_pack_step` (Adam fused with the refresh of the operand copies) for the copies `_weights` keeps, or
+            None before the first forward pass has created them.  Every GEMM weight with its copies; every other parameter as
+            flat ranges (merged where adjacent). '''
+        if not self._packed:
+            return None
+        if self._adam_table is None:
+            W, gemm = self._packed, set(self._gemm_weights)
+            weights, flats = [], []
+            for name, shape, _ in self._table:
+                off, n = self._offsets[name]
+                if name in gemm:
+                    taps = shape[2] if len(shape) == 3 else 1
+                    weights.append((off, (shape[0], shape[1], taps), W.get(name), W.get('T:' + name), W.get('F:' + name), W.get('FT:' + name)))
+                elif flats and flats[-1][0] + flats[-1][1] == off:
+                    flats[-1] = (flats[-1][0], flats[-1][1] + n)
+                else:
+                    flats.append((off, n))
+            self._adam_table = ops.adam_pack_table(weights, flats, self._flat.device)
+        return self._adam_table
+
+    def packs_are_current(self):
+        ''' the optimizer has just refreshed EVERY operand copy together with the parameters (`ops.adam_pack_step`) '''
+        try:
+            version = (self._param_version, tuple(self._params[n]._version for n in self._gemm_weights))
+        except RuntimeError:
+            return
+        self._packed_version = self._dgrad_version = version
 
     def _join_packs(self):
         ''' the launch stream waits for the weight copies a deferred `_weights` call refreshes on the pack stream '''

@@ -636,6 +636,38 @@ def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, grad_norm_sq=None,
                                  H.ptr(norm_accum), STEP_PTR, H.stream()))
 
 
+def adam_pack_table(weights, flats, device):
+    ''' device tables of dx_adam_pack_step.  weights: [(offset, (Cout, Cin, taps), fwd, tr, frag_fwd, frag_tr)] (copies: tensors or None);
+        flats: [(offset, numel)].  Returns (bricks table, n_weights, total_bricks, flats table, n_flats, total_flat_blocks). '''
+    import numpy as np
+    bd = np.dtype([('off', '<i8'), ('fwd', '<u8'), ('tr', '<u8'), ('ffwd', '<u8'), ('ftr', '<u8'), ('Cout', '<i4'), ('Cin', '<i4'),
+                   ('taps', '<i4'), ('pad', '<i4'), ('begin', '<i8')])
+    fd = np.dtype([('off', '<i8'), ('n', '<i8'), ('begin', '<i8')])
+    assert bd.itemsize == H.lib().dx_adam_pack_desc_size() and fd.itemsize == H.lib().dx_adam_flat_desc_size()
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    arr, begin = np.zeros(len(weights), dtype=bd), 0
+    for i, (off, (cout, cin, taps), fwd, tr, ffwd, ftr) in enumerate(weights):
+        if ffwd is not None or ftr is not None:
+            assert taps == 3 and cout % 32 == 0 and cin % 32 == 0
+        arr[i] = (off, ptr(fwd), ptr(tr), ptr(ffwd), ptr(ftr), cout, cin, taps, 0, begin)
+        begin += ((cout + 31) // 32) * ((cin + 31) // 32)
+    blk = H.lib().dx_adam_flat_block()
+    farr, fbegin = np.zeros(max(1, len(flats)), dtype=fd), 0
+    for i, (off, n) in enumerate(flats):
+        farr[i] = (off, n, fbegin)
+        fbegin += (n + blk - 1) // blk
+    up = lambda a: torch.from_numpy(a.view(np.uint8).copy()).to(device)
+    return up(arr), len(weights), begin, up(farr), len(flats), fbegin
+
+
+def adam_pack_step(p, g, m, v, table, out_dtype, lr, betas, eps, weight_decay, step, norm_accum=None):
+    ''' whole-buffer Adam + refresh of every MFMA operand copy in one launch (dx_adam_pack_step) '''
+    bricks, nw, nbricks, flats, nf, nfb = table
+    H.check(H.lib().dx_adam_pack_step(H.ptr(p), H.ptr(g), H.ptr(m), H.ptr(v), H.ptr(bricks), nw, nbricks, H.ptr(flats) if nf else None, nf, nfb,
+                                      H._DT[out_dtype], float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step),
+                                      H.ptr(norm_accum), STEP_PTR, H.stream()))
+
+
 def step_scalars_set(block, seed_salt, lr, betas, step, w_speaker):
     ''' fill the device-side step block (a 48-byte uint8 tensor) for the step about to be replayed (dx_step_scalars_set) '''
     H.check(H.lib().dx_step_scalars_set(H.ptr(block), int(seed_salt), float(lr), float(betas[0]), float(betas[1]), int(step),

@@ -21,6 +21,7 @@ class FusedAdam(object):
         self.grad_norm_sq = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self.step_count = 0
         self.grad_clip_thresh = grad_clip_thresh
+        self.fuse_pack = bool(int(__import__('os').environ.get('DX_ADAM_PACK', '1')))   # 0: flat Adam, copies refreshed by the pack launches of the next step
         self.param_groups = [{'lr': lr, 'betas': tuple(betas), 'eps': eps, 'weight_decay': weight_decay, 'amsgrad': False,
                               'params': list(range(len(model._table)))}]
 
@@ -29,6 +30,17 @@ class FusedAdam(object):
         g = self.param_groups[0]
         self.step_count += 1
         flat, gflat = self.model.flat_parameters(), self.model.flat_gradients()
+        table = self.model.adam_pack_table() if (self.fuse_pack and self.grad_clip_thresh == float('inf') and flat.is_cuda) else None
+        if table is not None:
+            # Adam + the refresh of every MFMA operand copy of the GEMM weights in ONE launch (the copies the next forward / backward pass
+            # reads: forward, data-gradient and fragment-order packings): the weights are read once instead of three times, and the 5 pack
+            # launches at the head of the next step disappear
+            ops.H.check(ops.H.lib().dx_fill_zero(ops.H.ptr(self.grad_norm_sq), 4, ops.H.stream()))
+            ops.adam_pack_step(flat, gflat, self.exp_avg, self.exp_avg_sq, table, self.model.cd, g['lr'], g['betas'], g['eps'],
+                               g['weight_decay'], self.step_count, norm_accum=self.grad_norm_sq)
+            self.model.mark_updated()
+            self.model.packs_are_current()
+            return self.grad_norm_sq
         if self.grad_clip_thresh == float('inf'):   # the norm is only logged (train.py:399): summed inside the Adam launch, no pass of its own
             ops.H.check(ops.H.lib().dx_fill_zero(ops.H.ptr(self.grad_norm_sq), 4, ops.H.stream()))
             ops.adam_step(flat, gflat, self.exp_avg, self.exp_avg_sq, g['lr'], g['betas'], g['eps'], g['weight_decay'],
