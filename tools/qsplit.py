@@ -11,7 +11,7 @@ tabs = [r[0] for r in c.execute("select name from sqlite_master where type='tabl
 kd = [t for t in tabs if 'kernel_dispatch' in t][0]
 ks = [t for t in tabs if 'kernel_symbol' in t][0]
 rows = list(c.execute(f"select d.start,d.end,d.queue_id,s.kernel_name from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
-idx = [i for i, r in enumerate(rows) if 'adam_kernel' in r[3]]
+idx = [i for i, r in enumerate(rows) if 'adam_' in r[3]]
 pick = len(idx) - 2
 step = rows[idx[pick - 1] + 1: idx[pick] + 1]
 t0 = step[0][0]

@@ -12,7 +12,7 @@ kd = [t for t in tabs if 'kernel_dispatch' in t][0]
 ks = [t for t in tabs if 'kernel_symbol' in t][0]
 rows = list(c.execute(f"select d.start,d.end,d.queue_id,d.grid_size_x,d.grid_size_y,d.workgroup_size_x,s.kernel_name "
                       f"from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
-idx = [i for i, r in enumerate(rows) if 'adam_kernel' in r[6]]
+idx = [i for i, r in enumerate(rows) if 'adam_' in r[6]]
 # bench.py cycles a pool of POOL batches of different sizes: among the later steps that ran the SAME batch as the last one, the one with
 # the median period (the profiler's own hiccups land on single steps)
 POOL = 4

@@ -2458,7 +2458,10 @@ int launch_wgrad(const WgradArgs& a, int taps, hipStream_t s) {
   static int use_ring = getenv("DX_WGRAD_RING") ? atoi(getenv("DX_WGRAD_RING")) : 1;
   const bool ring = use_ring && sizeof(TA) == 2 && sizeof(TB) == 2 && sizeof(TC) == 2 && a.lddy % 8 == 0 && a.ldx % 8 == 0 &&
                     a.Cout % 8 == 0 && a.Cin % 8 == 0;
-  static int ring_k1 = getenv("DX_WGRAD_RING_K1") ? atoi(getenv("DX_WGRAD_RING_K1")) : 0;   // k = 1: fetch-bound, two register-staged workgroups per CU hide more latency
+  // k = 1 (QKV / output projections): round 3 kept the register-staged kernel at 192 workgroups (the ring kernel at 192 was 0.15 % slower).
+  // With FEWER, longer-lived workgroups the ring kernel wins: a 64-split launch has 7 items per workgroup and is all prologue + partial
+  // tile; 64 workgroups (21 splits of the 3 QKV tiles) on the 4-deep ring: 7.61 vs 7.64 ms per step, a third of the partial-tile traffic
+  static int ring_k1 = getenv("DX_WGRAD_RING_K1") ? atoi(getenv("DX_WGRAD_RING_K1")) : 1;
   if (taps == 1) {
     if (ring && ring_k1) hipLaunchKernelGGL((conv_wgrad_ring_kernel<1>), grid, dim3(WGR_THREADS), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 1>), grid, block, 0, s, a);
@@ -2616,7 +2619,7 @@ static int wgrad_nsplit(int B, int N, int Cin, int Cout, int taps) {
   // 256 -> 10.42, 320 -> 10.69; B = 128: 192 -> 22.1, 256 -> 22.5, 384 -> 23.2.  3/4 of the CUs, 8 waves each.
   static int fixed = getenv("DX_WGRAD_BLOCKS") ? atoi(getenv("DX_WGRAD_BLOCKS")) : 0;
   static int fixed_k1 = getenv("DX_WGRAD_BLOCKS_K1") ? atoi(getenv("DX_WGRAD_BLOCKS_K1")) : 0;
-  const int target = (taps == 1 && fixed_k1 > 0) ? fixed_k1 : (fixed > 0 ? fixed : 192);
+  const int target = taps == 1 ? (fixed_k1 > 0 ? fixed_k1 : (fixed > 0 ? fixed : 64)) : (fixed > 0 ? fixed : 192);   // k = 1: see launch_wgrad
   const int tiles = dx_cdiv(Cout, WG_CO) * dx_cdiv(Cin, WG_CI);
   // every split costs one more partial tile to write and re-read: keep >= ~8 items (64 positions each) per workgroup,
   // 16 for the linear layers (a third of the MFMA work per item)

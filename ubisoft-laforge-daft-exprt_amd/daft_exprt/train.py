@@ -125,11 +125,12 @@ class Trainer(object):
         self._done = set()
         # whole-step hipGraphs, keyed on the addresses and shapes of the step's input tensors (`CapturedStep`): one rank only -- a
         # captured RCCL collective is untested here -- and only with the whole-buffer optimizer
-        # DX_STEP_GRAPH: 1 = every repeating step is captured, 0 = never, auto (default) = only steps small enough to be bound by the
-        # host's launch rate (`CapturedStep.AUTO_ROWS`): measured on MI355X / ROCm 7.0 a replay TIES the eager step from B = 16 up
-        # (7.73 vs 7.69 ms at B = 48, 13.2 vs 13.0 ms for 16 x 3) -- the dispatch boundaries cost the same ~2 us on the GPU side whether
-        # the host or the graph executor feeds them -- and wins below (3.88 vs 4.05 ms at B = 8)
-        use_graph = os.environ.get('DX_STEP_GRAPH', 'auto')
+        # DX_STEP_GRAPH: 0 (default) = never, 1 = every repeating step is captured, auto = only steps small enough to be bound by the
+        # host's launch rate (`CapturedStep.AUTO_ROWS`).  Opt-in because, measured on MI355X / ROCm 7.0, a replay only TIES the eager step
+        # from B = 16 up (7.73 vs 7.69 ms at B = 48, 13.2 vs 13.0 ms for 16 x 3): the dispatch boundaries cost the same ~2 us on the GPU
+        # side whether the host or the graph executor feeds them, and at these sizes the host keeps ahead of the device.  It wins below
+        # (3.88 vs 4.05 ms at B = 8).
+        use_graph = os.environ.get('DX_STEP_GRAPH', '0')
         self.captured = CapturedStep(self, auto=(use_graph == 'auto')) if (world_size == 1 and use_graph != '0' and
                                                                            model.flat_parameters().is_cuda) else None
 
@@ -296,6 +297,12 @@ class CapturedStep(object):
         model.mark_updated()                                  # the graph always begins by re-packing the operand copies
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(dev)
+        # no cyclic garbage collection while the stream is capturing: a collected hipGraph / event of an EARLIER trainer runs runtime calls
+        # in its destructor that are illegal during a capture (the process aborted inside `Garbage-collecting` in the test suite)
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             ops.STEP_PTR, ops.ATTN_WS_OWNER, model._capture_step0 = self.block.data_ptr(), own_ws, step_id
             with torch.cuda.graph(graph):
@@ -306,6 +313,8 @@ class CapturedStep(object):
             torch.cuda.synchronize(dev)
             return None
         finally:
+            if gc_was_on:
+                gc.enable()
             ops.STEP_PTR, ops.ATTN_WS_OWNER, ops.H.AFTER_LAUNCH, model._side_deferred = None, None, None, None
             graph_ws, model._wgrad_ws = model._wgrad_ws, eager_ws
             model._step_id, opt.step_count, opt.param_groups[0]['lr'] = step_id, step_count, lr
