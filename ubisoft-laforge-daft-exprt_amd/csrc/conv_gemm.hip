@@ -821,15 +821,28 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
   }
 
   // ---- this workgroup's share of the live position tiles (flat list over the batch)
-  auto live_of = [&](int b) { return p.skip_len ? min(ptiles, dx_cdiv(min(N, (int)p.skip_len[b] + 2), BM)) : ptiles; };
-  int total = 0;
-  for (int b = 0; b < p.B; ++b) total += live_of(b);
-  const int i0 = (int)((long)total * grp / ngrp), i1 = (int)((long)total * (grp + 1) / ngrp);
-  int b = 0, pt = 0, nlive = 0;
-  for (int cum = 0; b < p.B; ++b) {
-    nlive = live_of(b);
-    if (i0 < cum + nlive) { pt = i0 - cum; break; }
-    cum += nlive;
+  // (cooperative count + prefix sums in LDS, dx_block_count_scan: the serial walks over the lengths -- count, locate the first live
+  //  tile, locate the first dead tile -- were most of this kernel's 8 us prologue)
+  __shared__ int s_live[DX_SCAN_MAXB + 1], s_cum[DX_SCAN_MAXB + 1], s_part[WR_THREADS / 64];
+  const bool scan = p.B <= DX_SCAN_MAXB;
+  auto live_g = [&](int b) { return p.skip_len ? min(ptiles, dx_cdiv(min(N, (int)p.skip_len[b] + 2), BM)) : ptiles; };
+  auto live_of = [&](int b) { return scan ? s_live[b] : live_g(b); };
+  int total = 0, b = 0, pt = 0, nlive = 0, i0, i1;
+  if (scan) {
+    dx_block_count_scan<WR_THREADS>(p.B, live_g, [](int v) { return v; }, s_live, s_cum, s_part);
+    total = s_cum[p.B];
+    i0 = (int)((long)total * grp / ngrp); i1 = (int)((long)total * (grp + 1) / ngrp);
+    b = dx_locate_item(s_cum, p.B, i0);
+    nlive = s_live[b];
+    pt = i0 - s_cum[b];
+  } else {
+    for (int bb = 0; bb < p.B; ++bb) total += live_g(bb);
+    i0 = (int)((long)total * grp / ngrp); i1 = (int)((long)total * (grp + 1) / ngrp);
+    for (int cum = 0; b < p.B; ++b) {
+      nlive = live_g(b);
+      if (i0 < cum + nlive) { pt = i0 - cum; break; }
+      cum += nlive;
+    }
   }
   int left = i1 - i0;
 
@@ -1052,10 +1065,17 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
     const int dead = ptiles * p.B - total;
     const int j0 = (int)((long)dead * grp / ngrp), j1 = (int)((long)dead * (grp + 1) / ngrp);
     int db = 0, dpt = 0, cum = 0;
-    for (; db < p.B; ++db) {
-      const int nd = ptiles - live_of(db);
-      if (j0 < cum + nd) { dpt = live_of(db) + (j0 - cum); break; }
-      cum += nd;
+    if (scan && j0 < j1) {   // dead tiles before utterance u: u * ptiles - s_cum[u] (monotone): the largest u with that <= j0
+      int lo = 0, hi = p.B - 1;
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (mid * ptiles - s_cum[mid] <= j0) lo = mid; else hi = mid - 1; }
+      db = lo;
+      dpt = s_live[db] + (j0 - (db * ptiles - s_cum[db]));
+    } else if (!scan) {
+      for (; db < p.B; ++db) {
+        const int nd = ptiles - live_of(db);
+        if (j0 < cum + nd) { dpt = live_of(db) + (j0 - cum); break; }
+        cum += nd;
+      }
     }
     const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int j = j0; j < j1; ++j) {
@@ -1976,16 +1996,27 @@ __global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wg
   const int N = p.N, Cin = p.Cin, Cout = p.Cout;
 
   // rows beyond len + halo carry exactly-zero gradients (masked upstream): not part of the item list
-  auto nlim_of = [&](int b) { return p.lengths ? min(N, (int)p.lengths[b] + 2) : N; };
-  int total = 0;
-  for (int b = 0; b < p.B; ++b) total += dx_cdiv(nlim_of(b), WG_P);
-  const int i0 = (int)((long)total * split / p.nsplit), i1 = (int)((long)total * (split + 1) / p.nsplit);
-  int b = 0, n0 = 0, nlim = 0;
-  for (int cum = 0; b < p.B; ++b) {                 // locate item i0
-    nlim = nlim_of(b);
-    const int c = dx_cdiv(nlim, WG_P);
-    if (i0 < cum + c) { n0 = (i0 - cum) * WG_P; break; }
-    cum += c;
+  __shared__ int s_nl[DX_SCAN_MAXB + 1], s_cum[DX_SCAN_MAXB + 1], s_part[WG_THREADS / 64];
+  const bool scan = p.B <= DX_SCAN_MAXB;               // (else: the serial walk over the lengths)
+  auto nlim_g = [&](int b) { return p.lengths ? min(N, (int)p.lengths[b] + 2) : N; };
+  auto nlim_of = [&](int b) { return scan ? s_nl[b] : nlim_g(b); };
+  int total = 0, b = 0, n0 = 0, nlim = 0, i0, i1;
+  if (scan) {
+    dx_block_count_scan<WG_THREADS>(p.B, nlim_g, [](int nl) { return dx_cdiv(nl, WG_P); }, s_nl, s_cum, s_part);
+    total = s_cum[p.B];
+    i0 = (int)((long)total * split / p.nsplit); i1 = (int)((long)total * (split + 1) / p.nsplit);
+    b = dx_locate_item(s_cum, p.B, i0);
+    nlim = s_nl[b];
+    n0 = (i0 - s_cum[b]) * WG_P;
+  } else {
+    for (int bb = 0; bb < p.B; ++bb) total += dx_cdiv(nlim_g(bb), WG_P);
+    i0 = (int)((long)total * split / p.nsplit); i1 = (int)((long)total * (split + 1) / p.nsplit);
+    for (int cum = 0; b < p.B; ++b) {                 // locate item i0
+      nlim = nlim_g(b);
+      const int c = dx_cdiv(nlim, WG_P);
+      if (i0 < cum + c) { n0 = (i0 - cum) * WG_P; break; }
+      cum += c;
+    }
   }
   int left = i1 - i0;
 
@@ -2182,9 +2213,17 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
   }
   const int co0 = (tile / p.tiles_ci) * WG_CO, ci0 = (tile % p.tiles_ci) * WG_CI;
   const int N = p.N, Cin = p.Cin, Cout = p.Cout;
-  auto nlim_of = [&](int b) { return p.lengths ? min(N, (int)p.lengths[b] + 2) : N; };
+  __shared__ int s_nl[DX_SCAN_MAXB + 1], s_cum[DX_SCAN_MAXB + 1], s_part[WGR_THREADS / 64];
+  const bool scan = p.B <= DX_SCAN_MAXB;               // (else: the serial walk over the lengths)
+  auto nlim_g = [&](int b) { return p.lengths ? min(N, (int)p.lengths[b] + 2) : N; };
+  auto nlim_of = [&](int b) { return scan ? s_nl[b] : nlim_g(b); };
   int total = 0;
-  for (int b = 0; b < p.B; ++b) total += dx_cdiv(nlim_of(b), WG_P);
+  if (scan) {
+    dx_block_count_scan<WGR_THREADS>(p.B, nlim_g, [](int nl) { return dx_cdiv(nl, WG_P); }, s_nl, s_cum, s_part);
+    total = s_cum[p.B];
+  } else {
+    for (int b = 0; b < p.B; ++b) total += dx_cdiv(nlim_g(b), WG_P);
+  }
   const int i0 = (int)((long)total * split / p.nsplit), i1 = (int)((long)total * (split + 1) / p.nsplit);
   const int count = i1 - i0;
 
@@ -2193,11 +2232,17 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
     const int lw = __builtin_amdgcn_readfirstlane(wave) - 8;
     const int mine = (NP - lw + 3) >> 2;
     int ib = 0, in0 = 0, ilim = 0;
-    for (int cum = 0; ib < p.B; ++ib) {               // locate item i0
-      ilim = nlim_of(ib);
-      const int c = dx_cdiv(ilim, WG_P);
-      if (i0 < cum + c) { in0 = (i0 - cum) * WG_P; break; }
-      cum += c;
+    if (scan) {
+      ib = dx_locate_item(s_cum, p.B, i0);
+      ilim = s_nl[ib];
+      in0 = (i0 - s_cum[ib]) * WG_P;
+    } else {
+      for (int cum = 0; ib < p.B; ++ib) {             // locate item i0
+        ilim = nlim_g(ib);
+        const int c = dx_cdiv(ilim, WG_P);
+        if (i0 < cum + c) { in0 = (i0 - cum) * WG_P; break; }
+        cum += c;
+      }
     }
     // per-piece constants (A_PIECES is a multiple of 4: slot t < A_PIECES / 4 is a dY piece for every loader): the row
     // inside the item and this lane's column; per item only the row number changes -- the loaders are instruction-bound

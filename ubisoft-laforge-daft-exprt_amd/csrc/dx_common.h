@@ -105,6 +105,47 @@ __device__ __forceinline__ float dx_wave_max(float v) {
   return v;
 }
 
+// ---- per-utterance work lists without serial walks over the batch ------------------------------------------------------
+// Several kernels split a flat list of work items (64-row items, 128-row tiles) over their workgroups, where utterance b owns
+// cnt_of(val_of(b)) items and val_of(b) is derived from lengths[b].  Walking the lengths serially -- once to count, once more to find
+// the utterance that holds the workgroup's first item, every wave of every workgroup -- is a chain of up to 2 B dependent global
+// round trips: ~20 us in front of a 25 us weight-gradient launch at B = 48 (the launches never got shorter than 25 us however little
+// work they had).  Here every thread loads ONE length (one round trip for the workgroup), a wave scan + a pass over the wave totals
+// build the exclusive prefix sums in LDS, and the rest are LDS reads.
+//   s_val[b] = val_of(b), s_cum[b] = items before utterance b, s_cum[B] = total.   s_part: THREADS / 64 ints.
+// Every thread of the workgroup must call it (it has barriers); B <= DX_SCAN_MAXB (callers fall back to the serial walk above that).
+constexpr int DX_SCAN_MAXB = 512;    // (LDS: two arrays of this many ints per workgroup; the largest published batch is 256 utterances)
+template <int THREADS, typename FV, typename FC>
+__device__ __forceinline__ void dx_block_count_scan(int B, FV val_of, FC cnt_of, int* s_val, int* s_cum, int* s_part) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int carry = 0;
+  for (int b0 = 0; b0 < B; b0 += THREADS) {               // one trip for B <= THREADS
+    const int b = b0 + tid;
+    const int val = b < B ? val_of(b) : 0;
+    const int v = b < B ? cnt_of(val) : 0;
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
+    if (lane == 63) s_part[wave] = x;
+    __syncthreads();
+    int woff = carry, chunk = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; ++w) { const int t = s_part[w]; if (w < wave) woff += t; chunk += t; }
+    if (b < B) { s_val[b] = val; s_cum[b] = woff + x - v; }
+    carry += chunk;
+    __syncthreads();
+  }
+  if (tid == 0) s_cum[B] = carry;
+  __syncthreads();
+}
+// the utterance that holds item i (0 <= i < s_cum[B]): the largest b with s_cum[b] <= i (utterances without items share their
+// successor's prefix and are skipped)
+__device__ __forceinline__ int dx_locate_item(const int* s_cum, int B, int i) {
+  int lo = 0, hi = B - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_cum[mid] <= i) lo = mid; else hi = mid - 1; }
+  return lo;
+}
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // k-major gather from a row-major tile: lane gets column c = col0 + (lane & 31) % WRAP and the 8 rows

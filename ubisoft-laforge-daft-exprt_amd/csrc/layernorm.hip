@@ -436,7 +436,8 @@ extern "C" int dx_layernorm_bwd(const void* dy, int dy_dtype, const void* s_in, 
   DX_REQUIRE((film == nullptr) == (dfilm == nullptr), DX_ERR_ARG, "dx_layernorm_bwd: film and dfilm come together");
   // enough workgroups to fill 256 CUs, few enough that the per-channel atomics stay cheap
   static int dbg = getenv("DX_LN_DEBUG") ? atoi(getenv("DX_LN_DEBUG")) : 0;
-  const int maxblk = 768;   // keep in sync with dx_layernorm_bwd_ws_floats
+  static int maxblk_env = getenv("DX_LN_BWD_MAXBLK") ? atoi(getenv("DX_LN_BWD_MAXBLK")) : 0;
+  const int maxblk = (maxblk_env > 0 && maxblk_env <= 768) ? maxblk_env : 768;   // (<= 768: dx_layernorm_bwd_ws_floats sizes the two-stage workspace for 768)
   int rpb = 32;
   while (rpb < 1024 && (long)dx_cdiv(N, rpb) * B > maxblk) rpb *= 2;
   LNBwdArgs a{dy, s_in, mean, rstd, gamma, beta, film, ldf, lengths, skip_lengths, ds, dx_pre, dx_pre_lp, dgamma, dbeta, dfilm, lddf, N, B, rpb,

@@ -61,17 +61,17 @@ struct ScalarEmbedBwdArgs {
 };
 
 constexpr int SE_MAX_ROWS = 1024;
-// grid (ceil(N / rows_per_block), B); 512 threads = 4 row lanes x 128 channels: row lane q walks rows q, q + 4, ... of the
-// slab, the four partial sums meet in LDS, and the workgroup ends with ONE atomic per (feature, tap, channel) -- all
+// grid (ceil(N / rows_per_block), B); 1024 threads = 8 row lanes x 128 channels: row lane q walks rows q, q + 8, ... of the
+// slab, the eight partial sums meet in LDS, and the workgroup ends with ONE atomic per (feature, tap, channel) -- all
 // workgroups hit the same 1024 addresses, so few fat workgroups (the 2048-workgroup launch spent ~100 us queueing atomics)
-__global__ __launch_bounds__(512) void scalar_embed_bwd_kernel(ScalarEmbedBwdArgs a) {
-  __shared__ float red[4][3][4][C128];
+__global__ __launch_bounds__(1024) void scalar_embed_bwd_kernel(ScalarEmbedBwdArgs a) {
+  __shared__ float red[8][3][4][C128];
   __shared__ float fs[3][SE_MAX_ROWS + 2];      // the slab's feature values with a one-row halo: one LDS read instead of three global loads per tap
   const int c = threadIdx.x & 127, q = threadIdx.x >> 7, b = blockIdx.y;
   const int n0 = blockIdx.x * a.rows_per_block;
   const int len = a.lengths ? (int)a.lengths[b] : a.N;
   const int n1 = min(min(a.N, n0 + a.rows_per_block), a.dbase ? a.N : len);
-  for (int i = threadIdx.x; i < a.nfeat * (a.rows_per_block + 2); i += 512) {
+  for (int i = threadIdx.x; i < a.nfeat * (a.rows_per_block + 2); i += 1024) {
     const int f = i / (a.rows_per_block + 2), r = i - f * (a.rows_per_block + 2), n = n0 + r - 1;
     fs[f][r] = (n >= 0 && n < a.N) ? a.feat[f][(long)b * a.N + n] : 0.f;
   }
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(512) void scalar_embed_bwd_kernel(ScalarEmbedBwdArg
 #pragma unroll
   for (int f = 0; f < 3; ++f) { ab[f] = 0.f; aw[f][0] = aw[f][1] = aw[f][2] = 0.f; }
 #pragma unroll 4
-  for (int n = n0 + q; n < n1; n += 4) {
+  for (int n = n0 + q; n < n1; n += 8) {
     const long row = (long)b * a.N + n;
     const float g = n < len ? a.dout[row * C128 + c] : 0.f;
     if (a.dbase) a.dbase[row * C128 + c] = g;
@@ -96,9 +96,10 @@ __global__ __launch_bounds__(512) void scalar_embed_bwd_kernel(ScalarEmbedBwdArg
 #pragma unroll
   for (int f = 0; f < 3; ++f) { red[q][f][0][c] = aw[f][0]; red[q][f][1][c] = aw[f][1]; red[q][f][2][c] = aw[f][2]; red[q][f][3][c] = ab[f]; }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < a.nfeat * 4 * C128; idx += 512) {
+  for (int idx = threadIdx.x; idx < a.nfeat * 4 * C128; idx += 1024) {
     const int f = idx / (4 * C128), k = (idx / C128) & 3, ch = idx & (C128 - 1);
-    const float t = red[0][f][k][ch] + red[1][f][k][ch] + red[2][f][k][ch] + red[3][f][k][ch];
+    const float t = ((red[0][f][k][ch] + red[1][f][k][ch]) + (red[2][f][k][ch] + red[3][f][k][ch])) +
+                    ((red[4][f][k][ch] + red[5][f][k][ch]) + (red[6][f][k][ch] + red[7][f][k][ch]));
     if (k < 3) atomicAdd(a.dw[f] + ch * 3 + k, t);
     else atomicAdd(a.dbias[f] + ch, t);
   }
@@ -201,40 +202,39 @@ struct FilmBwdArgs {
   int B, W, nblk;
 };
 __global__ void film_assemble_bwd_kernel(FilmBwdArgs a) {
+  // (+ the post-multiplier gradient: dpost[0][blk] += sum_{b,c} dfilm_gamma * g_raw, dpost[1][blk] += sum_{b,c} dfilm_beta * b_raw.  A wave's 64
+  //  consecutive columns lie in ONE FiLM block whenever the block widths are multiples of 64, as in every published config: one wave
+  //  reduction + two atomics per wave; the separate one-workgroup-per-block reduction launch took 34 us for 120 k products)
   const long total = (long)a.B * a.W;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int b = (int)(i / a.W);
-    int col = (int)(i - (long)b * a.W), m = 0, blk0 = 0;
-    while (col >= a.nb[m] * a.ch[m]) { col -= a.nb[m] * a.ch[m]; blk0 += a.nb[m]; ++m; }
-    const int blk = col / a.ch[m], c = col - blk * a.ch[m];
-    const float* src = a.dfilm[m] + ((long)b * a.nb[m] + blk) * 2 * a.ch[m];
-    const float dg = src[c], db = src[a.ch[m] + c];
-    const float pg = a.post ? a.post[blk0 + blk] : 1.f, pb = a.post ? a.post[a.nblk + blk0 + blk] : 1.f;
-    a.dg_raw[i] = dg * pg;
-    a.db_raw[i] = db * pb;
+  for (long i0 = blockIdx.x * (long)blockDim.x; i0 < total; i0 += (long)gridDim.x * blockDim.x) {
+    const long i = i0 + threadIdx.x;
+    const bool live = i < total;
+    float tg = 0.f, tb = 0.f;
+    int key = -1;
+    if (live) {
+      const int b = (int)(i / a.W);
+      int col = (int)(i - (long)b * a.W), m = 0, blk0 = 0;
+      while (col >= a.nb[m] * a.ch[m]) { col -= a.nb[m] * a.ch[m]; blk0 += a.nb[m]; ++m; }
+      const int blk = col / a.ch[m], c = col - blk * a.ch[m];
+      const float* src = a.dfilm[m] + ((long)b * a.nb[m] + blk) * 2 * a.ch[m];
+      const float dg = src[c], db = src[a.ch[m] + c];
+      const float pg = a.post ? a.post[blk0 + blk] : 1.f, pb = a.post ? a.post[a.nblk + blk0 + blk] : 1.f;
+      a.dg_raw[i] = dg * pg;
+      a.db_raw[i] = db * pb;
+      if (a.dpost) { tg = dg * a.g_raw[i]; tb = db * a.b_raw[i]; key = blk0 + blk; }
+    }
+    if (a.dpost) {
+      const int key0 = __builtin_amdgcn_readfirstlane(key);
+      if (__all(key == key0 || !live)) {
+        const float sg = dx_wave_sum(tg), sb = dx_wave_sum(tb);
+        if ((threadIdx.x & 63) == 0 && key0 >= 0) { atomicAdd(a.dpost + key0, sg); atomicAdd(a.dpost + a.nblk + key0, sb); }
+      } else if (live) {
+        atomicAdd(a.dpost + key, tg);
+        atomicAdd(a.dpost + a.nblk + key, tb);
+      }
+    }
   }
 }
-// dpost[0][blk] += sum_{b,c} dfilm_gamma * g_raw, dpost[1][blk] += sum_{b,c} dfilm_beta * b_raw: one workgroup per
-// (gamma|beta, block) -- a block-level tree reduction instead of 2 * B * W contended atomics
-__global__ __launch_bounds__(256) void film_dpost_kernel(FilmBwdArgs a) {
-  __shared__ float red[4];
-  const int which = blockIdx.x / a.nblk, gblk = blockIdx.x % a.nblk;
-  int m = 0, blk0 = 0, col0 = 0;
-  while (gblk >= blk0 + a.nb[m]) { blk0 += a.nb[m]; col0 += a.nb[m] * a.ch[m]; ++m; }
-  const int blk = gblk - blk0, ch = a.ch[m];
-  const float* raw = which ? a.b_raw : a.g_raw;
-  float acc = 0.f;
-  for (int i = threadIdx.x; i < a.B * ch; i += 256) {
-    const int b = i / ch, c = i - b * ch;
-    const float d = a.dfilm[m][((long)b * a.nb[m] + blk) * 2 * ch + (which ? ch : 0) + c];
-    acc += d * raw[(long)b * a.W + col0 + blk * ch + c];
-  }
-  acc = dx_wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) a.dpost[which * a.nblk + gblk] += red[0] + red[1] + red[2] + red[3];
-}
-
 // ------------------------------------------------------------------ exact-fp32 small linear
 // y[m][o] = act(sum_k x[m][k] W[o][k] + bias[o]); rows m >= mask_len[b] (b = m / N) are written as zeros
 __global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -451,11 +451,12 @@ extern "C" int dx_scalar_embed_bwd(const float* dout, const float* const* feats,
   ScalarEmbedBwdArgs a{};
   a.dout = dout; a.nfeat = nfeat; a.lengths = lengths; a.dbase = dbase; a.N = N;
   // every workgroup ends with 512-1024 atomics on the same few addresses: few, fat workgroups
+  // (same-address atomics serialise at ~50 ns each: ~256 workgroups keep that tail under the time the rows take to stream)
   int rpb = 64;
-  while (rpb < 1024 && (long)dx_cdiv(N, rpb) * B > 512) rpb *= 2;
+  while (rpb < 1024 && (long)dx_cdiv(N, rpb) * B > 256) rpb *= 2;
   a.rows_per_block = rpb;
   for (int f = 0; f < nfeat; ++f) { a.feat[f] = feats[f]; a.dw[f] = dws[f]; a.dbias[f] = dbiases[f]; }
-  hipLaunchKernelGGL(scalar_embed_bwd_kernel, dim3(dx_cdiv(N, rpb), B), dim3(512), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(scalar_embed_bwd_kernel, dim3(dx_cdiv(N, rpb), B), dim3(1024), 0, (hipStream_t)stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
@@ -517,7 +518,6 @@ extern "C" int dx_film_assemble_bwd(const float* g_raw, const float* b_raw, cons
   a.dg_raw = dg_raw; a.db_raw = db_raw; a.dpost = post ? dpost : nullptr; a.B = B;
   for (int m = 0; m < 3; ++m) { a.nb[m] = nb[m]; a.ch[m] = ch[m]; a.W += nb[m] * ch[m]; a.nblk += nb[m]; }
   hipLaunchKernelGGL(film_assemble_bwd_kernel, dim3(grid_for((long)B * a.W)), dim3(256), 0, (hipStream_t)stream, a);
-  if (a.dpost) hipLaunchKernelGGL(film_dpost_kernel, dim3(2 * a.nblk), dim3(256), 0, (hipStream_t)stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }

@@ -58,40 +58,47 @@ __global__ __launch_bounds__(256) void mel_loss_kernel(const float* __restrict__
 // the same terms with the gradient written TRANSPOSED, (B, T, C) for the channel-last decoder backward: a workgroup
 // takes 64 frames x all channels, reads pred / tgt along t (coalesced), and writes the gradient tile along c through LDS
 // (the direct transposed store above writes 4 bytes per 320-byte row: 76 us for 48 x 80 x 1000)
-constexpr int MT_T = 64, MT_CMAX = 128;
+constexpr int MT_T = 64, MT_CMAX = 128, MT_TPW = 4;
 __global__ __launch_bounds__(256) void mel_loss_t_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
                                                          float* __restrict__ dpred, const int64_t* __restrict__ out_len,
                                                          float* terms, int B, int C, int T, float w, float gscale) {
   __shared__ float tile[MT_CMAX][MT_T + 1];
   __shared__ float red[4];
-  const int b = blockIdx.y, t0 = blockIdx.x * MT_T;
+  const int b = blockIdx.y;
   const float inv = 1.f / ((float)C * (float)out_len[b] * (float)B);
   const long base = (long)b * C * T;
   float a1 = 0.f, a2 = 0.f;
   constexpr int U = 10;                                 // loads in flight per thread and operand (80 bins: two rounds)
-  for (int i0 = threadIdx.x; i0 < C * MT_T; i0 += 256 * U) {
-    float pv[U], tv[U];
+  // MT_TPW tiles of 64 frames per workgroup: every workgroup ends with two atomics on the SAME two addresses, and same-address atomics
+  // serialise at ~50 ns each -- 768 one-tile workgroups spent more time queueing there (~30 us) than reading their 46 MB
+  for (int tile_i = 0; tile_i < MT_TPW; ++tile_i) {
+    const int t0 = (blockIdx.x * MT_TPW + tile_i) * MT_T;
+    if (t0 >= T) break;
+    for (int i0 = threadIdx.x; i0 < C * MT_T; i0 += 256 * U) {
+      float pv[U], tv[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = i0 + u * 256, c = i / MT_T, t = t0 + i % MT_T;
-      const bool ok = i < C * MT_T && t < T;
-      pv[u] = ok ? pred[base + (long)c * T + t] : 0.f;
-      tv[u] = ok ? tgt[base + (long)c * T + t] : 0.f;
-    }
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * 256, c = i / MT_T, t = t0 + i % MT_T;
+        const bool ok = i < C * MT_T && t < T;
+        pv[u] = ok ? pred[base + (long)c * T + t] : 0.f;
+        tv[u] = ok ? tgt[base + (long)c * T + t] : 0.f;
+      }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = i0 + u * 256;
-      if (i >= C * MT_T) break;
-      const float d = pv[u] - tv[u];                    // 0 past T: contributes nothing
-      a1 += fabsf(d);
-      a2 += d * d;
-      tile[i / MT_T][i % MT_T] = gscale * w * ((d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) + 2.f * d) * inv;
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * 256;
+        if (i >= C * MT_T) break;
+        const float d = pv[u] - tv[u];                    // 0 past T: contributes nothing
+        a1 += fabsf(d);
+        a2 += d * d;
+        tile[i / MT_T][i % MT_T] = gscale * w * ((d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) + 2.f * d) * inv;
+      }
     }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < C * MT_T; i += 256) {
-    const int tt = i / C, c = i % C, t = t0 + tt;
-    if (t < T) dpred[base + (long)t * C + c] = tile[c][tt];
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * MT_T; i += 256) {
+      const int tt = i / C, c = i % C, t = t0 + tt;
+      if (t < T) dpred[base + (long)t * C + c] = tile[c][tt];
+    }
+    __syncthreads();
   }
   a1 = block_sum_256(a1, red);
   a2 = block_sum_256(a2, red);
@@ -320,7 +327,7 @@ extern "C" int dx_loss_fwd_bwd(const float* dur, const float* energy, const floa
   int chunks = dx_cdiv(n_mel * T, 256 * 8);
   if (chunks > 64) chunks = 64;
   if (d_mel && d_mel_transposed && n_mel <= MT_CMAX)
-    hipLaunchKernelGGL(mel_loss_t_kernel, dim3(dx_cdiv(T, MT_T), B), dim3(256), 0, s, mel, mel_t, d_mel, out_lengths, terms, B, n_mel, T, w_mel, grad_scale);
+    hipLaunchKernelGGL(mel_loss_t_kernel, dim3(dx_cdiv(T, MT_T * MT_TPW), B), dim3(256), 0, s, mel, mel_t, d_mel, out_lengths, terms, B, n_mel, T, w_mel, grad_scale);
   else
     hipLaunchKernelGGL(mel_loss_kernel, dim3(chunks, B), dim3(256), 0, s, mel, mel_t, d_mel, out_lengths, terms, B, n_mel, T, w_mel, grad_scale, d_mel_transposed);
   hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, s, terms);
