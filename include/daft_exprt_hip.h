@@ -189,6 +189,21 @@ int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const void* x, int 
                     int compute_dtype, float* dw, float* db, const int64_t* lengths, float* ws, int B, int N, int Cin,
                     int Cout, int taps, void* stream);
 
+/* n (<= 8) weight gradients over the SAME batch rows (B, N, lengths) in one call -- e.g. the four of an FFT block's backward pass
+ * (model.py:182-186, 226-235: QKV and output projections, the two feed-forward convolutions): the n GEMM launches of dx_conv1d_wgrad,
+ * then ONE launch that adds every partial tile to its dw (instead of one reduce launch behind each GEMM; same summation order per
+ * element, so the results are those of n dx_conv1d_wgrad calls bit for bit).  descs: HOST array of n records; ws: scratch of
+ * dx_conv1d_wgrad_multi_ws_floats(descs, n, B, N) floats (required). */
+typedef struct DxWgradDesc {
+  const void* dy; const void* x; float* dw; float* db;
+  long lddy, ldx;
+  int dy_dtype, x_dtype, Cin, Cout, taps, pad;
+} DxWgradDesc;
+int dx_wgrad_desc_size(void);
+long dx_conv1d_wgrad_multi_ws_floats(const DxWgradDesc* descs, int n, int B, int N);
+int dx_conv1d_wgrad_multi(const DxWgradDesc* descs, int n, int compute_dtype, const int64_t* lengths, float* ws, int B, int N,
+                          void* stream);
+
 /* ---- K5: LayerNorm(C) over channel-last rows fused with its neighbours (C in {128, 256, 1024}):
  *   s = dropout_pre(x) + residual;  y = LN(s) * gamma + beta;  y = dropout_post(y);
  *   y = film[b, :C] * y + film[b, C:];  y = 0 where n >= lengths[b]

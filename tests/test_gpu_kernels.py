@@ -514,3 +514,29 @@ def test_small_linear_heads_match_fp32_reference(shape):
     torch.cuda.synchronize()
     close = lambda a, r, what: float((a.double().cpu() - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-6 or pytest.fail(what)
     close(y, y_ref, 'y'); close(dx, dx_ref, 'dx'); close(dw - 1., dw_ref, 'dw'); close(db - 1., db_ref, 'db')
+
+
+def test_wgrad_multi_equals_separate_calls():
+    ''' dx_conv1d_wgrad_multi (the four weight gradients of an FFT block's backward pass in one call: four GEMM launches, ONE launch that
+        adds all partial tiles) == four dx_conv1d_wgrad calls, bit for bit (same partial tiles, same summation order per element);
+        dW / db are accumulated into '''
+    from daft_exprt import ops
+    g = torch.Generator().manual_seed(5)
+    lens_list = [700, 433, 257, 130, 64, 5, 0, 699]
+    B, N = len(lens_list), 700
+    lens = torch.tensor(lens_list).to(DEV)
+    live = (torch.arange(N, device=DEV)[None, :, None] < lens[:, None, None] + 2)
+    mk = lambda c: (torch.randn(B, N, c, generator=g).to(DEV) * live).to(torch.bfloat16)
+    shapes = [(128, 1024, 3), (1024, 128, 3), (128, 384, 1), (128, 128, 1)]          # (Cin, Cout, taps)
+    items = []
+    for cin, cout, taps in shapes:
+        dw = torch.randn((cout, cin, taps) if taps == 3 else (cout, cin), generator=g).to(DEV)
+        items.append((mk(cout), mk(cin), dw, torch.randn(cout, generator=g).to(DEV)))
+    ref = [(dw.clone(), db.clone()) for _, _, dw, db in items]
+    for (dy, x, _, _), (dw, db) in zip(items, ref):
+        ops.conv1d_wgrad(dy, x, dw, db, torch.bfloat16, lens)
+    ops.conv1d_wgrad_multi(items, torch.bfloat16, lens)
+    torch.cuda.synchronize()
+    for (_, _, dw, db), (rw, rb), sh in zip(items, ref, shapes):
+        assert torch.equal(dw, rw), sh
+        assert float((db - rb).abs().max()) <= 1e-4 * float(rb.abs().max()), sh       # bias sums: fp32 atomics

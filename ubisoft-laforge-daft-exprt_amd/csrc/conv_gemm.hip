@@ -2388,10 +2388,12 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
           const bf16x8 bx0 = __builtin_bit_cast(bf16x8, c), bx1 = __builtin_bit_cast(bf16x8, t1), bx2 = __builtin_bit_cast(bf16x8, t2);
 #pragma unroll
           for (int i = 0; i < 2; ++i) dx_mma(acc[0][i], a[ks & 1][i], bx0);
+          if (!(p.debug & 32)) {   // (debug 32: one tap's MFMAs only -- does the item time follow the MFMA count?)
 #pragma unroll
           for (int i = 0; i < 2; ++i) dx_mma(acc[1][i], a[ks & 1][i], bx1);
 #pragma unroll
           for (int i = 0; i < 2; ++i) dx_mma(acc[2][i], a[ks & 1][i], bx2);
+          }
         }
       } else {
       bf16x8 a[2][2], bx[2][TAPS];
@@ -2496,8 +2498,67 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// several weight gradients' partial tiles added to their dW by ONE launch (dx_conv1d_wgrad_multi): the entries ride in the kernel
+// arguments; a block finds its entry by its first-block table and then runs the body of wgrad_reduce_kernel with run-time taps
+constexpr int WG_MULTI_MAX = 8;
+struct MultiReduceArgs {
+  const float* ws[WG_MULTI_MAX]; float* dw[WG_MULTI_MAX];
+  int nsplit[WG_MULTI_MAX], ntiles[WG_MULTI_MAX], tiles_ci[WG_MULTI_MAX], Cout[WG_MULTI_MAX], Cin[WG_MULTI_MAX], taps[WG_MULTI_MAX];
+  int begin[WG_MULTI_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(MultiReduceArgs m) {
+  __shared__ f32x4 part[4][64];
+  int e = 0;
+#pragma unroll
+  for (int i = 1; i < WG_MULTI_MAX; ++i) if (i < m.n && (int)blockIdx.x >= m.begin[i]) e = i;
+  const int TAPS = m.taps[e], nsplit = m.nsplit[e], ntiles = m.ntiles[e], tiles_ci = m.tiles_ci[e], Cout = m.Cout[e], Cin = m.Cin[e];
+  const float* __restrict__ ws = m.ws[e];
+  float* __restrict__ dw = m.dw[e];
+  const int TILE_FLOATS = TAPS * 2 * 16 * WG_THREADS, QUADS = TILE_FLOATS / 4;
+  const int grp = threadIdx.x >> 6, ql = threadIdx.x & 63;
+  const long q = ((long)blockIdx.x - m.begin[e]) * 64L + ql;
+  const bool live = q < (long)ntiles * QUADS;
+  const int tile = live ? (int)(q / QUADS) : 0, e0 = live ? (int)(q - (long)tile * QUADS) * 4 : 0;
+  const float* src = ws + (size_t)tile * TILE_FLOATS + e0;
+  const size_t stride = (size_t)ntiles * TILE_FLOATS;
+  const int per = (nsplit + 3) >> 2, k_lo = grp * per, k_hi = min(nsplit, k_lo + per);
+  f32x4 acc8[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc8[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    int k = k_lo;
+    for (; k + 7 < k_hi; k += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(k + u) * stride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc8[u] += v[u];
+    }
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (k + u < k_hi) ? *reinterpret_cast<const f32x4*>(src + (size_t)(k + u) * stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc8[u] += v[u];
+  }
+  part[grp][ql] = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+  __syncthreads();
+  if (grp != 0 || !live) return;
+  const f32x4 sum = (part[0][ql] + part[1][ql]) + (part[2][ql] + part[3][ql]);
+  const int slot = e0 / WG_THREADS, tid = e0 % WG_THREADS;
+  const int t = slot / 32, i = (slot >> 4) & 1, r = slot & 15;
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+  const int co = (tile / tiles_ci) * WG_CO + wm * 64 + i * 32 + dx_acc_row(r, lane >> 5);
+  const int ci = (tile % tiles_ci) * WG_CI + wn * 32 + (lane & 31);
+  if (co < Cout) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (ci + j < Cin) dw[((size_t)co * Cin + ci + j) * TAPS + t] += sum[j];
+  }
+}
+
 template <typename TA, typename TB, typename TC>
-int launch_wgrad(const WgradArgs& a, int taps, hipStream_t s) {
+int launch_wgrad(const WgradArgs& a, int taps, hipStream_t s, bool reduce = true) {
   const int ntiles = dx_cdiv(a.Cout, WG_CO) * a.tiles_ci;
   dim3 grid(ntiles * a.nsplit), block(WG_THREADS);
   static int use_ring = getenv("DX_WGRAD_RING") ? atoi(getenv("DX_WGRAD_RING")) : 1;
@@ -2510,12 +2571,12 @@ int launch_wgrad(const WgradArgs& a, int taps, hipStream_t s) {
   if (taps == 1) {
     if (ring && ring_k1) hipLaunchKernelGGL((conv_wgrad_ring_kernel<1>), grid, dim3(WGR_THREADS), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 1>), grid, block, 0, s, a);
-    if (a.ws && !(a.debug & 1))
+    if (reduce && a.ws && !(a.debug & 1))
       hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(ntiles * (1 * 2 * 16 * WG_THREADS / 4 / 64)), dim3(256), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
   } else {
     if (ring) hipLaunchKernelGGL((conv_wgrad_ring_kernel<3>), grid, dim3(WGR_THREADS), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 3>), grid, block, 0, s, a);
-    if (a.ws && !(a.debug & 1))
+    if (reduce && a.ws && !(a.debug & 1))
       hipLaunchKernelGGL((wgrad_reduce_kernel<3>), dim3(ntiles * (3 * 2 * 16 * WG_THREADS / 4 / 64)), dim3(256), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
   }
   DX_LAUNCH_CHECK();
@@ -2680,9 +2741,8 @@ extern "C" long dx_conv1d_wgrad_ws_floats(int B, int N, int Cin, int Cout, int t
   return (long)wgrad_nsplit(B, N, Cin, Cout, taps) * tiles * taps * 2 * 16 * WG_THREADS;
 }
 
-extern "C" int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const void* x, int x_dtype, long ldx,
-                               int compute_dtype, float* dw, float* db, const int64_t* lengths, float* ws, int B, int N,
-                               int Cin, int Cout, int taps, void* stream) {
+static int wgrad_one(const void* dy, int dy_dtype, long lddy, const void* x, int x_dtype, long ldx, int compute_dtype, float* dw, float* db,
+                     const int64_t* lengths, float* ws, int B, int N, int Cin, int Cout, int taps, hipStream_t s, bool reduce, WgradArgs* out) {
   DX_REQUIRE(dy && x && dw, DX_ERR_ARG, "dx_conv1d_wgrad: null pointer");
   DX_REQUIRE(B > 0 && N > 0 && Cin > 0 && Cout > 0, DX_ERR_SHAPE, "dx_conv1d_wgrad: empty shape");
   DX_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0, DX_ERR_SHAPE,
@@ -2693,17 +2753,57 @@ extern "C" int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const vo
   static int k1_atomic = getenv("DX_WGRAD_K1_ATOMIC") ? atoi(getenv("DX_WGRAD_K1_ATOMIC")) : 0;
   if (taps == 1 && k1_atomic) ws = nullptr;
   WgradArgs a{dy, lddy, x, ldx, dw, db, lengths, ws, B, N, Cin, Cout, wgrad_nsplit(B, N, Cin, Cout, taps), dx_cdiv(Cin, WG_CI), dbg};
-  hipStream_t s = (hipStream_t)stream;
+  if (out) *out = a;
   if (compute_dtype == DX_BF16) {
-    if (dy_dtype == DX_F32 && x_dtype == DX_F32) return launch_wgrad<float, float, bf16_t>(a, taps, s);
-    if (dy_dtype == DX_F32 && x_dtype == DX_BF16) return launch_wgrad<float, bf16_t, bf16_t>(a, taps, s);
-    if (dy_dtype == DX_BF16 && x_dtype == DX_F32) return launch_wgrad<bf16_t, float, bf16_t>(a, taps, s);
-    if (dy_dtype == DX_BF16 && x_dtype == DX_BF16) return launch_wgrad<bf16_t, bf16_t, bf16_t>(a, taps, s);
+    if (dy_dtype == DX_F32 && x_dtype == DX_F32) return launch_wgrad<float, float, bf16_t>(a, taps, s, reduce);
+    if (dy_dtype == DX_F32 && x_dtype == DX_BF16) return launch_wgrad<float, bf16_t, bf16_t>(a, taps, s, reduce);
+    if (dy_dtype == DX_BF16 && x_dtype == DX_F32) return launch_wgrad<bf16_t, float, bf16_t>(a, taps, s, reduce);
+    if (dy_dtype == DX_BF16 && x_dtype == DX_BF16) return launch_wgrad<bf16_t, bf16_t, bf16_t>(a, taps, s, reduce);
   } else if (compute_dtype == DX_F32) {
-    if (dy_dtype == DX_F32 && x_dtype == DX_F32) return launch_wgrad<float, float, float>(a, taps, s);
+    if (dy_dtype == DX_F32 && x_dtype == DX_F32) return launch_wgrad<float, float, float>(a, taps, s, reduce);
   }
   dx_set_error("dx_conv1d_wgrad: unsupported dtype combination dy=%d x=%d compute=%d", dy_dtype, x_dtype, compute_dtype);
   return DX_ERR_DTYPE;
+}
+
+extern "C" int dx_conv1d_wgrad(const void* dy, int dy_dtype, long lddy, const void* x, int x_dtype, long ldx,
+                               int compute_dtype, float* dw, float* db, const int64_t* lengths, float* ws, int B, int N,
+                               int Cin, int Cout, int taps, void* stream) {
+  return wgrad_one(dy, dy_dtype, lddy, x, x_dtype, ldx, compute_dtype, dw, db, lengths, ws, B, N, Cin, Cout, taps, (hipStream_t)stream, true, nullptr);
+}
+
+extern "C" int dx_wgrad_desc_size(void) { return (int)sizeof(DxWgradDesc); }
+
+extern "C" long dx_conv1d_wgrad_multi_ws_floats(const DxWgradDesc* d, int n, int B, int N) {
+  long total = 0;
+  for (int i = 0; i < n; ++i) total += dx_conv1d_wgrad_ws_floats(B, N, d[i].Cin, d[i].Cout, d[i].taps);
+  return total;
+}
+
+extern "C" int dx_conv1d_wgrad_multi(const DxWgradDesc* d, int n, int compute_dtype, const int64_t* lengths, float* ws, int B, int N,
+                                     void* stream) {
+  DX_REQUIRE(d && n > 0 && n <= WG_MULTI_MAX && ws, DX_ERR_ARG, "dx_conv1d_wgrad_multi: 1..%d descriptors and a workspace", WG_MULTI_MAX);
+  hipStream_t s = (hipStream_t)stream;
+  MultiReduceArgs m{};
+  int blocks = 0;
+  float* wsp = ws;
+  for (int i = 0; i < n; ++i) {
+    WgradArgs a;
+    if (int rc = wgrad_one(d[i].dy, d[i].dy_dtype, d[i].lddy, d[i].x, d[i].x_dtype, d[i].ldx, compute_dtype, d[i].dw, d[i].db, lengths, wsp, B, N,
+                           d[i].Cin, d[i].Cout, d[i].taps, s, false, &a)) return rc;
+    const int ntiles = dx_cdiv(a.Cout, WG_CO) * a.tiles_ci;
+    if (a.ws && !(a.debug & 1)) {          // (k = 1 with DX_WGRAD_K1_ATOMIC went straight to dW)
+      const int k = m.n++;
+      m.ws[k] = a.ws; m.dw[k] = a.dw; m.nsplit[k] = a.nsplit; m.ntiles[k] = ntiles; m.tiles_ci[k] = a.tiles_ci; m.Cout[k] = a.Cout; m.Cin[k] = a.Cin;
+      m.taps[k] = d[i].taps; m.begin[k] = blocks;
+      blocks += ntiles * (d[i].taps * 2 * 16 * WG_THREADS / 4 / 64);
+    }
+    wsp += dx_conv1d_wgrad_ws_floats(B, N, d[i].Cin, d[i].Cout, d[i].taps);
+  }
+  m.begin[m.n] = blocks;
+  if (m.n) hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, s, m);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
 }
 
 // ---- balanced position tiles (dx_conv_tile_plan) ----------------------------------------------------------------

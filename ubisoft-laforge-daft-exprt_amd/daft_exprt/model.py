@@ -795,21 +795,39 @@ class DaftExprt(nn.Module):
 
     def _issue_side(self, pend):
         side = self._side_stream
-        need = max(ops.wgrad_ws_floats(dy.shape[0], dy.shape[1], x.shape[2], dy.shape[2], dw.shape[2] if dw.dim() == 3 else 1)
-                   for dy, x, dw, db, lengths in pend)
+        shape = lambda dy, x, dw: (dy.shape[0], dy.shape[1], x.shape[2], dy.shape[2], dw.shape[2] if dw.dim() == 3 else 1)
+        # the weight gradients of one flush over the same rows (an FFT block's four, a conv stage's one) go out as ONE call: their GEMM
+        # launches, then a single launch that adds all partial tiles (`ops.conv1d_wgrad_multi`; a reduce launch per weight cost ~20 us
+        # of side-stream time each, 54 times per step)
+        groups = []
+        for it in pend:
+            dy, x, dw, db, lengths = it
+            key = (dy.shape[0], dy.shape[1], None if lengths is None else lengths.data_ptr())
+            if ops.USE_WGRAD_MULTI and ops.WGRAD_WORKSPACE and groups and groups[-1][0] == key and len(groups[-1][1]) < ops.WGRAD_MULTI_MAX:
+                groups[-1][1].append(it)
+            else:
+                groups.append((key, [it]))
+        need = max(sum(ops.wgrad_ws_floats(*shape(dy, x, dw)) for dy, x, dw, db, lengths in items) for _, items in groups)
         if self._wgrad_ws is None or self._wgrad_ws.numel() < need:
             with torch.cuda.stream(side):
                 self._wgrad_ws = torch.empty(max(need, 1 << 24), dtype=torch.float32, device=pend[0][0].device)
         probe = ops.PROBE is not None
-        for dy, x, dw, db, lengths in pend:
+        for _, items in groups:
+            lengths = items[0][4]
+            if len(items) > 1 or (ops.USE_WGRAD_MULTI and ops.WGRAD_WORKSPACE):
+                call = lambda **kw: ops.conv1d_wgrad_multi([(dy, x, dw, db) for dy, x, dw, db, _ in items], self.cd, lengths, ws=self._wgrad_ws, **kw)
+            else:
+                dy, x, dw, db, _ = items[0]
+                call = lambda **kw: ops.conv1d_wgrad(dy, x, dw, db, self.cd, lengths, ws=self._wgrad_ws, **kw)
             if probe:                                   # bench.py's per-family HIP events must sit on the launch stream
                 with torch.cuda.stream(side):
-                    ops.conv1d_wgrad(dy, x, dw, db, self.cd, lengths, ws=self._wgrad_ws)
+                    call()
             else:
-                ops.conv1d_wgrad(dy, x, dw, db, self.cd, lengths, stream=side.cuda_stream, ws=self._wgrad_ws)
+                call(stream=side.cuda_stream)
             # keep the operands alive until the side stream has joined the main one at the end of the backward pass (cheaper on
             # the host than two record_stream calls per launch; the small-N encoder blocks are host-bound)
-            self._wgrad_keep.append((dy, x))
+            for dy, x, dw, db, _ in items:
+                self._wgrad_keep.append((dy, x))
 
     def _fft_stack_bwd(self, W, blocks, du, dfilms, hold=0):
         ''' backward through a stack of FFT blocks, top block first.  dfilms: (B, nb_blocks, 2C) gradient view or None.

@@ -309,6 +309,44 @@ def conv1d_wgrad(dy, x, dw, db, compute_dtype, lengths=None, stream=None, ws=Non
                                     H.stream() if stream is None else stream))
 
 
+class _WgradDesc(ctypes.Structure):
+    _fields_ = [('dy', ctypes.c_void_p), ('x', ctypes.c_void_p), ('dw', ctypes.c_void_p), ('db', ctypes.c_void_p), ('lddy', ctypes.c_long),
+                ('ldx', ctypes.c_long), ('dy_dtype', ctypes.c_int), ('x_dtype', ctypes.c_int), ('Cin', ctypes.c_int), ('Cout', ctypes.c_int),
+                ('taps', ctypes.c_int), ('pad', ctypes.c_int)]
+
+
+WGRAD_MULTI_MAX = 8
+USE_WGRAD_MULTI = bool(int(os.environ.get('DX_WGRAD_MULTI', '1')))   # 0: one dx_conv1d_wgrad call (GEMM + reduce launch) per weight (A/B switch)
+
+
+def conv1d_wgrad_multi(items, compute_dtype, lengths, stream=None, ws=None):
+    ''' items: [(dy (B, N, Cout), x (B, N, Cin), dw, db)] over the same (B, N, lengths), at most WGRAD_MULTI_MAX: the GEMM launches of
+        conv1d_wgrad for each, then ONE launch that adds all their partial tiles to the dw's (dx_conv1d_wgrad_multi).  ws: scratch of at
+        least `wgrad_multi_ws_floats(items)` floats, valid until the call has completed on the stream. '''
+    n = len(items)
+    assert 0 < n <= WGRAD_MULTI_MAX and WGRAD_WORKSPACE
+    B, N = items[0][0].shape[0], items[0][0].shape[1]
+    arr = (_WgradDesc * n)()
+    flops = 0.
+    for i, (dy, x, dw, db) in enumerate(items):
+        assert dy.shape[0] == B and dy.shape[1] == N and x.shape[0] == B and x.shape[1] == N and dy.stride(2) == 1 and x.stride(2) == 1
+        taps = dw.shape[2] if dw.dim() == 3 else 1
+        assert dw.shape[0] == dy.shape[2] and dw.shape[1] == x.shape[2]
+        arr[i] = _WgradDesc(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, dy.stride(1), x.stride(1),
+                            H.dt(dy), H.dt(x), x.shape[2], dy.shape[2], taps, 0)
+        flops += 2. * B * N * x.shape[2] * dy.shape[2] * taps
+    if ws is None:
+        ws = torch.empty(H.lib().dx_conv1d_wgrad_multi_ws_floats(arr, n, B, N), dtype=torch.float32, device=items[0][0].device)
+    with _probe('conv_wgrad', lambda: flops, N):
+        H.check(H.lib().dx_conv1d_wgrad_multi(arr, n, H._DT[compute_dtype], H.ptr(lengths), H.ptr(ws), B, N,
+                                              H.stream() if stream is None else stream))
+
+
+def wgrad_multi_ws_floats(shapes):
+    ''' scratch floats of conv1d_wgrad_multi for [(B, N, Cin, Cout, taps)] '''
+    return sum(H.lib().dx_conv1d_wgrad_ws_floats(*s) for s in shapes)
+
+
 def wgrad_ws_floats(B, N, Cin, Cout, taps):
     return H.lib().dx_conv1d_wgrad_ws_floats(B, N, Cin, Cout, taps)
 
