@@ -2191,6 +2191,9 @@ constexpr int WGR_THREADS = 768, WGR_RING = 4;
 #ifndef WGR_XCD_BLOCKS
 #define WGR_XCD_BLOCKS 1
 #endif
+#ifndef WGR_AHEAD
+#define WGR_AHEAD 1   // 0: one barrier per item in front of its first fragment reads (A/B build)
+#endif
 #ifndef WGR_TAP_SHIFT
 #define WGR_TAP_SHIFT 1   // 0: every tap operand by its own transposed LDS read (A/B build)
 #endif
@@ -2295,6 +2298,23 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
 #pragma unroll
     for (int st = 0; st < WGR_RING - 1; ++st)
       if (st < count) issue_item(st);
+    if constexpr (WGR_AHEAD) {
+      // Barrier j (j = 0 .. count) promises the MFMA waves that items <= j + 1 have landed and that item j - 1's slot is free: one item
+      // of slack, so that they can read the NEXT item's first fragments during the last k-step of the current one (no LDS round trip
+      // and no barrier wait in the open at every item boundary: that was ~40 % of their loop).  Two items in flight instead of three.
+      if (count > 2) dx_wait_vmcnt(mine); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      int nbuf = WGR_RING - 1, buf = 0;
+      for (int k = 0; k < count; ++k) {
+        const bool more = k + WGR_RING - 1 < count;
+        if (more) issue_item(nbuf);
+        if (bias_wg) bias_rows(buf);
+        if (more) dx_wait_vmcnt(mine); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        nbuf = nbuf + 1 == WGR_RING ? 0 : nbuf + 1;
+        buf = buf + 1 == WGR_RING ? 0 : buf + 1;
+      }
+    } else {
     int nbuf = WGR_RING - 1, buf = 0, k = 0;
     for (; k + WGR_RING - 1 < count; ++k) {
       dx_wait_vmcnt(mine * (WGR_RING - 2));
@@ -2309,6 +2329,7 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
       __builtin_amdgcn_s_barrier();
       if (bias_wg) bias_rows(buf);
       buf = buf + 1 == WGR_RING ? 0 : buf + 1;
+    }
     }
     if (bias_wg) {
       const int co = co0 + 2 * lane;
@@ -2347,6 +2368,76 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
   constexpr int NKS = WG_P / 16;
   if (!(p.debug & 16)) __builtin_amdgcn_s_setprio(2);   // the loader wave of this SIMD takes the issue slots the MFMA waves leave (debug 16: equal priority)
   int buf = 0;
+  if constexpr (WGR_AHEAD && (TAPS == 1 || WGR_TAP_SHIFT)) {
+    // software pipeline ACROSS items (see the loader loop: barrier j guarantees item j + 1): the fragments of (item k + 1, k-step 0)
+    // are requested in front of the MFMAs of (item k, last k-step); NKS is even, so the fragment double-buffer keeps its parity
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+    static_assert(NKS % 2 == 0, "fragment parity across items");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    bf16x8 a[2][2];
+    u32x4 f[2];
+    if (count > 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[0][i] = tr8(ring, offA[i], 0);
+      f[0] = __builtin_bit_cast(u32x4, tr8(ring + A_PIECES * 512, offX[0], 0));
+    }
+    for (int k = 0; k < count; ++k) {
+      const bf16_t* A = ring + buf * ITEM_EL;
+      const bf16_t* Xs = A + A_PIECES * 512;
+      const int nb = buf + 1 == WGR_RING ? 0 : buf + 1;
+      const bf16_t* An = ring + nb * ITEM_EL;
+      const bf16_t* Xn = An + A_PIECES * 512;
+      const bool more = k + 1 < count;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        uint32_t tail0 = 0;
+        if (ks + 1 < NKS) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a[(ks + 1) & 1][i] = tr8(A, offA[i], ks + 1);
+          f[(ks + 1) & 1] = __builtin_bit_cast(u32x4, tr8(Xs, offX[0], ks + 1));
+        } else {
+          if constexpr (TAPS == 3) {   // rows 64 .. 67 of the haloed tile: the dword behind the last 8-position block (lanes 0 - 31 are consumed)
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Xs + offX[0] + NKS * 16 * 128 - g * 8 * 128));
+            tail0 = __builtin_bit_cast(u32x2v, lo)[0];
+          }
+          if (more) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[(ks + 1) & 1][i] = tr8(An, offA[i], 0);
+            f[(ks + 1) & 1] = __builtin_bit_cast(u32x4, tr8(Xn, offX[0], 0));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.debug & 2)) {
+          const u32x4 c = f[ks & 1];
+          const bf16x8 bx0 = __builtin_bit_cast(bf16x8, c);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) dx_mma(acc[0][i], a[ks & 1][i], bx0);
+          if constexpr (TAPS == 3) {
+            const uint32_t nxt = ks + 1 < NKS ? f[(ks + 1) & 1][0] : tail0;
+            const u32x2v sw = __builtin_amdgcn_permlane32_swap(c[0], nxt, false, false);
+            const uint32_t n0 = g ? sw[0] : sw[1];        // first two positions of the next 8-position block of this lane's channel
+            const u32x4 t1 = {__builtin_amdgcn_alignbit(c[1], c[0], 16), __builtin_amdgcn_alignbit(c[2], c[1], 16),
+                              __builtin_amdgcn_alignbit(c[3], c[2], 16), __builtin_amdgcn_alignbit(n0, c[3], 16)};
+            const u32x4 t2 = {c[1], c[2], c[3], n0};
+            const bf16x8 bx1 = __builtin_bit_cast(bf16x8, t1), bx2 = __builtin_bit_cast(bf16x8, t2);
+            if (!(p.debug & 32)) {
+#pragma unroll
+              for (int i = 0; i < 2; ++i) dx_mma(acc[TAPS > 1 ? 1 : 0][i], a[ks & 1][i], bx1);
+#pragma unroll
+              for (int i = 0; i < 2; ++i) dx_mma(acc[TAPS > 2 ? 2 : 0][i], a[ks & 1][i], bx2);
+            }
+          }
+        }
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();      // item k consumed (its slot may be refilled); item k + 2 has landed
+      asm volatile("" ::: "memory");
+      buf = nb;
+    }
+  } else
   for (int k = 0; k < count; ++k) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
