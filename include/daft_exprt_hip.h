@@ -313,6 +313,26 @@ int dx_linear_small_bwd(const float* dy, const float* y, const float* x, const f
 int dx_gather_add_fwd(const float* a, const float* table, const int64_t* ids, float* out, int B, int C, void* stream);
 int dx_gather_add_bwd(const float* dz, const int64_t* ids, float* dtable, int B, int C, void* stream);
 
+/* The two per-utterance heads behind the prosody embedding as single launches (C = 128).
+ * dx_film_head_fwd = dx_gather_add_fwd + 2 x dx_linear_small_fwd + dx_film_assemble_fwd (model.py:419-462): z = emb + spk_table[ids]
+ * (B, C), g_raw / b_raw = z W^T + bias (B, W), the three FiLM tensors assembled; bit-identical to the separate launches.
+ * dx_film_head_bwd: from dfilm_* -- (dg_raw, db_raw) into the two (B, W) scratch buffers, dpost +=, d_emb += dz and d_spk_table[ids] += dz
+ * (fp32 atomics), then the weight / bias gradients of both projections (+=, one thread per element: deterministic).
+ * dx_classifier_fwd / _bwd (model.py:27-54, 276-292): three linear layers with ReLU; the backward WRITES d_emb = -lambda * (...) (the
+ * gradient reversal), stores the gated gradients of layers 1 / 2 in two (B, C) scratch buffers and accumulates the six parameter
+ * gradients.  S = number of logits (<= 128). */
+int dx_film_head_fwd(const float* emb, const float* spk_table, const int64_t* spk_ids, const float* wg, const float* bg, const float* wb,
+                     const float* bb, const float* post, float* z, float* g_raw, float* b_raw, float* film_enc, float* film_pp,
+                     float* film_dec, const int* nb, const int* ch, int B, int C, void* stream);
+int dx_film_head_bwd(const float* g_raw, const float* b_raw, const float* post, const float* z, const int64_t* spk_ids, const float* wg,
+                     const float* wb, const float* dfilm_enc, const float* dfilm_pp, const float* dfilm_dec, float* dg_raw_ws,
+                     float* db_raw_ws, float* d_emb, float* d_spk_table, float* dpost, float* dwg, float* dbg, float* dwb, float* dbb,
+                     const int* nb, const int* ch, int B, int C, void* stream);
+int dx_classifier_fwd(const float* emb, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                      const float* b3, float* h1, float* h2, float* logits, int B, int C, int S, void* stream);
+int dx_classifier_bwd(const float* d_logits, const float* emb, const float* h1, const float* h2, const float* w1, const float* w2,
+                      const float* w3, float* g1_ws, float* g2_ws, float* d_emb, float lambda, float* dw1, float* db1, float* dw2,
+                      float* db2, float* dw3, float* db3, int B, int C, int S, void* stream);
 int dx_add_inplace(float* dst, const float* src, long n, void* stream);           /* dst += src */
 int dx_colsum(const void* x, int dtype, float* out, long rows, int C, void* stream); /* out[c] += sum_r x[r][c] (bias grads) */
 int dx_scale(float* x, long n, float s, void* stream);

@@ -628,13 +628,19 @@ class DaftExprt(nn.Module):
                                                     f'{pre}.blocks.{blk + 1}' if blk + 1 < cfg['nb_blocks'] else None)
             s.blocks.append(sb)
         emb = ops.masked_mean_fwd(x0, output_lengths)
-        z = ops.gather_add_fwd(emb, P[f'{pre}.spk_embedding.weight'], speaker_ids)
-        g_raw = ops.linear_small_fwd(z, P[f'{pre}.gammas_predictor.linear_layer.weight'], P[f'{pre}.gammas_predictor.linear_layer.bias'])
-        b_raw = ops.linear_small_fwd(z, P[f'{pre}.betas_predictor.linear_layer.weight'], P[f'{pre}.betas_predictor.linear_layer.bias'])
         layout = film_layout(hp)
         nb, ch = [n for n, _ in layout], [c for _, c in layout]
         post = P[f'{pre}.post_multipliers'] if hp.post_mult_weight != 0. else None
-        films = ops.film_assemble_fwd(g_raw, b_raw, post, nb, ch)
+        if ops.USE_FUSED_HEADS:      # speaker-embedding add + both FiLM projections + the FiLM split in one launch
+            z, g_raw, b_raw, films = ops.film_head_fwd(emb, P[f'{pre}.spk_embedding.weight'], speaker_ids,
+                                                       P[f'{pre}.gammas_predictor.linear_layer.weight'], P[f'{pre}.gammas_predictor.linear_layer.bias'],
+                                                       P[f'{pre}.betas_predictor.linear_layer.weight'], P[f'{pre}.betas_predictor.linear_layer.bias'],
+                                                       post, nb, ch)
+        else:
+            z = ops.gather_add_fwd(emb, P[f'{pre}.spk_embedding.weight'], speaker_ids)
+            g_raw = ops.linear_small_fwd(z, P[f'{pre}.gammas_predictor.linear_layer.weight'], P[f'{pre}.gammas_predictor.linear_layer.bias'])
+            b_raw = ops.linear_small_fwd(z, P[f'{pre}.betas_predictor.linear_layer.weight'], P[f'{pre}.betas_predictor.linear_layer.bias'])
+            films = ops.film_assemble_fwd(g_raw, b_raw, post, nb, ch)
         s.T, s.z, s.g_raw, s.b_raw, s.nb, s.ch, s.post = x0.shape[1], z, g_raw, b_raw, nb, ch, post
         s.frames_energy, s.frames_pitch, s.speaker_ids, s.output_lengths = frames_energy, frames_pitch, speaker_ids, output_lengths
         return emb, films, s
@@ -642,6 +648,10 @@ class DaftExprt(nn.Module):
     def _classifier_fwd(self, emb):
         ''' `model.py:285-292`; the gradient reversal is an identity here and a sign flip in `_backward` '''
         P, pre = self._P, 'speaker_classifier.classifier'
+        if ops.USE_FUSED_HEADS:
+            logits, h1, h2 = ops.classifier_fwd(emb, P[f'{pre}.1.linear_layer.weight'], P[f'{pre}.1.linear_layer.bias'], P[f'{pre}.3.linear_layer.weight'],
+                                                P[f'{pre}.3.linear_layer.bias'], P[f'{pre}.5.linear_layer.weight'], P[f'{pre}.5.linear_layer.bias'])
+            return logits, (emb, h1, h2)
         h1 = ops.linear_small_fwd(emb, P[f'{pre}.1.linear_layer.weight'], P[f'{pre}.1.linear_layer.bias'], relu=True)
         h2 = ops.linear_small_fwd(h1, P[f'{pre}.3.linear_layer.weight'], P[f'{pre}.3.linear_layer.bias'], relu=True)
         logits = ops.linear_small_fwd(h2, P[f'{pre}.5.linear_layer.weight'], P[f'{pre}.5.linear_layer.bias'])
@@ -1028,7 +1038,12 @@ class DaftExprt(nn.Module):
         pe = S.pe
         emb, h1, h2 = S.cls
         cl = 'speaker_classifier.classifier'
-        if d_spk is not None:
+        if d_spk is not None and ops.USE_FUSED_HEADS:
+            d_emb = ops.classifier_bwd(d_spk.contiguous(), emb, h1, h2, P[f'{cl}.1.linear_layer.weight'], P[f'{cl}.3.linear_layer.weight'],
+                                       P[f'{cl}.5.linear_layer.weight'], float(hp.lambda_reversal), G[f'{cl}.1.linear_layer.weight'],
+                                       G[f'{cl}.1.linear_layer.bias'], G[f'{cl}.3.linear_layer.weight'], G[f'{cl}.3.linear_layer.bias'],
+                                       G[f'{cl}.5.linear_layer.weight'], G[f'{cl}.5.linear_layer.bias'])
+        elif d_spk is not None:
             d_h2 = ops.linear_small_bwd(d_spk.contiguous(), None, h2, P[f'{cl}.5.linear_layer.weight'], G[f'{cl}.5.linear_layer.weight'],
                                         G[f'{cl}.5.linear_layer.bias'])
             d_h1 = ops.linear_small_bwd(d_h2, h2, h1, P[f'{cl}.3.linear_layer.weight'], G[f'{cl}.3.linear_layer.weight'],
@@ -1041,14 +1056,20 @@ class DaftExprt(nn.Module):
         # ---- FiLM head
         pre = 'prosody_encoder'
         dpost = G[f'{pre}.post_multipliers'] if pe.post is not None else None
-        dg_raw, db_raw = ops.film_assemble_bwd(pe.g_raw, pe.b_raw, pe.post, dfilms, dpost, pe.nb, pe.ch)
-        dz = ops.linear_small_bwd(dg_raw, None, pe.z, P[f'{pre}.gammas_predictor.linear_layer.weight'],
-                                  G[f'{pre}.gammas_predictor.linear_layer.weight'], G[f'{pre}.gammas_predictor.linear_layer.bias'])
-        dz2 = ops.linear_small_bwd(db_raw, None, pe.z, P[f'{pre}.betas_predictor.linear_layer.weight'],
-                                   G[f'{pre}.betas_predictor.linear_layer.weight'], G[f'{pre}.betas_predictor.linear_layer.bias'])
-        ops.add_(dz, dz2)
-        ops.gather_add_bwd(dz, pe.speaker_ids, G[f'{pre}.spk_embedding.weight'])
-        ops.add_(d_emb, dz)
+        if ops.USE_FUSED_HEADS:      # two launches: data side (into d_emb, the speaker-embedding gradient, dpost) + all four parameter gradients
+            ops.film_head_bwd(pe.g_raw, pe.b_raw, pe.post, pe.z, pe.speaker_ids, P[f'{pre}.gammas_predictor.linear_layer.weight'],
+                              P[f'{pre}.betas_predictor.linear_layer.weight'], dfilms, d_emb, G[f'{pre}.spk_embedding.weight'], dpost,
+                              G[f'{pre}.gammas_predictor.linear_layer.weight'], G[f'{pre}.gammas_predictor.linear_layer.bias'],
+                              G[f'{pre}.betas_predictor.linear_layer.weight'], G[f'{pre}.betas_predictor.linear_layer.bias'], pe.nb, pe.ch)
+        else:
+            dg_raw, db_raw = ops.film_assemble_bwd(pe.g_raw, pe.b_raw, pe.post, dfilms, dpost, pe.nb, pe.ch)
+            dz = ops.linear_small_bwd(dg_raw, None, pe.z, P[f'{pre}.gammas_predictor.linear_layer.weight'],
+                                      G[f'{pre}.gammas_predictor.linear_layer.weight'], G[f'{pre}.gammas_predictor.linear_layer.bias'])
+            dz2 = ops.linear_small_bwd(db_raw, None, pe.z, P[f'{pre}.betas_predictor.linear_layer.weight'],
+                                       G[f'{pre}.betas_predictor.linear_layer.weight'], G[f'{pre}.betas_predictor.linear_layer.bias'])
+            ops.add_(dz, dz2)
+            ops.gather_add_bwd(dz, pe.speaker_ids, G[f'{pre}.spk_embedding.weight'])
+            ops.add_(d_emb, dz)
         # ---- prosody encoder trunk
         dx = ops.masked_mean_bwd(d_emb, pe.output_lengths, pe.T)
         dx = self._fft_stack_bwd(W, pe.blocks, dx, None)

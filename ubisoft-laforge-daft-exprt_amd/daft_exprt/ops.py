@@ -517,6 +517,55 @@ def film_assemble_bwd(g_raw, b_raw, post, dfilms, dpost, nb, ch):
     return dg, db
 
 
+USE_FUSED_HEADS = bool(int(os.environ.get('DX_FUSED_HEADS', '1')))   # 0: the FiLM head / speaker classifier as their separate small launches (A/B switch)
+
+
+def film_head_fwd(emb, spk_table, spk_ids, wg, bg, wb, bb, post, nb, ch):
+    ''' (z, g_raw, b_raw, [film_enc, film_pp, film_dec]) in one launch (dx_film_head_fwd) '''
+    B, C = emb.shape
+    W = sum(n * c for n, c in zip(nb, ch))
+    dev = emb.device
+    z = torch.empty((B, C), dtype=torch.float32, device=dev)
+    g_raw, b_raw = torch.empty((B, W), dtype=torch.float32, device=dev), torch.empty((B, W), dtype=torch.float32, device=dev)
+    films = [torch.empty((B, nb[m], 2 * ch[m]), dtype=torch.float32, device=dev) for m in range(3)]
+    H.check(H.lib().dx_film_head_fwd(H.ptr(emb), H.ptr(spk_table), H.ptr(spk_ids), H.ptr(wg), H.ptr(bg), H.ptr(wb), H.ptr(bb), H.ptr(post),
+                                     H.ptr(z), H.ptr(g_raw), H.ptr(b_raw), H.ptr(films[0]), H.ptr(films[1]), H.ptr(films[2]),
+                                     _int_array(nb), _int_array(ch), B, C, H.stream()))
+    return z, g_raw, b_raw, films
+
+
+def film_head_bwd(g_raw, b_raw, post, z, spk_ids, wg, wb, dfilms, d_emb, d_spk_table, dpost, dwg, dbg, dwb, dbb, nb, ch):
+    ''' everything behind the FiLM tensors' gradients in two launches (dx_film_head_bwd); d_emb, d_spk_table, dpost and the four
+        parameter gradients are accumulated '''
+    B, C = z.shape
+    ws = torch.empty((2,) + tuple(g_raw.shape), dtype=torch.float32, device=z.device)
+    H.check(H.lib().dx_film_head_bwd(H.ptr(g_raw), H.ptr(b_raw), H.ptr(post), H.ptr(z), H.ptr(spk_ids), H.ptr(wg), H.ptr(wb), H.ptr(dfilms[0]),
+                                     H.ptr(dfilms[1]), H.ptr(dfilms[2]), H.ptr(ws[0]), H.ptr(ws[1]), H.ptr(d_emb), H.ptr(d_spk_table), H.ptr(dpost),
+                                     H.ptr(dwg), H.ptr(dbg), H.ptr(dwb), H.ptr(dbb), _int_array(nb), _int_array(ch), B, C, H.stream()))
+
+
+def classifier_fwd(emb, w1, b1, w2, b2, w3, b3):
+    B, C = emb.shape
+    S = w3.shape[0]
+    h1, h2 = torch.empty_like(emb), torch.empty_like(emb)
+    logits = torch.empty((B, S), dtype=torch.float32, device=emb.device)
+    H.check(H.lib().dx_classifier_fwd(H.ptr(emb), H.ptr(w1), H.ptr(b1), H.ptr(w2), H.ptr(b2), H.ptr(w3), H.ptr(b3), H.ptr(h1), H.ptr(h2),
+                                      H.ptr(logits), B, C, S, H.stream()))
+    return logits, h1, h2
+
+
+def classifier_bwd(d_logits, emb, h1, h2, w1, w2, w3, lambda_, dw1, db1, dw2, db2, dw3, db3):
+    ''' returns d_emb = -lambda * dL/d(classifier input); parameter gradients accumulated (dx_classifier_bwd, two launches) '''
+    B, C = emb.shape
+    ws = torch.empty((2, B, C), dtype=torch.float32, device=emb.device)
+    d_emb = torch.empty_like(emb)
+    assert d_logits.is_contiguous()
+    H.check(H.lib().dx_classifier_bwd(H.ptr(d_logits), H.ptr(emb), H.ptr(h1), H.ptr(h2), H.ptr(w1), H.ptr(w2), H.ptr(w3), H.ptr(ws[0]), H.ptr(ws[1]),
+                                      H.ptr(d_emb), float(lambda_), H.ptr(dw1), H.ptr(db1), H.ptr(dw2), H.ptr(db2), H.ptr(dw3), H.ptr(db3), B, C,
+                                      w3.shape[0], H.stream()))
+    return d_emb
+
+
 def linear_small_fwd(x, w, bias, relu=False, mask_lengths=None, N=1):
     K = x.shape[-1]
     M = x.numel() // K
