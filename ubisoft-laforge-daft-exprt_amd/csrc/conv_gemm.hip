@@ -2194,6 +2194,9 @@ constexpr int WGR_THREADS = 768, WGR_RING = 4;
 #ifndef WGR_AHEAD
 #define WGR_AHEAD 1   // 0: one barrier per item in front of its first fragment reads (A/B build)
 #endif
+#ifndef WGR_BIAS_IN_MFMA_WAVES
+#define WGR_BIAS_IN_MFMA_WAVES 1   // 0: bias column sums by the loader waves from the LDS tile (A/B build)
+#endif
 #ifndef WGR_TAP_SHIFT
 #define WGR_TAP_SHIFT 1   // 0: every tap operand by its own transposed LDS read (A/B build)
 #endif
@@ -2308,7 +2311,7 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
       for (int k = 0; k < count; ++k) {
         const bool more = k + WGR_RING - 1 < count;
         if (more) issue_item(nbuf);
-        if (bias_wg) bias_rows(buf);
+        if (bias_wg && !WGR_BIAS_IN_MFMA_WAVES) bias_rows(buf);
         if (more) dx_wait_vmcnt(mine); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         nbuf = nbuf + 1 == WGR_RING ? 0 : nbuf + 1;
@@ -2331,7 +2334,7 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
       buf = buf + 1 == WGR_RING ? 0 : buf + 1;
     }
     }
-    if (bias_wg) {
+    if (bias_wg && !(WGR_AHEAD && WGR_BIAS_IN_MFMA_WAVES && (TAPS == 1 || WGR_TAP_SHIFT))) {
       const int co = co0 + 2 * lane;
       if (co < Cout) atomicAdd(p.db + co, bs0);
       if (co + 1 < Cout) atomicAdd(p.db + co + 1, bs1);
@@ -2379,6 +2382,12 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
     asm volatile("" ::: "memory");
     bf16x8 a[2][2];
     u32x4 f[2];
+    // bias gradient = column sums of the dY tile.  The loader waves used to take them from the LDS tile between their barriers (16 LDS
+    // reads + 32 adds per item ON THE LOADERS' critical path: 5 us of a 41 us launch, 10 us of the MFMA-waves-only ablation).  The four
+    // waves of a channel-row group hold the same dY fragments: wave wn sums the fragments of k-step ks == wn (8 positions of one channel
+    // per lane and fragment: 16 VALU ops per fragment beside the MFMAs), one register per channel block.
+    const bool bias_here = WGR_BIAS_IN_MFMA_WAVES && p.db && ci0 == 0 && !(p.debug & 4);
+    float bsum[2] = {0.f, 0.f};
     if (count > 0) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) a[0][i] = tr8(ring, offA[i], 0);
@@ -2394,7 +2403,8 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         uint32_t tail0 = 0;
-        if (ks + 1 < NKS) {
+        if (p.debug & 64) {   // (debug 64: no fragment reads inside the loop -- the MFMA sequence alone)
+        } else if (ks + 1 < NKS) {
 #pragma unroll
           for (int i = 0; i < 2; ++i) a[(ks + 1) & 1][i] = tr8(A, offA[i], ks + 1);
           f[(ks + 1) & 1] = __builtin_bit_cast(u32x4, tr8(Xs, offX[0], ks + 1));
@@ -2410,6 +2420,14 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (bias_here && ks == wn) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const u32x4 av = __builtin_bit_cast(u32x4, a[ks & 1][i]);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) bsum[i] += __uint_as_float(av[d] << 16) + __uint_as_float(av[d] & 0xffff0000u);
+          }
+        }
         if (!(p.debug & 2)) {
           const u32x4 c = f[ks & 1];
           const bf16x8 bx0 = __builtin_bit_cast(bf16x8, c);
@@ -2436,6 +2454,14 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
       __builtin_amdgcn_s_barrier();      // item k consumed (its slot may be refilled); item k + 2 has landed
       asm volatile("" ::: "memory");
       buf = nb;
+    }
+    if (bias_here) {   // the two half-waves hold the two position halves of every k-step
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float t = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+        const int co = co0 + wm * 64 + i * 32 + l31;
+        if (g == 0 && co < Cout) atomicAdd(p.db + co, t);
+      }
     }
   } else
   for (int k = 0; k < count; ++k) {
