@@ -419,8 +419,11 @@ def main():
         raise SystemExit(f'bench.py: {world} ranks requested but only {torch.cuda.device_count()} GPU(s) visible')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # DX_FORCE_DIST=1: also a single rank builds its (one-rank) RCCL world and runs every collective of the N > 1 path
+    dist_on = world > 1 or os.environ.get('DX_FORCE_DIST', '0') == '1'
+    if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('NCCL_DEBUG', 'VERSION')
         dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev)
@@ -441,7 +444,7 @@ def main():
     model.set_rank(rank)
     trainer = Trainer(model, hp, world)
     if rank == 0:      # stderr: the JSON line stays alone on stdout
-        print(f'[bench] torch.distributed world {dist.get_world_size() if world > 1 else 1}; {trainer.reducer.describe()}', file=sys.stderr)
+        print(f'[bench] torch.distributed world {dist.get_world_size() if dist_on else 1}; {trainer.reducer.describe()}', file=sys.stderr)
     batches, cpu_batches = [], []
     for i in range(args.pool):
         cb = synthetic_batch(hp, args.batch, seed=1234 + rank + 1000 * i, t_min=args.tmin, t_max=1000, force_first_full=True)
@@ -452,7 +455,7 @@ def main():
     flops = [3. * sum(f_fwd(int(t), int(l)) for t, l in zip(b[0][9].tolist(), b[0][5].tolist())) for b in batches]
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
     it = 20000   # adversarial weight at its maximum (>= warmup_steps): the GRL path is live
@@ -476,7 +479,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     stats = torch.tensor([elapsed, float(done_frames), done_flops], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tot = stats[1:].clone()
@@ -548,7 +551,7 @@ def main():
             sargs.batch, sargs.steps, sargs.warmup, sargs.workload = 256, 10, 3, 'synth'
             out['synth'] = synth_bench(sargs, make_hparams(256, 'bf16'), dev, 0, 1, emit=False, cpu_steps=(1, 3))
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

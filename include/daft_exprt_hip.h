@@ -350,6 +350,11 @@ int dx_fill_zero(void* p, size_t bytes, void* stream);
  * executor keeps on the forking node's queue -- the capturing trainer records one on the launch stream right behind every fork to
  * the weight-gradient stream (train.CapturedStep) */
 int dx_anchor(void* stream);
+/* one wave that occupies its hardware queue for `microseconds` (<= 100 000): HIP maps streams onto a few hardware queues
+ * (GPU_MAX_HW_QUEUES, 4 by default) and two streams on the SAME queue run in submission order -- the weight-gradient stream, the
+ * optimizer stream and RCCL's stream only overlap with the launch stream when they sit on other queues.  daft_exprt.streams probes
+ * that with this kernel and picks streams that do (no reference counterpart: torch / DDP leave it to chance). */
+int dx_spin(int microseconds, void* stream);
 
 /* ---- K11: Gaussian upsampling (GaussianUpsamplingModule.forward, model.py:608-662), fp32, integer prefix sums exact.
  * dx_gu_prepare : xp = enc + conv(energy) + conv(pitch); rin = xp + conv(dur_float); r_pre = w_range . rin + b_range;

@@ -20,7 +20,7 @@ def _state(mode, fuse, steps=2):
     model = DaftExprt(hp).to(DEV).train()
     trainer = Trainer(model, hp, 1)
     trainer.captured = None
-    trainer.optimizer.fuse_pack = fuse
+    trainer.optimizer.fuse_pack = bool(fuse)
     cb = synthetic_batch(hp, 4, seed=21, t_max=150, force_first_full=True, l_range=(6, 20))
     inputs, targets, _ = model.parse_batch(DEV, cb)
     g_fixed = None
@@ -31,7 +31,13 @@ def _state(mode, fuse, steps=2):
         gen = torch.Generator(device=DEV).manual_seed(100 + it)
         model.flat_gradients().copy_(torch.randn(model.n_params, generator=gen, device=DEV) * 1e-2)
         trainer.optimizer.param_groups[0]['lr'] = 1e-3
-        gn = trainer.optimizer.step().clone()
+        if fuse == 'buckets':      # the data-parallel form: one fused launch per gradient bucket, in backward order
+            trainer.optimizer.begin_step()
+            for _, off, n in trainer.reducer.buckets:
+                trainer.optimizer.step_slice(off, n)
+            gn = trainer.optimizer.end_step().clone()
+        else:
+            gn = trainer.optimizer.step().clone()
         model.zero_grad()
     W = model._weights(need_dgrad=True)       # flat path: re-packs here; fused path: everything is already current
     torch.cuda.synchronize()
@@ -51,6 +57,17 @@ def test_fused_adam_pack_equals_adam_then_pack(mode):
         assert torch.equal(W0[k], W1[k]), k
         kinds.add(k.split(':')[0] if ':' in k else 'fwd')
     assert kinds == ({'fwd', 'T', 'F', 'FT'} if mode == 'bf16' else {'fwd', 'T'}), kinds
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'fp32'])
+def test_fused_adam_pack_per_bucket_equals_adam_then_pack(mode):
+    ''' the per-bucket form the multi-rank trainer runs behind each all-reduce (`FusedAdam.step_slice`) '''
+    p0, m0, v0, gn0, W0 = _state(mode, False)
+    p1, m1, v1, gn1, W1 = _state(mode, 'buckets')
+    assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+    assert abs(float(gn0) - float(gn1)) <= 1e-5 * float(gn0)
+    for k in W0:
+        assert torch.equal(W0[k], W1[k]), k
 
 
 def test_fused_path_skips_the_pack_launches():

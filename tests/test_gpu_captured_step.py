@@ -82,7 +82,8 @@ def test_replays_follow_the_eager_trajectory_and_schedule(monkeypatch):
     for a, b in ((tr_e.optimizer.exp_avg, tr_g.optimizer.exp_avg), (tr_e.optimizer.exp_avg_sq, tr_g.optimizer.exp_avg_sq)):
         assert float((a - b).abs().mean()) <= 8e-2 * float(a.abs().mean())   # (two eager runs differ by ~3 % after 8 steps: fp32-atomic order, fed back through Adam)
     assert tr_e.optimizer.step_count == tr_g.optimizer.step_count == steps
-    assert torch.allclose(terms_e, terms_g, rtol=2e-2, atol=1e-6), (terms_e - terms_g).abs().max()
+    # (bit-identity of replays is the lr = 0 test above; two EAGER runs of these 8 steps already differ by up to ~3 % per term)
+    assert torch.allclose(terms_e, terms_g, rtol=6e-2, atol=1e-5), (terms_e - terms_g).abs().max()
     assert torch.allclose(gn_e, gn_g, rtol=1e-1)          # squared norms, 8 steps apart on a 4-utterance batch: the runs decorrelate by a few per cent
     # the speaker term carries the ramped weight: iteration * 1e-6 (it grows step by step also inside the replays)
     assert terms_g[-1, 0] > terms_g[2, 0] > 0.

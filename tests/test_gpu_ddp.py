@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(backend, world):
+def _run(backend, world, **extra_env):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), **extra_env)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'tests', 'ddp_worker.py'), backend]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -33,6 +33,29 @@ def test_two_ranks_match_single_process_gradients():
         _run('nccl', 2)
     else:
         _run('gloo', 2)
+
+
+def test_one_rank_rccl_world_runs_the_multi_rank_path():
+    ''' what a 1-GPU box can prove about the N > 1 path on REAL RCCL: a one-rank "nccl" process group with DX_FORCE_DIST=1 builds
+        the communicator, broadcasts, issues the asynchronous per-bucket all-reduces from the backward hooks, orders the per-bucket
+        Adam behind them with stream waits, and lands on the parameters of a trainer that does none of that (tests/ddp_worker.py) '''
+    _run('nccl', 1, DX_FORCE_DIST='1')
+
+
+def test_bench_line_through_a_one_rank_rccl_world():
+    ''' bench.py's N > 1 branches (process group, barriers, max-over-ranks clock, summed frames) on a one-rank RCCL world '''
+    import json
+    env = dict(os.environ, DX_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '3',
+                        '--batch', '8', '--no-cpu-baseline', '--no-probe', '--no-secondary'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 1 and line['value'] > 0
+    assert 'backend nccl' in r.stderr and 'world 1' in r.stderr, r.stderr[-2000:]
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs >= 2 GPUs for an RCCL world')

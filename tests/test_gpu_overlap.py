@@ -52,7 +52,7 @@ def _run(monkeypatch, delay_cycles, sync, sectioned, steps=2):
     torch.manual_seed(7)
     model = DaftExprt(hp).to(DEV).train()
     trainer = Trainer(model, hp, 1)
-    trainer.world = trainer.reducer.world = 2      # two "ranks": the reducer issues its collectives
+    trainer.world = trainer.reducer.world = 2; trainer.reducer.active = True      # two "ranks": the reducer issues its collectives
     for it in range(steps):
         micro = []
         for k in range(2):
@@ -143,6 +143,7 @@ def _run_snapshots(monkeypatch, producer_delay, sync, sectioned, steps=2):
     model = DaftExprt(hp).to(DEV).train()
     trainer = Trainer(model, hp, 1)
     trainer.world = trainer.reducer.world = 2
+    trainer.reducer.active = True
     for it in range(steps):
         micro = []
         for k in range(2):
@@ -169,3 +170,15 @@ def test_collective_reads_a_bucket_only_after_every_producer(monkeypatch, sectio
         assert err <= 1e-3, f'bucket "{names[i]}" was read {err:.3f} away from its finished value: a producer was still writing it'
     moved = ((p_ref - p_late).abs() > 1e-5).float().mean()
     assert float(moved) < 0.2, float(moved)
+
+
+def test_stream_probe_tells_shared_from_separate_hardware_queues():
+    ''' `streams.runs_beside`: a stream never runs beside itself; `streams.pick` returns a stream that does run beside the launch
+        stream (and beside a second picked one), which is what the weight-gradient / optimizer streams are built from '''
+    from daft_exprt import streams
+    main = torch.cuda.current_stream()
+    assert not streams.runs_beside(main, main)
+    a = streams.pick([main], what='test stream')
+    assert streams.runs_beside(a, main) and streams.runs_beside(main, a)
+    b = streams.pick([main, a], what='second test stream')
+    assert streams.runs_beside(b, main) and streams.runs_beside(b, a)

@@ -642,6 +642,19 @@ extern "C" int dx_anchor(void* stream) {
   return DX_OK;
 }
 
+// one wave that keeps its hardware queue occupied for `microseconds` (100 MHz constant clock): the probe behind
+// daft_exprt.streams.runs_beside -- "do these two HIP streams sit on different hardware queues?"
+__global__ void spin_kernel(long ticks) {
+  const long t0 = wall_clock64();
+  while ((long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int dx_spin(int microseconds, void* stream) {
+  DX_REQUIRE(microseconds >= 0 && microseconds <= 100000, DX_ERR_ARG, "dx_spin: 0 .. 100000 us");
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long)microseconds * 100);
+  DX_LAUNCH_CHECK();
+  return DX_OK;
+}
+
 extern "C" int dx_fill_zero(void* p, size_t bytes, void* stream) {
   DX_REQUIRE(p || bytes == 0, DX_ERR_ARG, "dx_fill_zero: null pointer");
   if (bytes == 0) return DX_OK;

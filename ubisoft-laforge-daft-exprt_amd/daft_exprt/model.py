@@ -26,7 +26,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from daft_exprt import ops
+from daft_exprt import ops, streams
 
 _MASK63 = (1 << 63) - 1
 
@@ -186,7 +186,7 @@ class DaftExprt(nn.Module):
         assert [n for n, _ in self.named_parameters()] == [n for n, _, _ in self._table]
         self._flat = self._gflat = None
         self._packed, self._packed_version, self._param_version = {}, -1, 0
-        self._adam_table = None
+        self._adam_table = {}
         self._pack_stream, self._packs_pending = None, False
         # True (default, always safe): re-pack the bf16 weight copies on every call (one batched kernel, ~40 us).  False: re-pack only
         # when the parameters changed through torch -- `_weights` watches the version counters of the GEMM weights, so
@@ -248,7 +248,7 @@ class DaftExprt(nn.Module):
         self._flat, self._gflat = flat, gflat
         self._pos = None
         self._packed = {}
-        self._adam_table = None
+        self._adam_table = {}
         self._pack_stream, self._packs_pending = None, False   # (a new device after .to(): new stream)
         self.mark_updated()
 
@@ -384,17 +384,22 @@ class DaftExprt(nn.Module):
             self._packs_pending = True
         return self._packed
 
-    def adam_pack_table(self):
+    def adam_pack_table(self, rng=None):
         ''' the tables of `ops.adam_pack_step` (Adam fused with the refresh of the operand copies) for the copies `_weights` keeps, or
             None before the first forward pass has created them.  Every GEMM weight with its copies; every other parameter as
-            flat ranges (merged where adjacent). '''
+            flat ranges (merged where adjacent).  rng = (offset, numel): only the parameters inside that slice of the flat buffer
+            (a gradient bucket of the data-parallel reducer; slices end on parameter boundaries). '''
         if not self._packed:
             return None
-        if self._adam_table is None:
+        if rng not in self._adam_table:
             W, gemm = self._packed, set(self._gemm_weights)
             weights, flats = [], []
+            lo, hi = (0, self._flat.numel()) if rng is None else (rng[0], rng[0] + rng[1])
             for name, shape, _ in self._table:
                 off, n = self._offsets[name]
+                if off < lo or off >= hi:
+                    continue
+                assert off + n <= hi, f'{name} straddles the end of the slice'
                 if name in gemm:
                     taps = shape[2] if len(shape) == 3 else 1
                     weights.append((off, (shape[0], shape[1], taps), W.get(name), W.get('T:' + name), W.get('F:' + name), W.get('FT:' + name)))
@@ -402,8 +407,8 @@ class DaftExprt(nn.Module):
                     flats[-1] = (flats[-1][0], flats[-1][1] + n)
                 else:
                     flats.append((off, n))
-            self._adam_table = ops.adam_pack_table(weights, flats, self._flat.device)
-        return self._adam_table
+            self._adam_table[rng] = ops.adam_pack_table(weights, flats, self._flat.device) if weights else None
+        return self._adam_table[rng]
 
     def packs_are_current(self):
         ''' the optimizer has just refreshed EVERY operand copy together with the parameters (`ops.adam_pack_step`) '''
@@ -940,22 +945,29 @@ class DaftExprt(nn.Module):
             self._trace_bwd.append(('conv_ln', s, None, dy.clone(), dx.clone()))
         return dx
 
+    def ensure_side_stream(self):
+        ''' the weight-gradient stream (created once, with the launch stream of the first backward pass current) '''
+        if self._side is None:
+            # DX_WGRAD_PRIO: stream priority of the weight-gradient stream (default: the runtime's default; 'low' = the lowest the device
+            # offers, so that the dispatcher prefers the data-gradient chain whenever both streams have workgroups waiting)
+            prio = __import__('os').environ.get('DX_WGRAD_PRIO', '')
+            lo = None
+            if prio == 'low':
+                lo, _hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, 'priority_range') else (0, 0)
+            # a stream on ANOTHER hardware queue than the launch stream (probed, `streams.pick`: after RCCL has taken its streams from
+            # torch's pool the next pool stream can share the launch stream's queue, and the weight gradients would run in line)
+            self._side = streams.pick([torch.cuda.current_stream()], priority=lo, what='weight-gradient stream')
+            self._hop = torch.cuda.Event()
+        return self._side
+
     def _backward(self, S, d_spk, d_dur, d_energy, d_pitch, d_mel, d_mel_is_bt=False, section_done=None):
         ''' hand-written backward pass: accumulates every parameter gradient into the flat gradient buffer.
             d_mel: (B, n_mel, T) like the output, or (B, T, n_mel) when d_mel_is_bt.
             section_done(name): called as soon as every gradient of a top-level module is final, in reverse
             registration order (frame_decoder first) -- the data-parallel reducer launches that slice's all-reduce. '''
         use_side = bool(int(__import__('os').environ.get('DX_WGRAD_SIDE_STREAM', '1')))
-        if use_side and self._side is None:
-            # DX_WGRAD_PRIO: stream priority of the weight-gradient stream (default: the runtime's default; 'low' = the lowest the device
-            # offers, so that the dispatcher prefers the data-gradient chain whenever both streams have workgroups waiting)
-            prio = __import__('os').environ.get('DX_WGRAD_PRIO', '')
-            if prio == 'low':
-                lo, _hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, 'priority_range') else (0, 0)
-                self._side = torch.cuda.Stream(device=S.enc_out.device, priority=lo)
-            else:
-                self._side = torch.cuda.Stream(device=S.enc_out.device)
-            self._hop = torch.cuda.Event()
+        if use_side:
+            self.ensure_side_stream()
         self._side_stream = self._side if use_side else None
 
         def done(name, last=False):

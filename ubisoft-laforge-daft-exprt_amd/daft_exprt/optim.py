@@ -60,16 +60,27 @@ class FusedAdam(object):
 
     def begin_step(self):
         self.step_count += 1
+        self._all_packed, self._covered = True, 0
         ops.H.check(ops.H.lib().dx_fill_zero(ops.H.ptr(self.grad_norm_sq), 4, ops.H.stream()))
 
     def step_slice(self, off, n):
         g = self.param_groups[0]
         flat, gflat = self.model.flat_parameters(), self.model.flat_gradients()
+        table = self.model.adam_pack_table((off, n)) if (self.fuse_pack and flat.is_cuda) else None
+        self._covered += n
+        if table is not None:      # the slice's Adam + the refresh of the operand copies of the GEMM weights inside it, one launch
+            ops.adam_pack_step(flat, gflat, self.exp_avg, self.exp_avg_sq, table, self.model.cd, g['lr'], g['betas'], g['eps'],
+                               g['weight_decay'], self.step_count, norm_accum=self.grad_norm_sq)
+            return
+        if not (self.fuse_pack and flat.is_cuda and self.model._packed):   # (a slice WITHOUT GEMM weights has no copies to refresh)
+            self._all_packed = False
         ops.adam_step(flat[off: off + n], gflat[off: off + n], self.exp_avg[off: off + n], self.exp_avg_sq[off: off + n], g['lr'],
                       g['betas'], g['eps'], g['weight_decay'], self.step_count, None, float('inf'), norm_accum=self.grad_norm_sq)
 
     def end_step(self):
         self.model.mark_updated()
+        if self._all_packed and self._covered == self.model.flat_parameters().numel():
+            self.model.packs_are_current()
         return self.grad_norm_sq
 
     def zero_grad(self, set_to_none=False):

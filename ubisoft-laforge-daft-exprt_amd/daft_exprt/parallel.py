@@ -17,6 +17,8 @@ What this build does instead, with the same mathematics (sum of per-rank mean gr
 xGMI is point-to-point (7 links per GPU): a few large messages per step (3.4-30 MB) keep every link busy;
 tiny sections are merged with their neighbour so that nothing below ~1 MB goes out on its own.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -25,6 +27,10 @@ class GradReducer(object):
     def __init__(self, model, process_group=None, min_bucket_elems=1 << 18):
         self.model, self.group = model, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # the collectives are issued when there is more than one rank -- or, with DX_FORCE_DIST=1, also inside a ONE-rank process group:
+        # a 1-GPU box can then drive the complete multi-rank code path (RCCL communicator, asynchronous all-reduce per bucket,
+        # stream-ordered `work.wait()`, per-bucket Adam) on real RCCL (tests/test_gpu_ddp.py)
+        self.active = dist.is_initialized() and (self.world > 1 or os.environ.get('DX_FORCE_DIST', '0') == '1')
         slices = model.section_slices()
         # buckets in backward order (reverse registration order); merge small sections into the next one
         order = [s for s in reversed(model.SECTIONS) if s in slices]
@@ -42,9 +48,34 @@ class GradReducer(object):
         self._ready_after = {sec: (off, n) for sec, off, n in self.buckets}
         self._works = []
 
+    def pick_group(self, beside, tries=4):
+        ''' make sure the collectives of this reducer execute BESIDE the streams in `beside` (launch stream, weight-gradient stream).
+            A process group launches on a stream of its own, taken from torch's pool when its communicator is built; if that stream
+            shares a hardware queue with the launch stream, every all-reduce would sit in line with the backward kernels instead of
+            under them.  The probe is `streams.collective_runs_beside`; a group that fails it is replaced by a NEW group over the same
+            ranks (new communicator, next pool stream), at most `tries` times.  All ranks take the same decisions (MIN over ranks).
+            RCCL ("nccl") only; collective over all ranks. '''
+        from daft_exprt import streams
+        self.queue_probe = None
+        if not self.active or dist.get_backend(self.group) != 'nccl' or os.environ.get('DX_STREAM_PROBE', '1') == '0':
+            return None
+        dev = beside[0].device
+        group = self.group
+        for attempt in range(tries):
+            ok = all([streams.collective_runs_beside(b, group) for b in beside])
+            flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()):
+                self.group, self.queue_probe = group, f'own hardware queue (group {attempt + 1})'
+                return True
+            if attempt + 1 < tries:
+                group = dist.new_group(backend='nccl')
+        self.group, self.queue_probe = group, f'SHARES a hardware queue with the launch or weight-gradient stream after {tries} groups'
+        return False
+
     def broadcast_parameters(self, src=0):
         ''' rank-0 parameters to everyone, once (DDP constructor semantics, train.py:293) '''
-        if self.world > 1:
+        if self.active:
             dist.broadcast(self.model.flat_parameters(), src=src, group=self.group)
             self.model.mark_updated()
 
@@ -54,7 +85,7 @@ class GradReducer(object):
         if name not in self._ready_after:
             return None
         off, n = self._ready_after[name]
-        if self.world == 1:
+        if not self.active:
             return off, n, None
         g = self.model.flat_gradients()[off: off + n]
         work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -65,7 +96,9 @@ class GradReducer(object):
         ''' one line for the rank-0 log: world size, backend and the bucket sizes in backward order '''
         backend = dist.get_backend(self.group) if dist.is_initialized() else 'none'
         sizes = ', '.join(f'{sec} {n * 4 / 1e6:.1f} MB' for sec, _, n in self.buckets)
-        return f'gradient all-reduce: world {self.world}, backend {backend}, {len(self.buckets)} buckets in backward order: {sizes}'
+        probe = getattr(self, 'queue_probe', None)
+        return f'gradient all-reduce: world {self.world}, backend {backend}, {len(self.buckets)} buckets in backward order: {sizes}' + \
+            (f'; collectives on their {probe}' if probe else '')
 
     def wait(self):
         for w in self._works:
@@ -74,5 +107,5 @@ class GradReducer(object):
 
     def all_reduce_now(self):
         ''' non-overlapped variant (used when gradients were produced through the autograd bridge) '''
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(self.model.flat_gradients(), op=dist.ReduceOp.SUM, group=self.group)

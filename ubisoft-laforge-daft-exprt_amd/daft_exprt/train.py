@@ -32,7 +32,7 @@ from daft_exprt.data_loader import DaftExprtDataCollate, SyntheticUtterances, pr
 from daft_exprt.hparams import HyperParams
 from daft_exprt.loss import DaftExprtLoss, KEYS
 from daft_exprt.model import DaftExprt
-from daft_exprt import ops
+from daft_exprt import ops, streams
 from daft_exprt.optim import FusedAdam
 from daft_exprt.parallel import GradReducer
 
@@ -106,7 +106,10 @@ class Trainer(object):
         self.optimizer = FusedAdam(model, betas=hparams.betas, eps=hparams.epsilon, weight_decay=hparams.weight_decay,
                                    grad_clip_thresh=hparams.grad_clip_thresh)
         self.reducer = GradReducer(model)     # also on one rank: its bucket table drives the per-section optimizer
-        if world_size > 1:
+        if self.reducer.active:
+            if model.flat_parameters().is_cuda and int(os.environ.get('DX_WGRAD_SIDE_STREAM', '1')):
+                # launch stream, weight-gradient stream and RCCL's stream on three different hardware queues (probed, `streams.py`)
+                self.reducer.pick_group([torch.cuda.current_stream(), model.ensure_side_stream()])
             self.reducer.broadcast_parameters()
         model.always_repack = False   # parameters only change through self.optimizer
         self.terms = None
@@ -118,7 +121,7 @@ class Trainer(object):
         # the per-bucket update orders itself behind the collective through `work.wait()`, which is a STREAM wait only with RCCL
         # (backend "nccl"); gloo's wait blocks the host inside the backward hook and would stall kernel issue for the rest of the
         # backward pass, so any other backend keeps the whole-buffer step
-        stream_ordered = world_size > 1 and dist.is_initialized() and dist.get_backend() == 'nccl' and \
+        stream_ordered = self.reducer.active and dist.get_backend() == 'nccl' and \
             not int(os.environ.get('TORCH_NCCL_BLOCKING_WAIT', '0') or 0)
         self.sectioned = stream_ordered if mode == 'auto' else bool(int(mode))
         self._opt_stream = self._sec_event = None
@@ -131,7 +134,7 @@ class Trainer(object):
         # side whether the host or the graph executor feeds them, and at these sizes the host keeps ahead of the device.  It wins below
         # (3.88 vs 4.05 ms at B = 8).
         use_graph = os.environ.get('DX_STEP_GRAPH', '0')
-        self.captured = CapturedStep(self, auto=(use_graph == 'auto')) if (world_size == 1 and use_graph != '0' and
+        self.captured = CapturedStep(self, auto=(use_graph == 'auto')) if (not self.reducer.active and use_graph != '0' and
                                                                            model.flat_parameters().is_cuda) else None
 
     def _section_done(self, name):
@@ -155,7 +158,7 @@ class Trainer(object):
             Returns (terms (8,) device tensor summed over micro-batches / accumulation_steps, grad_norm_sq device scalar).
             The tensors may live in buffers a later call overwrites (captured steps reuse theirs): consume them -- or enqueue the
             copy that does -- before the next call. '''
-        if self.captured is not None and self.world == 1 and not self.sectioned:
+        if self.captured is not None and not self.reducer.active and not self.sectioned:
             return self.captured.step(micro_batches, iteration)
         return self.step_eager(micro_batches, iteration)
 
@@ -170,13 +173,16 @@ class Trainer(object):
         self._sectioned_now = self.sectioned and self.optimizer.sectioned()
         if self._sectioned_now:
             if self._opt_stream is None:
-                self._opt_stream, self._sec_event = torch.cuda.Stream(device=model.flat_parameters().device), torch.cuda.Event()
+                # on hardware queues of their own (probed): beside the launch stream and the weight-gradient stream
+                side = model.ensure_side_stream() if int(os.environ.get('DX_WGRAD_SIDE_STREAM', '1')) else None
+                beside = [torch.cuda.current_stream()] + ([side] if side is not None else [])
+                self._opt_stream, self._sec_event = streams.pick(beside, what='optimizer stream'), torch.cuda.Event()
             self.optimizer.begin_step()     # step count, zeroed norm accumulator: on the compute stream, ahead of every slice update
             self._done = set()
         total = None
         for k, (inputs, targets) in enumerate(micro_batches):
             last = k == accum - 1
-            hook = self._section_done if (last and (self.world > 1 or self._sectioned_now)) else None
+            hook = self._section_done if (last and (self.reducer.active or self._sectioned_now)) else None
             terms = model.forward_backward(inputs, targets, weights, grad_scale=scale, section_done=hook)
             total = terms if total is None else ops.add_(total, terms)
         main = torch.cuda.current_stream()
