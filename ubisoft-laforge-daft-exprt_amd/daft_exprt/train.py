@@ -411,7 +411,8 @@ def train(gpu, hparams, log_file):
     # reference's per-iteration `dist.barrier()` (it only paces the ranks' log output) and the round-1 NaN all-reduce are gone:
     # nothing in the step depends on them, and the gradient all-reduce already keeps the ranks in lockstep.
     stats_host = torch.empty(9, dtype=torch.float32).pin_memory()
-    log_stream, stats_ready, step_done = torch.cuda.Stream(device=gpu), torch.cuda.Event(), torch.cuda.Event()
+    # (both helper streams on hardware queues other than the launch stream's: probed, `streams.pick`)
+    log_stream, stats_ready, step_done = streams.pick([torch.cuda.current_stream(gpu)], what='log stream'), torch.cuda.Event(), torch.cuda.Event()
     pending = None        # (iteration, lr, valid frames) of the step whose scalars are in flight
 
     def report(now):
@@ -439,7 +440,7 @@ def train(gpu, hparams, log_file):
                 f.write(json.dumps(rec) + '\n')
         return True
 
-    copy_stream = torch.cuda.Stream(device=gpu)
+    copy_stream = streams.pick([torch.cuda.current_stream(gpu)], what='copy stream')
 
     def device_batches():
         ''' the loader's batches one ahead of the step that consumes them: the H2D copies of batch i + 1 (15.8 MB at B = 48) run on
