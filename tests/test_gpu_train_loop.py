@@ -13,10 +13,15 @@ pytestmark = pytest.mark.gpu
 from tests.util import make_hparams
 
 
-@pytest.mark.parametrize('ddp_flag', [False, True])
-def test_train_from_feature_files_then_checkpoint_and_synthesis(golden_dir, tmp_path, ddp_flag):
+@pytest.mark.parametrize('ddp_flag', [False, True, 'collectives'])
+def test_train_from_feature_files_then_checkpoint_and_synthesis(golden_dir, tmp_path, ddp_flag, monkeypatch):
     ''' ddp_flag=True is the default launch path of scripts/training.py on a 1-GPU node: `--multiprocessing_distributed`
-        with world_size 1 -- process group of one rank, DistributedSampler, `module.`-prefixed checkpoints '''
+        with world_size 1 -- process group of one rank, DistributedSampler, `module.`-prefixed checkpoints;
+        'collectives': the same with DX_FORCE_DIST=1 -- the one-rank RCCL world issues every collective of the multi-rank loop
+        (per-bucket all-reduce from the backward hooks, per-bucket Adam, validation reduction) '''
+    if ddp_flag == 'collectives':
+        monkeypatch.setenv('DX_FORCE_DIST', '1')
+        ddp_flag = True
     from daft_exprt.generate import generate_mel_specs
     from daft_exprt.model import DaftExprt
     from daft_exprt.train import train
