@@ -133,11 +133,18 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
 #define DX_RING_ABL 0   // compile-time ablation (development): 1 no fragment reads / MFMAs, 2 no loads, 4 no activation pieces, 8 no weight pieces
 #endif
 // RING: 0 = register-staged single-buffer pipeline; S >= 2 = S-stage LDS ring filled by four loader waves (512 threads, bf16)
+#ifndef CG_K1_PF
+#define CG_K1_PF 1   // chunks in flight of the register-staged k = 1 GEMMs (2: measured +-0, 29.8 vs 30.5 us / 20.2 vs 19.6 us: the chunk period is its barrier / LDS chain, not the global round trip)
+#endif
 #ifdef CG_TIMING
 __device__ unsigned long long dx_cg_wg[1024 * 4];   // [workgroup]{start, main loop start, main loop end, end}, s_memrealtime ticks; ring kernels with LNM == CG_TIMING
 __device__ unsigned long long dx_cg_chunk[2 * 64 * 4];   // workgroup 40, loader wave 0 / MFMA wave 0: per chunk {before wait, after wait, after barrier, after issue / MFMAs} (s_memtime)
 #define CG_CHUNK(who, k, i) do { if (LNM == CG_TIMING && RING && blockIdx.x == 40 && lane == 0 && (k) < 64) dx_cg_chunk[((who) * 64 + (k)) * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifdef CG_TIMING_K1   // the register-staged k = 1 instantiations instead of the ring kernels (tools/cg_timing_k1.py)
+#define CG_STAMP(i) do { if (LNM == CG_TIMING && !RING && TAPS == 1 && tid == 0) dx_cg_wg[(blockIdx.x & 1023) * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
 #define CG_STAMP(i) do { if (LNM == CG_TIMING && RING && tid == 0) dx_cg_wg[(blockIdx.x & 1023) * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#endif
 #else
 #define CG_STAMP(i)
 #define CG_CHUNK(who, k, i)
@@ -435,17 +442,22 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
     }
     __syncthreads();                                 // every MFMA wave is done with the ring: the epilogue stages through it
   } else {
-  raw_t ra[A_PT];
-    frag_t rw[W_PT];
-    auto fetch = [&](int k0) {
+  // register-staged pipeline.  CG_K1_PF = 2 keeps TWO chunks of the k = 1 GEMMs in flight in two static register sets: no gain (see the
+    // macro) -- their chunk loop (0.74 us per chunk, tools/cg_timing_k1.py: 8.9 us of an 18 us QKV data gradient, 3.6 us of a 14 us
+    // out-projection + LayerNorm whose epilogue runs at 5 TB/s) is bound by its two barriers and the LDS round trip per chunk
+    constexpr int PF = TAPS == 1 ? CG_K1_PF : 1;
+    raw_t ra[PF][A_PT];
+    frag_t rw[PF][W_PT];
+    auto fetch = [&](auto slot, int k0) {
+      constexpr int S = decltype(slot)::value;
 #pragma unroll
       for (int t = 0; t < A_PT; ++t) {
         const int c = tid + t * NTHREADS;
         const int r = c / KC, kc = (c % KC) * 8;
         const int n = n0 + r - HALO, ci = k0 + kc;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ra[t][e] = (TA)0.f;
-        if (c < A_CH && n >= 0 && n < N && ci < Cin) ra[t] = raw_load8<TA>(X + (size_t)n * p.ldx + ci);
+        for (int e = 0; e < 8; ++e) ra[S][t][e] = (TA)0.f;
+        if (c < A_CH && n >= 0 && n < N && ci < Cin) ra[S][t] = raw_load8<TA>(X + (size_t)n * p.ldx + ci);
       }
 #pragma unroll
       for (int t = 0; t < W_PT; ++t) {
@@ -453,30 +465,25 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
         const int tap = c / (BN * KC), rem = c - tap * (BN * KC);
         const int row = rem / KC, kc = (rem % KC) * 8;
         const int co = co0 + row, ci = k0 + kc;
-        rw[t] = zero8<TC>();
-        if (co < Cout && ci < Cin) rw[t] = *reinterpret_cast<const frag_t*>(W + ((size_t)tap * Cout + co) * Cin + ci);
+        rw[S][t] = zero8<TC>();
+        if (co < Cout && ci < Cin) rw[S][t] = *reinterpret_cast<const frag_t*>(W + ((size_t)tap * Cout + co) * Cin + ci);
       }
     };
-    auto commit = [&]() {
+    auto commit = [&](auto slot) {
+      constexpr int S = decltype(slot)::value;
 #pragma unroll
       for (int t = 0; t < A_PT; ++t) {
         const int c = tid + t * NTHREADS;
-        if (c < A_CH) *reinterpret_cast<frag_t*>(&As[lds_at(c / KC, c % KC)]) = cvt8<TA, TC>(ra[t]);
+        if (c < A_CH) *reinterpret_cast<frag_t*>(&As[lds_at(c / KC, c % KC)]) = cvt8<TA, TC>(ra[S][t]);
       }
 #pragma unroll
       for (int t = 0; t < W_PT; ++t) {
         const int c = tid + t * NTHREADS;
         const int tap = c / (BN * KC), rem = c - tap * (BN * KC);
-        *reinterpret_cast<frag_t*>(&Ws[lds_at(tap * BN + rem / KC, rem % KC)]) = rw[t];
+        *reinterpret_cast<frag_t*>(&Ws[lds_at(tap * BN + rem / KC, rem % KC)]) = rw[S][t];
       }
     };
-  
-    fetch(0);
-    commit();
-    __syncthreads();
-    for (int k0 = 0; k0 < Cin; k0 += BK) {
-      const bool more = k0 + BK < Cin;
-      if (more) fetch(k0 + BK);
+    auto compute = [&]() {
 #pragma unroll
       for (int tap = 0; tap < TAPS; ++tap) {
 #pragma unroll
@@ -494,12 +501,45 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
             for (int j = 0; j < 2; ++j) dx_mma(acc[i][j], a[i], bf[j]);
         }
       }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, PF - 1>;
+
+    CG_STAMP(1);
+    fetch(S0{}, 0);
+    if constexpr (PF == 2) {
+      if (BK < Cin) fetch(S1{}, BK);
+      commit(S0{});
       __syncthreads();
-      if (more) {
-        commit();
+      // chunk k0 is in LDS, chunk k0 + BK in the registers of the other set, chunk k0 + 2 BK is requested into the set just committed
+      auto step = [&](auto cur, auto nxt, int k0) {
+        if (k0 + 2 * BK < Cin) fetch(cur, k0 + 2 * BK);
+        compute();
         __syncthreads();
+        if (k0 + BK < Cin) {
+          commit(nxt);
+          __syncthreads();
+        }
+      };
+      for (int k0 = 0; k0 < Cin; k0 += 2 * BK) {
+        step(S0{}, S1{}, k0);
+        if (k0 + BK < Cin) step(S1{}, S0{}, k0 + BK);
+      }
+    } else {
+      commit(S0{});
+      __syncthreads();
+      for (int k0 = 0; k0 < Cin; k0 += BK) {
+        const bool more = k0 + BK < Cin;
+        if (more) fetch(S0{}, k0 + BK);
+        compute();
+        __syncthreads();
+        if (more) {
+          commit(S0{});
+          __syncthreads();
+        }
       }
     }
+    CG_STAMP(2);
   }
 
   // ---- epilogue
