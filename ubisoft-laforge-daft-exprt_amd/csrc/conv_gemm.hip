@@ -133,6 +133,9 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
 #define DX_RING_ABL 0   // compile-time ablation (development): 1 no fragment reads / MFMAs, 2 no loads, 4 no activation pieces, 8 no weight pieces
 #endif
 // RING: 0 = register-staged single-buffer pipeline; S >= 2 = S-stage LDS ring filled by four loader waves (512 threads, bf16)
+#ifndef CG_K1_BK
+#define CG_K1_BK 32   // K chunk of the LayerNorm-fused k = 1 GEMMs (64: A/B build; the operand image stays below the epilogue stage)
+#endif
 #ifndef CG_K1_PF
 #define CG_K1_PF 1   // chunks in flight of the register-staged k = 1 GEMMs (2: measured +-0, 29.8 vs 30.5 us / 20.2 vs 19.6 us: the chunk period is its barrier / LDS chain, not the global round trip)
 #endif
@@ -1938,8 +1941,8 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
     const long ptiles = (long)dx_cdiv(a.N, 64) * B;
     dim3 grid((unsigned)(((ptiles + 7) / 8) * 8)), block(NTHREADS);
     if (taps == 1) {
-      if (film) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 1, 32, LN>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 1, 32, LNB>), grid, block, 0, s, a);
+      if (film) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 1, CG_K1_BK, LN>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 1, 1, CG_K1_BK, LNB>), grid, block, 0, s, a);
     } else {
       if (film) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 1, 32, LN>), grid, block, 0, s, a);
       else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 1, 32, LNB>), grid, block, 0, s, a);
