@@ -585,6 +585,18 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
       constexpr bool PFB = !(LNFILM && MI != 2);     // FiLM-gradient variants at the 128 / 256 register caps: loads stay in their pass
       f32x8 pf_a[4], pf_b[4];
       float pf_m[4], pf_r[4];
+      // the per-channel operands of the row passes (gamma, beta, FiLM row of this utterance) depend on the thread's channel segment
+      // only: requested once per slab in front of the barrier.  Inside the passes every one of them sat behind the stores of the
+      // pass before -- y / s_out may alias them as far as the compiler knows -- one exposed L2 round trip per pass (conv_sk_kernel:
+      // 8.9 -> 7.3 us of epilogue).  Not for the variants at their register caps (PFB).
+      const int cl_h = (etid & 15) * 8;
+      f32x8 gm_h, bt_h, fg_h, fb_h;
+      if (LN != 0 && PFB) {
+        gm_h = raw_load8<float>(p.ln.gamma + cl_h);
+        if (LN == 1 || LNFILM) bt_h = raw_load8<float>(p.ln.beta + cl_h);
+        if (p.ln.film && (LN == 1 || LNFILM)) fg_h = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + cl_h);
+        if (p.ln.film && LN == 1) fb_h = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + BN + cl_h);
+      }
       if (LN != 0 && PFB) {
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
@@ -625,12 +637,12 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
             }
             const f32x8 sv = PFB ? pf_b[pass] : raw_load8<float>(p.ln.s_out + offl);
             const float mean = PFB ? pf_m[pass] : p.ln.mean[rowg], rstd = PFB ? pf_r[pass] : p.ln.rstd[rowg];
-            const f32x8 gm = raw_load8<float>(p.ln.gamma + cl);
+            const f32x8 gm = PFB ? gm_h : raw_load8<float>(p.ln.gamma + cl);
             float xh[8], s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) xh[e] = (sv[e] - mean) * rstd;
             if (LNFILM) {                                         // y = fg * LN + fb
-              const f32x8 fg = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + cl), bt = raw_load8<float>(p.ln.beta + cl);
+              const f32x8 fg = PFB ? fg_h : raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + cl), bt = PFB ? bt_h : raw_load8<float>(p.ln.beta + cl);
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
                 csum[LNFILM ? 2 : 0][e] += v[e] * (xh[e] * gm[e] + bt[e]);
@@ -688,11 +700,11 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
             for (int o = 1; o < 16; o <<= 1) sq += __shfl_xor(sq, o, 64);
             const float rstd = rsqrtf(sq * (1.f / BN) + 1e-5f);
             if (p.ln.mean && cl == 0) { p.ln.mean[rowg] = mean; p.ln.rstd[rowg] = rstd; }
-            const f32x8 gm = raw_load8<float>(p.ln.gamma + cl), bt = raw_load8<float>(p.ln.beta + cl);
+            const f32x8 gm = gm_h, bt = bt_h;                      // (LN == 1: PFB is always true)
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * gm[e] + bt[e];
             if (p.ln.film) {
-              const f32x8 fg = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + cl), fb = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + BN + cl);
+              const f32x8 fg = fg_h, fb = fb_h;
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = fg[e] * v[e] + fb[e];
             }
@@ -1401,6 +1413,15 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
           for (int ks = 0; ks < 8; ++ks) w2f[c][ks] = *reinterpret_cast<const frag_t*>(w2 + ks * 16);
         }
     }
+    // the per-channel operands of the row passes depend on (b, channel segment) only: loaded ONCE here.  Inside the passes they sat
+    // behind the stores of the pass before (the compiler cannot prove that y / s_out do not alias gamma / beta / film), one exposed
+    // L2 round trip per pass and slab
+    const int cl_h = (tid & 15) * 8;
+    const f32x8 gm_h = raw_load8<float>(p.ln.gamma + cl_h);
+    f32x8 bt_h = gm_h, fg_h = gm_h, fb_h = gm_h;
+    if (LN == 1 || LNFILM) bt_h = raw_load8<float>(p.ln.beta + cl_h);
+    if (p.ln.film && (LN == 1 || LNFILM)) fg_h = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + cl_h);
+    if (p.ln.film && LN == 1) fb_h = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + BN + cl_h);
 #pragma unroll
     for (int i = 0; i < MAXBLK / 2; ++i) {
       if (i * 64 >= h) break;                          // workgroup-uniform: the barriers below stay matched
@@ -1445,12 +1466,12 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
             }
             const f32x8 sv = pf_b[pass];
             const float mean = pf_m[pass], rstd = pf_r[pass];
-            const f32x8 gm = raw_load8<float>(p.ln.gamma + cl);
+            const f32x8 gm = gm_h;
             float xh[8], s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int e2 = 0; e2 < 8; ++e2) xh[e2] = (sv[e2] - mean) * rstd;
             if (LNFILM) {                                         // y = fg * LN + fb
-              const f32x8 fg = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + cl), bt = raw_load8<float>(p.ln.beta + cl);
+              const f32x8 fg = fg_h, bt = bt_h;
 #pragma unroll
               for (int e2 = 0; e2 < 8; ++e2) {
                 csum[LNFILM ? 2 : 0][e2] += v[e2] * (xh[e2] * gm[e2] + bt[e2]);
@@ -1506,11 +1527,11 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
             for (int o = 1; o < 16; o <<= 1) sq += __shfl_xor(sq, o, 64);
             const float rstd = rsqrtf(sq * (1.f / BN) + 1e-5f);
             if (p.ln.mean && cl == 0) { p.ln.mean[rowg] = mean; p.ln.rstd[rowg] = rstd; }
-            const f32x8 gm = raw_load8<float>(p.ln.gamma + cl), bt = raw_load8<float>(p.ln.beta + cl);
+            const f32x8 gm = gm_h, bt = bt_h;
 #pragma unroll
             for (int e2 = 0; e2 < 8; ++e2) v[e2] = (v[e2] - mean) * rstd * gm[e2] + bt[e2];
             if (p.ln.film) {
-              const f32x8 fg = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + cl), fb = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + BN + cl);
+              const f32x8 fg = fg_h, fb = fb_h;
 #pragma unroll
               for (int e2 = 0; e2 < 8; ++e2) v[e2] = fg[e2] * v[e2] + fb[e2];
             }
@@ -1533,6 +1554,12 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
         for (int c = 0; c < NC2; ++c) {
           if (c >= ncb2) break;
           const int co2 = (c * 4 + wave) * 32 + 4 * g;            // this lane's channels: co2 + 8 j + 0..3
+          f32x4 bj4[4];                                           // bias of this lane's channels: requested in front of the MFMAs
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            bj4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.ln.b2) bj4[j] = *reinterpret_cast<const f32x4*>(p.ln.b2 + co2 + 8 * j);
+          }
 #pragma unroll
           for (int rb = 0; rb < 2; ++rb) {
             f32x16 d2;
@@ -1548,8 +1575,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
               TC* yo = reinterpret_cast<TC*>(p.ln.y2) + ((size_t)b * N + n) * n2 + co2;
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                f32x4 bj = {0.f, 0.f, 0.f, 0.f};
-                if (p.ln.b2) bj = *reinterpret_cast<const f32x4*>(p.ln.b2 + co2 + 8 * j);
+                const f32x4 bj = bj4[j];
                 bf16x4 o4;
 #pragma unroll
                 for (int e2 = 0; e2 < 4; ++e2) o4[e2] = (TC)(d2[4 * j + e2] + bj[e2]);
