@@ -185,6 +185,14 @@ __global__ __launch_bounds__(256, C >= 1024 ? (FILM ? 1 : ((sizeof(TI) == 4 || s
   constexpr bool REG_PARAMS = C <= 256;
   constexpr int NRED = FILM ? 4 : 2;
   __shared__ float red[4][NRED][C];  // [wave][dgamma, dbeta (, dfilm_g, dfilm_b)][C]
+  // C = 1024: gamma / beta live in LDS, not in 32 registers and not re-read from global per row: vector memory returns in order, so a
+  // global re-read issued behind fetch_row(n + 4) or behind the row's stores waits for them; LDS reads count separately (lgkmcnt).
+  // (Measured: 55-57 vs 56-60 us alone, ~-0.01 ms per step: the compiler had already moved most of those re-reads up.)
+  __shared__ float par_s[REG_PARAMS ? 1 : 2 * C];
+  if (!REG_PARAMS) {
+    for (int i = threadIdx.x; i < 2 * C; i += 256) par_s[i] = i < C ? a.gamma[i] : a.beta[i - C];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
   const int n_begin = blockIdx.x * a.rows_per_block;
@@ -263,8 +271,8 @@ __global__ __launch_bounds__(256, C >= 1024 ? (FILM ? 1 : ((sizeof(TI) == 4 || s
     for (int k = 0; k < L::NV; ++k) {
       float gk[L::V], bk[L::V];
       if (!REG_PARAMS) {
-        load_vec<float, L::V>(a.gamma + L::col(lane, k), gk);
-        load_vec<float, L::V>(a.beta + L::col(lane, k), bk);
+#pragma unroll
+        for (int i = 0; i < L::V; ++i) { gk[i] = par_s[L::col(lane, k) + i]; bk[i] = par_s[(REG_PARAMS ? 0 : C) + L::col(lane, k) + i]; }
       }
 #pragma unroll
       for (int i = 0; i < L::V; ++i) {
