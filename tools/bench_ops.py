@@ -191,7 +191,8 @@ def bench_lnbwd():
     w1 = ops.pack_conv_weight(torch.randn(128, 384, 1, device=dev) / 384 ** 0.5, torch.bfloat16)
     t2 = timeit(lambda: ops.conv1d_lnbwd(x1, w1, y, s_in, mean, rstd, g, bt, lens, dg, db, p_pre=0.1, seed_pre=3))
     t3 = timeit(lambda: ops.conv1d(x1, w1, None, out_dtype=torch.float32, skip_lengths=lens))
-    print(f'lnbwd-fused data gradient 384->128 k1: {t2 * 1e3:6.1f} us | plain conv 384->128 (fp32 out) {t3 * 1e3:6.1f} us')
+    t4 = timeit(lambda: ops.conv1d_lnbwd(x1, w1, y, s_in, mean, rstd, g, bt, lens, dg, db, film=film, dfilm=dfilm, p_pre=0.1, seed_pre=3))
+    print(f'lnbwd-fused data gradient 384->128 k1: {t2 * 1e3:6.1f} us | with FiLM gradients {t4 * 1e3:6.1f} us | plain conv 384->128 (fp32 out) {t3 * 1e3:6.1f} us')
 
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'lnbwd':
