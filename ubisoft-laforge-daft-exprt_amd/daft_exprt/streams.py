@@ -42,7 +42,8 @@ def pick(beside, device=None, priority=None, tries=12, what='stream'):
     ''' a new torch stream that runs beside every stream in `beside` (a list of torch streams).  Falls back to the last candidate
         (with a warning on stderr) when none of `tries` pool streams qualifies -- e.g. GPU_MAX_HW_QUEUES=1. '''
     device = beside[0].device if device is None else device
-    if os.environ.get('DX_STREAM_PROBE', '1') == '0':
+    capturing = getattr(torch.cuda, 'is_current_stream_capturing', lambda: False)()     # (a probe synchronises: never inside a capture)
+    if os.environ.get('DX_STREAM_PROBE', '1') == '0' or capturing:
         return torch.cuda.Stream(device=device) if priority is None else torch.cuda.Stream(device=device, priority=priority)
     cand = None
     for k in range(tries):
