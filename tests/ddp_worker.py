@@ -35,7 +35,15 @@ def main():
     torch.manual_seed(1000 + rank)                      # different initial weights per rank: the broadcast must win
     model = DaftExprt(hp).to(dev).train()
     model.set_rank(rank)
+    if os.environ.get('DDP_TEST_REGROUP'):
+        # the first process group "fails" the hardware-queue probe: GradReducer.pick_group must replace it by a fresh group
+        from daft_exprt import streams
+        real, calls = streams.collective_runs_beside, []
+        streams.collective_runs_beside = lambda busy, group=None, **kw: (calls.append(1), real(busy, group, **kw) if len(calls) > 2 else False)[1]
     trainer = Trainer(model, hp, world)                 # broadcasts rank 0's parameters
+    if os.environ.get('DDP_TEST_REGROUP'):
+        assert 'group 2' in (trainer.reducer.queue_probe or ''), trainer.reducer.queue_probe
+        assert trainer.reducer.group is not None and trainer.reducer.group is not dist.group.WORLD
     ref = None
     if rank == 0:
         torch.manual_seed(1000)

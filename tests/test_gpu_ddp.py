@@ -42,6 +42,12 @@ def test_one_rank_rccl_world_runs_the_multi_rank_path():
     _run('nccl', 1, DX_FORCE_DIST='1')
 
 
+def test_process_group_that_shares_the_launch_queue_is_replaced():
+    ''' `GradReducer.pick_group`: a group whose collectives do not run beside the launch / weight-gradient streams (probe forced to fail
+        once) is replaced by a NEW process group over the same ranks, and the whole equivalence check then runs on that group '''
+    _run('nccl', 1, DX_FORCE_DIST='1', DDP_TEST_REGROUP='1')
+
+
 def test_bench_line_through_a_one_rank_rccl_world():
     ''' bench.py's N > 1 branches (process group, barriers, max-over-ranks clock, summed frames) on a one-rank RCCL world '''
     import json
