@@ -1,11 +1,13 @@
 """Build libdaftexprt_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
 One object per source under csrc/ (compiled in parallel, rebuilt only when the source or a
-header is newer), linked into csrc/libdaftexprt_hip.so -- kept IN-TREE so that it travels to
-the GPU box with the repo snapshot.
+header is newer) written to build/obj[.<tag>]/ (git- and gpurun-ignored), linked into
+csrc/libdaftexprt_hip.so -- the library is kept IN-TREE so that it travels to the GPU box with
+the repo snapshot; the objects do not.
 
-A/B builds: `DX_BUILD_TAG=ldt40 DX_EXTRA_HIPCC_FLAGS=-DDX_FB_LDT=40 python build_hip.py` writes csrc/*.ldt40.o and
-csrc/libdaftexprt_hip.ldt40.so next to the default build; run with DX_HIP_LIB=<that .so>.
+A/B builds: `DX_BUILD_TAG=ldt40 DX_EXTRA_HIPCC_FLAGS=-DDX_FB_LDT=40 python build_hip.py` writes
+build/obj.ldt40/*.o and build/libdaftexprt_hip.ldt40.so (that one does travel: build/*.so is not
+gpurun-ignored); run with DX_HIP_LIB=<that .so>.
 """
 import os
 import subprocess
@@ -17,7 +19,9 @@ CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 TAG = os.environ.get('DX_BUILD_TAG', '')
 SUFFIX = f'.{TAG}' if TAG else ''
-LIB = os.path.join(CSRC, f'libdaftexprt_hip{SUFFIX}.so')
+BUILD = os.path.join(HERE, 'build')
+OBJDIR = os.path.join(BUILD, 'obj' + SUFFIX)
+LIB = os.path.join(BUILD if TAG else CSRC, f'libdaftexprt_hip{SUFFIX}.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-Wno-unused-result'] + \
     os.environ.get('DX_EXTRA_HIPCC_FLAGS', '').split()
@@ -34,7 +38,7 @@ def _headers_mtime():
 
 
 def _compile(src):
-    obj = os.path.join(CSRC, os.path.splitext(src)[0] + SUFFIX + '.o')
+    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + '.o')
     path = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), _headers_mtime()):
         return obj, False
@@ -47,6 +51,7 @@ def _compile(src):
 
 def build(verbose=True):
     srcs = _sources()
+    os.makedirs(OBJDIR, exist_ok=True)
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         results = list(ex.map(_compile, srcs))
     objs = [o for o, _ in results]
