@@ -323,17 +323,22 @@ def train_loop_bench(args, hp):
                       'roofline': None, 'cpu_baseline': None}))
 
 
-def secondary_train(dev, batch, accum, dtype, steps, warmup, pool=4):
+def secondary_train(dev, batch, accum, dtype, steps, warmup, pool=4, group=True):
     ''' a second timing of the SAME train step under another schedule / arithmetic, reported as an extra object of the default line:
         `batch` utterances per micro-batch x `accum` micro-batches per optimizer step (the reference's own default is 16 x 3,
         hparams.py:66-67, README.md:180), operands `dtype` (fp32 = the exact-parity mode on v_mfma_f32_32x32x2_f32, peak 157.3 TFLOP/s).
-        Same synthetic utterance statistics as the headline (T <= 1000, utterance 0 of every micro-batch pool entry = 1000 frames). '''
+        Same synthetic utterance statistics as the headline (T <= 1000, utterance 0 of every micro-batch pool entry = 1000 frames).
+        group (hparams.group_micro_batches, the default): the micro-batches of a step run as ONE pass over their concatenation, each
+        utterance keeping its own micro-batch's padded length as a hard sequence end (data_loader.GroupedBatch: the same gradients
+        as the separate passes, tests/test_gpu_grouped.py); the concatenation is input staging (train() does it on the host before
+        the H2D copy) and is done once per resident batch, outside the timed region like the H2D copy itself. '''
     from daft_exprt.data_loader import synthetic_batch
     from daft_exprt.hparams import HyperParams
     from daft_exprt.model import DaftExprt
     from daft_exprt.train import Trainer
     hp = HyperParams(verbose=False, training_files='none', validation_files='none', output_directory='/nonexistent_out',
-                     language='english', speakers=list(SPEAKERS), batch_size=batch, accumulation_steps=accum, compute_dtype=dtype)
+                     language='english', speakers=list(SPEAKERS), batch_size=batch, accumulation_steps=accum, compute_dtype=dtype,
+                     group_micro_batches=group)
     torch.manual_seed(hp.seed)
     model = DaftExprt(hp).to(dev).train()
     trainer = Trainer(model, hp, 1)
@@ -365,7 +370,7 @@ def secondary_train(dev, batch, accum, dtype, steps, warmup, pool=4):
     torch.cuda.empty_cache()
     return {'value': done_frames / elapsed, 'unit': 'mel-frames/s', 'ms_per_step': elapsed / steps * 1e3, 'steps': steps, 'warmup': warmup,
             'dtype': dtype, 'batch_size': batch, 'accumulation_steps': accum, 'utterances_per_optimizer_step': batch * accum,
-            'valid_frames_per_step': done_frames / steps,
+            'valid_frames_per_step': done_frames / steps, 'grouped_micro_batches': bool(group and accum > 1),
             'whole_step': {'achieved': done_flops / elapsed / 1e12, 'unit': 'TFLOP/s (algorithmic 3*F_fwd)', 'peak': peak / 1e12,
                            'frac': done_flops / elapsed / peak}}
 
@@ -546,6 +551,8 @@ def main():
             del trainer, model, batches
             torch.cuda.empty_cache()
             out['train_16x3'] = secondary_train(dev, 16, 3, 'bf16', steps=15, warmup=6)
+            seq = secondary_train(dev, 16, 3, 'bf16', steps=10, warmup=5, group=False)
+            out['train_16x3']['sequential_passes'] = {k: seq[k] for k in ('value', 'ms_per_step', 'whole_step')}
             out['fp32'] = secondary_train(dev, 48, 1, 'fp32', steps=6, warmup=4)
             sargs = argparse.Namespace(**vars(args))
             sargs.batch, sargs.steps, sargs.warmup, sargs.workload = 256, 10, 3, 'synth'

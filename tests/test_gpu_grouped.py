@@ -1,0 +1,142 @@
+"""Grouped micro-batches (`data_loader.GroupedBatch`, `Trainer.group`): the reference's accumulation schedule
+(`hparams.py:66-67` batch_size 16 x accumulation_steps 3, `train.py:379-401`) as ONE pass over the concatenated
+micro-batches.  The pass must equal the sequential passes: every utterance keeps the padded length of its OWN
+micro-batch as a hard sequence end (the reference pads each micro-batch to its own maxima, and the unmasked FF
+hidden / pre-net rows at the sequence end reach valid outputs, so the longest utterance of every micro-batch sees a
+different boundary than it would inside one big batch).
+
+  * fp32 operand mode, dropout off: predictions of every utterance against the sequential passes (bit-equal: same rows,
+    same summation order per output element), gradients to summation-order precision;
+  * control: the same concatenation WITHOUT the bounds is measurably different on the longest utterance of a shorter
+    micro-batch -- the bounds are what makes the schedule the reference's;
+  * bf16: agreement at the end-to-end bf16 bound (summation-order flips in front of a bf16 rounding, amplified by the stack);
+  * `Trainer.step`: one optimizer step grouped == one optimizer step over three passes."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+T_MAXES = (300, 221, 150)      # three micro-batches with different padded lengths; utterance 0 of each is forced to its T_max
+
+
+def _micro_batches(model, hp, dev, n=6):
+    from daft_exprt.data_loader import synthetic_batch
+    out = []
+    for k, t_max in enumerate(T_MAXES):
+        cb = synthetic_batch(hp, n, seed=77 + k, t_max=t_max, force_first_full=True, l_range=(20 + 10 * k, 60 + 10 * k))
+        inputs, targets, _ = model.parse_batch(dev, cb)
+        assert int(inputs[9].max()) == t_max == inputs[8].shape[2]
+        out.append((inputs, targets))
+    return out
+
+
+def _setup(dtype, n=6):
+    from tests.util import make_hparams, no_dropout
+    from daft_exprt.loss import DaftExprtLoss
+    from daft_exprt.model import DaftExprt
+    hp = no_dropout(make_hparams(batch_size=n, accumulation_steps=3, compute_dtype=dtype))
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    model = DaftExprt(hp).to(dev).train()
+    weights = DaftExprtLoss(dev, hp).weights(20000)
+    return hp, dev, model, weights, _micro_batches(model, hp, dev, n)
+
+
+def _sequential(model, mbs, weights):
+    model.zero_grad()
+    preds, total = [], None
+    for inputs, targets in mbs:
+        terms = model.forward_backward(inputs, targets, weights, grad_scale=1. / len(mbs))
+        logits, films, (dur, energy, pitch), mel, _ = model.last_outputs
+        preds.append([t.clone() for t in (mel, dur, energy, pitch, logits)])
+        total = terms.clone() if total is None else total + terms
+    torch.cuda.synchronize()
+    return preds, total / len(mbs), model._gflat.clone()
+
+
+def _grouped(model, mbs, weights, use_bounds=True):
+    from daft_exprt.data_loader import group_micro_batches
+    g = group_micro_batches(mbs)
+    model.zero_grad()
+    terms = model.forward_backward(g.inputs, g.targets, weights, grad_scale=1., bounds=g.bounds if use_bounds else None)
+    logits, films, (dur, energy, pitch), mel, _ = model.last_outputs
+    preds, row = [], 0
+    for (inputs, _), n in zip(mbs, g.sizes):
+        L, T = inputs[0].shape[1], inputs[8].shape[2]
+        sl = slice(row, row + n)
+        preds.append([mel[sl, :, :T].clone(), dur[sl, :L].clone(), energy[sl, :L].clone(), pitch[sl, :L].clone(), logits[sl].clone()])
+        # everything past an utterance's own micro-batch is padding of the group: exactly zero
+        assert float(mel[sl, :, T:].abs().max() if T < mel.shape[2] else 0.) == 0.
+        assert float(dur[sl, L:].abs().max() if L < dur.shape[1] else 0.) == 0.
+        row += n
+    torch.cuda.synchronize()
+    return preds, terms.clone(), model._gflat.clone()
+
+
+def _grads(model, flat):
+    out, off = {}, 0
+    for name, p in model.named_parameters():
+        out[name] = flat[off:off + p.numel()].view(p.shape).cpu()
+        off += p.numel()
+    return out
+
+
+def test_grouped_pass_equals_sequential_micro_batches_fp32():
+    from tests.util import gradient_report
+    hp, dev, model, weights, mbs = _setup('fp32')
+    p_seq, t_seq, g_seq = _sequential(model, mbs, weights)
+    p_grp, t_grp, g_grp = _grouped(model, mbs, weights)
+    names = ('mel', 'dur', 'energy', 'pitch', 'speaker logits')
+    for k, (a, b) in enumerate(zip(p_seq, p_grp)):
+        for nm, x, y in zip(names, a, b):
+            assert x.shape == y.shape
+            assert torch.equal(x, y), (f'micro-batch {k}: {nm} differs', float((x - y).abs().max()), float(x.abs().max()))
+    assert torch.allclose(t_seq, t_grp, rtol=2e-5, atol=1e-7), (t_seq.tolist(), t_grp.tolist())
+    worst = gradient_report(_grads(model, g_grp), _grads(model, g_seq), rel=2e-4, floor=1e-6)
+    assert worst[0][0] <= 1., worst[:5]
+    # control: without the per-utterance bounds the longest utterance of the shorter micro-batches sees rows past its own
+    # sequence end (FF hidden / pre-net rows that do not exist in its micro-batch): a different function
+    p_raw, _, _ = _grouped(model, mbs, weights, use_bounds=False)
+    d = [float((a[0] - b[0]).abs().max()) for a, b in zip(p_seq[1:], p_raw[1:])]     # (each holds one utterance forced to its T_max)
+    assert min(d) > 1e-4, d
+
+
+def test_grouped_pass_matches_sequential_bf16():
+    hp, dev, model, weights, mbs = _setup('bf16')
+    p_seq, t_seq, g_seq = _sequential(model, mbs, weights)
+    p_grp, t_grp, g_grp = _grouped(model, mbs, weights)
+    for a, b in zip(p_seq, p_grp):
+        for x, y in zip(a, b):
+            # the two runs take different tile shapes (other batch geometry -> other split of the K sums), i.e. differ by fp32
+            # summation order in front of a bf16 rounding; random-init weights amplify such a flip ~3.6x per FFT block:
+            # the end-to-end bf16 bound of tests/test_gpu_parity_at_size.py applies, the EXACT statement is the fp32 test above
+            assert float((x - y).abs().max()) <= 8e-2 * float(x.abs().max()) + 1e-6, (float((x - y).abs().max()), float(x.abs().max()))
+            assert float((x - y).norm()) <= 2e-2 * float(x.norm()) + 1e-6, (float((x - y).norm()), float(x.norm()))
+    assert torch.allclose(t_seq, t_grp, rtol=1e-2, atol=1e-5), (t_seq.tolist(), t_grp.tolist())
+    assert float((g_seq - g_grp).norm()) <= 0.1 * float(g_seq.norm()), float((g_seq - g_grp).norm()) / float(g_seq.norm())
+
+
+def test_trainer_step_grouped_equals_three_passes():
+    from daft_exprt.train import Trainer
+    from tests.util import make_hparams, no_dropout
+    from daft_exprt.model import DaftExprt
+    dev = torch.device('cuda:0')
+    res = []
+    for group in (True, False):
+        hp = no_dropout(make_hparams(batch_size=6, accumulation_steps=3, compute_dtype='fp32', group_micro_batches=group))
+        torch.manual_seed(5)
+        model = DaftExprt(hp).to(dev).train()
+        tr = Trainer(model, hp, 1)
+        assert tr.group == group
+        mbs = _micro_batches(model, hp, dev)
+        for it in (1, 2):
+            terms, gn = tr.step(mbs, it)
+        torch.cuda.synchronize()
+        res.append((terms.clone(), gn.clone(), model.flat_parameters().clone()))
+    (t0, n0, p0), (t1, n1, p1) = res
+    assert torch.allclose(t0, t1, rtol=1e-4, atol=1e-6), (t0.tolist(), t1.tolist())
+    assert torch.allclose(n0, n1, rtol=1e-3)
+    # Adam's first steps move every weight by ~lr whatever the gradient's size: compare against that scale
+    lr = 1e-4
+    assert float((p0 - p1).abs().max()) <= 0.5 * lr, float((p0 - p1).abs().max())
+    assert float(((p0 - p1).abs() > 0.02 * lr).float().mean()) < 2e-3

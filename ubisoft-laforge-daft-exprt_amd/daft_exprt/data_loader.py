@@ -202,3 +202,60 @@ def centre_duration_head(model, mean_symbol_s=0.08):
         model._P['prosody_predictor.projection.linear_layer.bias'].copy_(
             torch.tensor([mean_symbol_s, 0., 0.], device=model._flat.device))
         model.mark_updated()
+
+
+# ------------------------------------------------------------------------------------------------
+# grouped micro-batches: the reference's `accumulation_steps` micro-batches of one optimizer step as ONE padded batch
+# ------------------------------------------------------------------------------------------------
+class GroupedBatch(tuple):
+    ''' (inputs, targets) of `accum` micro-batches concatenated along the batch axis and padded to the group's (L_max, T_max),
+        plus `bounds` = (skip_in, nmax_in, skip_out, nmax_out), int64 (B_total,) tensors on the inputs' device:
+        nmax_* = padded length of the utterance's OWN micro-batch -- rows at or past it do not exist for that utterance in the
+        reference's step (a hard sequence end: zero on read, never written), so the kernels treat them as dead rows;
+        skip_* = max(0, min(length, nmax - 2)) = what the kernels' `skip_lengths` argument has to be for rows >= min(length + 2,
+        nmax) to count as dead.  With these the ONE pass over the group is the reference's accumulation of the micro-batches
+        (`train.py:379-401`): its loss terms are per-utterance means averaged over the batch, so the mean over the group equals
+        the sum over micro-batches of (micro-batch mean / accum). '''
+    def __new__(cls, inputs, targets, bounds, accum, sizes):
+        self = super().__new__(cls, (inputs, targets))
+        self.inputs, self.targets, self.bounds, self.accum, self.sizes = inputs, targets, bounds, accum, sizes
+        return self
+
+
+def _pad_to(t, dim, size):
+    if t.shape[dim] == size:
+        return t
+    shape = list(t.shape)
+    shape[dim] = size
+    out = t.new_zeros(shape)
+    out.narrow(dim, 0, t.shape[dim]).copy_(t)
+    return out
+
+
+def group_micro_batches(micro_batches):
+    ''' [(inputs 11-tuple, targets 5-tuple)] (host or device tensors, `parse_batch` order) -> GroupedBatch.  Plain torch copies:
+        data staging like `parse_batch`, run once per optimizer step (or once per resident batch) outside the kernels' path. '''
+    ins = [mb[0] for mb in micro_batches]
+    accum = len(ins)
+    Lg = max(i[0].shape[1] for i in ins)
+    Tg = max(i[8].shape[2] for i in ins)
+    cat = lambda idx, dim, size: torch.cat([_pad_to(i[idx], dim, size) for i in ins], 0).contiguous()
+    inputs = (cat(0, 1, Lg), cat(1, 1, Lg), cat(2, 1, Lg), cat(3, 1, Lg), cat(4, 1, Lg), torch.cat([i[5] for i in ins]),
+              cat(6, 1, Tg), cat(7, 1, Tg), cat(8, 2, Tg), torch.cat([i[9] for i in ins]), torch.cat([i[10] for i in ins]))
+    targets = (inputs[1], inputs[3], inputs[4], inputs[8], inputs[10])
+    dev = inputs[5].device
+    nmax_in = torch.cat([torch.full((i[0].shape[0],), i[0].shape[1], dtype=torch.long, device=dev) for i in ins])
+    nmax_out = torch.cat([torch.full((i[8].shape[0],), i[8].shape[2], dtype=torch.long, device=dev) for i in ins])
+    skip_in = torch.clamp(torch.minimum(inputs[5], nmax_in - 2), min=0)
+    skip_out = torch.clamp(torch.minimum(inputs[9], nmax_out - 2), min=0)
+    return GroupedBatch(inputs, targets, (skip_in, nmax_in, skip_out, nmax_out), accum, [i[0].shape[0] for i in ins])
+
+
+def group_host_batches(batches):
+    ''' the same on collate outputs (13-tuples of host tensors): returns (13-tuple of the group, (nmax_in, nmax_out) host tensors);
+        `DaftExprt.parse_batch` + `bounds_from_nmax` finish the job on the device '''
+    ins = [(b[:11], None) for b in batches]
+    g = group_micro_batches(ins)
+    dirs = [d for b in batches for d in b[11]]
+    files = [f for b in batches for f in b[12]]
+    return tuple(g.inputs) + (dirs, files), (g.bounds[1], g.bounds[3]), g.sizes

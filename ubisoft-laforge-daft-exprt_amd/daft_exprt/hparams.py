@@ -67,6 +67,9 @@ def _defaults():
         ('frame_decoder', _fft_block_cfg(2, with_hidden=False)),
         # MI355X build additions
         ('compute_dtype', 'bf16'),
+        # the micro-batches of an optimizer step as ONE pass over their concatenation, each utterance keeping its own micro-batch's
+        # padded length as a hard sequence end: same gradients as `accumulation_steps` separate passes (train.py:379-401)
+        ('group_micro_batches', True),
         # must come from the caller
         ('training_files', None), ('validation_files', None), ('output_directory', None),
         ('language', None), ('speakers', None),

@@ -210,6 +210,7 @@ class DaftExprt(nn.Module):
         self.fuse_ln_backward = bool(int(__import__('os').environ.get('DX_FUSE_LN_BWD', '1')))   # see _fft_block_bwd
         self.balanced_tiles = bool(int(__import__('os').environ.get('DX_BALANCED_TILES', '1')))   # see _plan
         self._plans = {}
+        self._hard = {}
         self.attn_lpt = bool(int(__import__('os').environ.get('DX_ATTN_LPT', '1')))   # see _order
         self._plan_min_rows = int(__import__('os').environ.get('DX_PLAN_MIN_ROWS', '0'))
         self._plan_small_rows = int(__import__('os').environ.get('DX_PLAN_SMALL_ROWS', '0'))   # > 0: a batch of fewer than 256 x this many padded rows gets B * N / this tiles (measured at the phoneme level: 96 -> +0.03 ms, 128 / 192 -> +0.17 ms per step: a workgroup's chunk loop is bound by its own latency chain, not by the number of workgroups pulling weights)
@@ -462,10 +463,11 @@ class DaftExprt(nn.Module):
         order = self.attn_lpt and B >= 2
         if not (plan or bf or order):
             return
-        p0, p2, od = ops.batch_prep(lengths, N, plan, bf, order)
+        wide = bf and self._skip(lengths) is lengths   # (grouped step: the halo-2 plan is built from the skip tensor, lazily, by `_plan_wide`)
+        p0, p2, od = ops.batch_prep(lengths, N, plan, wide, order)
         if plan:
             self._plans[(lengths.data_ptr(), N)] = (lengths, p0)
-        if bf:
+        if wide:
             self._plans[('wide', lengths.data_ptr(), N)] = (lengths, p2)
         if order:
             self._plans[('order', lengths.data_ptr())] = (lengths, od)
@@ -479,6 +481,17 @@ class DaftExprt(nn.Module):
         if hit is None or hit[0] is not lengths:
             hit = self._plans[key] = (lengths, ops.length_order(lengths))
         return hit[1]
+
+    def _skip(self, lengths):
+        ''' the `skip_lengths` argument for this lengths tensor: the tensor itself, or -- inside a grouped step
+            (`data_loader.GroupedBatch`) -- min(length, n_max - 2) of the utterance's own micro-batch '''
+        hit = self._hard.get(lengths.data_ptr()) if lengths is not None else None
+        return lengths if hit is None else hit[0]
+
+    def _nmax(self, lengths):
+        ''' per-utterance hard sequence end of a grouped step (rows at or past it are written as zeros), else None '''
+        hit = self._hard.get(lengths.data_ptr()) if lengths is not None else None
+        return None if hit is None else hit[1]
 
     def set_rank(self, rank):
         ''' data-parallel rank of this replica: folded into every dropout seed so that the ranks draw independent masks
@@ -564,7 +577,7 @@ class DaftExprt(nn.Module):
         xin = x_lp if x_lp is not None else x
         if qkv is None:
             qkv = ops.conv1d(xin, W[f'{a_pre}.multi_head_attention.in_proj_weight'], P[f'{a_pre}.multi_head_attention.in_proj_bias'],
-                             out_dtype=cd, skip_lengths=lengths)
+                             out_dtype=cd, skip_lengths=self._skip(lengths))
         o, lse = ops.attention_fwd(qkv, lengths, cfg['attn_nb_heads'], p_attn, seeds[0], need_lse=save, order=self._order(lengths))
         # out-projection + Dropout + residual + LayerNorm + mask in ONE launch (the GEMM tile holds complete 128-ch rows)
         a, a_lp, s1, mean1, rstd1 = ops.conv1d_ln(o, W[f'{a_pre}.multi_head_attention.out_proj.weight'],
@@ -572,8 +585,9 @@ class DaftExprt(nn.Module):
                                                   P[f'{a_pre}.layer_norm.bias'], lengths, save=save, p_pre=p_attn, seed_pre=seeds[1],
                                                   lp_copy=lp)
         ain = a_lp if lp else a
+        # (grouped step: the FF hidden is the one unmasked tensor whose row AT the sequence end reaches valid outputs -- mask it there)
         h = ops.conv1d(ain, W[f'{f_pre}.convs.0.conv.weight'], P[f'{f_pre}.convs.0.conv.bias'], out_dtype=cd, relu=True,
-                       skip_lengths=lengths, w_frag=W.get(f'F:{f_pre}.convs.0.conv.weight'))
+                       skip_lengths=self._skip(lengths), mask_lengths=self._nmax(lengths), w_frag=W.get(f'F:{f_pre}.convs.0.conv.weight'))
         # second FF conv + Dropout + residual + LayerNorm + FiLM + mask in ONE launch
         nmha = f'{next_pre}.attention.multi_head_attention' if (next_pre is not None and lp) else None
         u, u_lp, s2, mean2, rstd2, qkv_next = ops.conv1d_ln(
@@ -618,9 +632,10 @@ class DaftExprt(nn.Module):
         # left to hide it under) then runs on the LDS-DMA ring kernel
         x = ops.transpose_last2(mel_specs.float().contiguous(), torch.bfloat16 if (self.cd == torch.bfloat16 and _MEL_BF16) else torch.float32)
         wide = self.cd
-        l1, s.c1 = self._conv_ln_fwd(W, f'{pre}.convs.0', f'{pre}.convs.2', x, p_conv, wide, save, skip=output_lengths)
-        l2, s.c2 = self._conv_ln_fwd(W, f'{pre}.convs.4', f'{pre}.convs.6', l1, p_conv, wide, save, skip=output_lengths)
-        l3, s.c3 = self._conv_ln_fwd(W, f'{pre}.convs.8', f'{pre}.convs.10', l2, p_conv, torch.float32, save, skip=output_lengths)
+        skip = self._skip(output_lengths)
+        l1, s.c1 = self._conv_ln_fwd(W, f'{pre}.convs.0', f'{pre}.convs.2', x, p_conv, wide, save, skip=skip)
+        l2, s.c2 = self._conv_ln_fwd(W, f'{pre}.convs.4', f'{pre}.convs.6', l1, p_conv, wide, save, skip=skip)
+        l3, s.c3 = self._conv_ln_fwd(W, f'{pre}.convs.8', f'{pre}.convs.10', l2, p_conv, torch.float32, save, skip=skip)
         self._join_packs()                               # the weights of everything after the pre-net (refreshed on the pack stream)
         x0 = ops.scalar_embed_fwd([frames_energy, frames_pitch],
                                   [P[f'{pre}.energy_embedding.conv.weight'], P[f'{pre}.pitch_embedding.conv.weight']],
@@ -679,10 +694,10 @@ class DaftExprt(nn.Module):
         p = cfg['conv_dropout'] if train else 0.
         x, saved = enc, []
         for blk in range(cfg['nb_blocks']):
-            x, s1 = self._conv_ln_fwd(W, f'{pre}.blocks.{blk}.0', f'{pre}.blocks.{blk}.2', x, p, self.cd, save, skip=input_lengths)
+            x, s1 = self._conv_ln_fwd(W, f'{pre}.blocks.{blk}.0', f'{pre}.blocks.{blk}.2', x, p, self.cd, save, skip=self._skip(input_lengths))
             last = blk == cfg['nb_blocks'] - 1
             x, s2 = self._conv_ln_fwd(W, f'{pre}.blocks.{blk}.4', f'{pre}.blocks.{blk}.6', x, p, torch.float32 if last else self.cd,
-                                      save, film=film[:, blk, :], lengths=input_lengths if last else None, skip=input_lengths)
+                                      save, film=film[:, blk, :], lengths=input_lengths if last else None, skip=self._skip(input_lengths))
             saved.append((s1, s2))
         L = x.shape[1]
         y = ops.linear_small_fwd(x, P[f'{pre}.projection.linear_layer.weight'], P[f'{pre}.projection.linear_layer.bias'],
@@ -723,13 +738,17 @@ class DaftExprt(nn.Module):
             self._trace.append(('mel_projection', f'{pre}.projection.linear_layer', x, None, output_lengths, mel))
         return mel, (blocks, x)
 
-    def _forward(self, inputs, train, save):
+    def _forward(self, inputs, train, save, bounds=None):
         symbols, durations_float, durations_int, symbols_energy, symbols_pitch, input_lengths, \
             frames_energy, frames_pitch, mel_specs, output_lengths, speaker_ids = inputs
         ops.H.require_gpu(symbols, mel_specs)
         self._step_id += 1
         self._site = 0
         self._plans = {}
+        self._hard = {}
+        if bounds is not None:    # grouped micro-batches (`data_loader.GroupedBatch`): per-utterance hard sequence ends
+            skip_in, nmax_in, skip_out, nmax_out = bounds
+            self._hard = {input_lengths.data_ptr(): (skip_in, nmax_in), output_lengths.data_ptr(): (skip_out, nmax_out)}
         self._prep(output_lengths, mel_specs.shape[2])
         self._prep(input_lengths, symbols.shape[1])
         W = self._weights(need_dgrad=save, defer=True)
@@ -877,7 +896,7 @@ class DaftExprt(nn.Module):
         cap_in = ds2.clone() if self._trace_bwd is not None else None   # dL/d(s2 of this block): the residual gradient is updated in place below
         da = ds2
         self._wgrad(dz, s.h, G[f'{f_pre}.convs.2.conv.weight'], G[f'{f_pre}.convs.2.conv.bias'], s.lengths)
-        dh = ops.conv1d(dz, W[f'T:{f_pre}.convs.2.conv.weight'], None, out_dtype=cd, relu_gate=s.h, skip_lengths=s.lengths,
+        dh = ops.conv1d(dz, W[f'T:{f_pre}.convs.2.conv.weight'], None, out_dtype=cd, relu_gate=s.h, skip_lengths=self._skip(s.lengths),
                         w_frag=W.get(f'FT:{f_pre}.convs.2.conv.weight'))
         self._wgrad(dh, s.a, G[f'{f_pre}.convs.0.conv.weight'], G[f'{f_pre}.convs.0.conv.bias'], s.lengths)
         mha = f'{a_pre}.multi_head_attention'
@@ -1122,11 +1141,13 @@ class DaftExprt(nn.Module):
         return out
 
     @torch.no_grad()
-    def forward_backward(self, inputs, targets, loss_weights, grad_scale=1., section_done=None):
+    def forward_backward(self, inputs, targets, loss_weights, grad_scale=1., section_done=None, bounds=None):
         ''' forward + 7-term loss + hand-written backward in one call: the body of `train.py:377-391` without an
-            autograd graph or host sync.  Gradients accumulate into `flat_gradients()`.  Returns the (8,) device
+            autograd graph or host sync.  Gradients accumulate into `flat_gradients()`.  bounds: the per-utterance hard sequence
+            ends of a grouped step (`data_loader.GroupedBatch.bounds`): the one pass then equals the reference's accumulation over
+            the group's micro-batches (`train.py:379-401`).  Returns the (8,) device
             tensor [speaker, post_mult, duration, energy, pitch, mel_l1, mel_l2, total] (unscaled). '''
-        (logits, films, (dur, energy, pitch), mel, weights), S = self._forward(inputs, True, True)
+        (logits, films, (dur, energy, pitch), mel, weights), S = self._forward(inputs, True, True, bounds=bounds)
         dur_t, energy_t, pitch_t, mel_t, spk_ids = targets
         B, n_mel, T = mel.shape
         g = {'d_dur': torch.empty_like(dur), 'd_energy': torch.empty_like(energy), 'd_pitch': torch.empty_like(pitch),
@@ -1186,6 +1207,7 @@ class DaftExprt(nn.Module):
         ops.H.require_gpu(symbols, mel_spec_refs)
         self._site = 0
         self._plans = {}
+        self._hard = {}
         W = self._weights(need_dgrad=False)
         _, films, _ = self._prosody_encoder_fwd(W, energy_refs, pitch_refs, mel_spec_refs, speaker_ids, ref_lengths, False, False)
         enc, _ = self._phoneme_encoder_fwd(W, symbols, films[0], input_lengths, False, False)

@@ -28,7 +28,8 @@ import time
 import torch
 import torch.distributed as dist
 
-from daft_exprt.data_loader import DaftExprtDataCollate, SyntheticUtterances, prepare_data_loaders
+from daft_exprt.data_loader import DaftExprtDataCollate, GroupedBatch, SyntheticUtterances, group_host_batches, \
+    group_micro_batches, prepare_data_loaders
 from daft_exprt.hparams import HyperParams
 from daft_exprt.loss import DaftExprtLoss, KEYS
 from daft_exprt.model import DaftExprt
@@ -113,6 +114,12 @@ class Trainer(object):
             self.reducer.broadcast_parameters()
         model.always_repack = False   # parameters only change through self.optimizer
         self.terms = None
+        # the `accumulation_steps` micro-batches of an optimizer step as ONE pass over their concatenation, every utterance keeping the
+        # padded length of its own micro-batch as a hard sequence end (`data_loader.GroupedBatch`): the reference's accumulation
+        # (`train.py:379-401`, default 16 x 3) at the launch count and tile efficiency of one batch of 48.  hparams.group_micro_batches
+        # = False keeps one pass per micro-batch.
+        self.group = bool(getattr(hparams, 'group_micro_batches', True))
+        self._groups = {}
         # per-bucket Adam behind each bucket's all-reduce: default on with several ranks (it hides the optimizer pass and the wait for
         # the last all-reduce); on ONE GPU the slice updates only compete with the backward kernels for HBM (measured 8.29 vs 8.08 ms
         # per step), so the whole-buffer step (one launch, gradient norm summed on the way) stays the default there
@@ -153,8 +160,21 @@ class Trainer(object):
             self.optimizer.step_slice(off, n)
         self._done.add(name)
 
+    def _grouped(self, micro_batches):
+        ''' the GroupedBatch of these micro-batches; resident batches (same tensors as a recent call) are grouped once '''
+        key = tuple(t.data_ptr() for mb in micro_batches for t in mb[0])
+        hit = self._groups.get(key)
+        if hit is not None and all(x is y for (a, _), (b, _) in zip(hit[0], micro_batches) for x, y in zip(a, b)):
+            return hit[1]
+        g = group_micro_batches(micro_batches)
+        if len(self._groups) >= 8:
+            self._groups.pop(next(iter(self._groups)))
+        self._groups[key] = (list(micro_batches), g)     # (keeps the source tensors alive: their addresses are the key)
+        return g
+
     def step(self, micro_batches, iteration):
-        ''' micro_batches: list of (inputs, targets) already on the device (len = accumulation_steps).
+        ''' micro_batches: list of (inputs, targets) already on the device (len = accumulation_steps), or one
+            `data_loader.GroupedBatch` in a list (what `train()` builds on the host before the H2D copy).
             Returns (terms (8,) device tensor summed over micro-batches / accumulation_steps, grad_norm_sq device scalar).
             The tensors may live in buffers a later call overwrites (captured steps reuse theirs): consume them -- or enqueue the
             copy that does -- before the next call. '''
@@ -165,6 +185,8 @@ class Trainer(object):
     def step_eager(self, micro_batches, iteration):
         ''' the step as individual launches (also what a capture records) '''
         hp, model = self.hp, self.model
+        if self.group and len(micro_batches) > 1 and model.flat_parameters().is_cuda:
+            micro_batches = [self._grouped(micro_batches)]
         accum = len(micro_batches)
         lr = update_learning_rate(hp, iteration)
         self.optimizer.param_groups[0]['lr'] = lr
@@ -180,10 +202,12 @@ class Trainer(object):
             self.optimizer.begin_step()     # step count, zeroed norm accumulator: on the compute stream, ahead of every slice update
             self._done = set()
         total = None
-        for k, (inputs, targets) in enumerate(micro_batches):
+        for k, mb in enumerate(micro_batches):
+            inputs, targets = mb
             last = k == accum - 1
             hook = self._section_done if (last and (self.reducer.active or self._sectioned_now)) else None
-            terms = model.forward_backward(inputs, targets, weights, grad_scale=scale, section_done=hook)
+            terms = model.forward_backward(inputs, targets, weights, grad_scale=scale, section_done=hook,
+                                           bounds=mb.bounds if isinstance(mb, GroupedBatch) else None)
             total = terms if total is None else ops.add_(total, terms)
         main = torch.cuda.current_stream()
         if self._sectioned_now:
@@ -442,33 +466,57 @@ def train(gpu, hparams, log_file):
 
     copy_stream = streams.pick([torch.cuda.current_stream(gpu)], what='copy stream')
 
+    group = trainer.group and hparams.accumulation_steps > 1
+
+    def host_units():
+        ''' collate outputs, one per forward / backward pass: the loader's batches, or -- grouped micro-batches -- the
+            `accumulation_steps` batches of an optimizer step merged on the host (`group_host_batches`) '''
+        held = []
+        for batch in loader:
+            if not group:
+                yield batch, None
+                continue
+            held.append(batch)
+            if len(held) == hparams.accumulation_steps:
+                merged, nmax, sizes = group_host_batches(held)
+                held = []
+                yield merged, (nmax, sizes)
+
     def device_batches():
         ''' the loader's batches one ahead of the step that consumes them: the H2D copies of batch i + 1 (15.8 MB at B = 48) run on
             a copy stream under step i instead of in front of step i + 1 on the compute stream '''
         ahead = None
-        for batch in loader:
+        for batch, grouped in host_units():
             frames = int(batch[9].sum())     # host tensor (collate output): no device round trip
             with torch.cuda.stream(copy_stream):
                 inputs, targets, _ = model.parse_batch(gpu, batch)
+                unit = (inputs, targets)
+                if grouped is not None:
+                    (nmax_in, nmax_out), sizes = grouped
+                    up = lambda t: t.to(inputs[5].device, non_blocking=True)
+                    nmax_in, nmax_out = up(nmax_in), up(nmax_out)
+                    bounds = (torch.clamp(torch.minimum(inputs[5], nmax_in - 2), min=0), nmax_in,
+                              torch.clamp(torch.minimum(inputs[9], nmax_out - 2), min=0), nmax_out)
+                    unit = GroupedBatch(inputs, targets, bounds, len(sizes), sizes)
                 ready = torch.cuda.Event()
                 ready.record(copy_stream)
             if ahead is not None:
                 yield ahead
-            ahead = (inputs, targets, frames, ready)
+            ahead = (unit, frames, ready)
         if ahead is not None:
             yield ahead
 
     while iteration <= hparams.nb_iterations:
-        for inputs, targets, frames, ready in device_batches():
+        for unit, frames, ready in device_batches():
             main = torch.cuda.current_stream()
             main.wait_event(ready)
-            for t in inputs:
+            for t in tuple(unit[0]) + (tuple(unit.bounds) if isinstance(unit, GroupedBatch) else ()):
                 t.record_stream(main)        # allocated on the copy stream, consumed on the compute stream
-            micro.append((inputs, targets, frames))
-            if len(micro) < hparams.accumulation_steps:
+            micro.append((unit, frames))
+            if len(micro) < (1 if group else hparams.accumulation_steps):
                 continue
-            terms, gnorm_sq = trainer.step([(i, t) for i, t, _ in micro], iteration)
-            frames = sum(f for _, _, f in micro)
+            terms, gnorm_sq = trainer.step([u for u, _ in micro], iteration)
+            frames = sum(f for _, f in micro)
             micro = []
             lr = trainer.optimizer.param_groups[0]['lr']
             report(time.time())              # the PREVIOUS iteration's scalars (this one is already queued on the device)
