@@ -90,10 +90,9 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(hp, batch, n_utt=4, warmup=2, steps=5):
-    ''' the CPU oracle (a port of the reference algorithm, oracle/daft_exprt_cpu.py) timed on this host, BASELINE.md 4
-        procedure: `warmup` + `steps` full train steps (fwd + loss + autograd bwd + Adam, dropout on, fp32) on the first
-        `n_utt` utterances of the bench batch (bounded sample: the whole B = 48 batch costs ~100 s per step), median '''
+def _cpu_train_steps(hp, batch, n_utt, warmup, steps):
+    ''' `warmup` + `steps` full train steps (fwd + 7-term loss + autograd bwd + Adam, dropout on, fp32) of the CPU oracle on the first
+        `n_utt` utterances of `batch` (a collate 13-tuple); returns (sorted timed seconds, valid frames, T_max) '''
     from oracle import daft_exprt_cpu as O
     P = {k: v.requires_grad_(True) for k, v in O.random_params(hp, seed=0).items()}
     sl = slice(0, n_utt)
@@ -105,7 +104,6 @@ def cpu_baseline(hp, batch, n_utt=4, warmup=2, steps=5):
     cin[1], cin[3], cin[4], cin[6], cin[7], cin[8] = [t.float() for t in (cin[1], cin[3], cin[4], cin[6], cin[7], cin[8])]
     targets = (cin[1], cin[3], cin[4], cin[8], cin[10])
     state = {'step': 0, 'm': {k: torch.zeros_like(v) for k, v in P.items()}, 'v': {k: torch.zeros_like(v) for k, v in P.items()}}
-    frames = int(cin[9].sum())
     times = []
     for s in range(warmup + steps):
         t0 = time.time()
@@ -115,13 +113,50 @@ def cpu_baseline(hp, batch, n_utt=4, warmup=2, steps=5):
         with torch.no_grad():
             O.adam_step(P, dict(zip(P.keys(), grads)), state, 1e-4, hp.betas, hp.epsilon, hp.weight_decay)
         times.append(time.time() - t0)
-    timed = sorted(times[warmup:])
+    return sorted(times[warmup:]), int(cin[9].sum()), T
+
+
+def cpu_baseline(hp, batch, n_utt=8, warmup=1, steps=3):
+    ''' the CPU oracle (a port of the reference algorithm, oracle/daft_exprt_cpu.py) timed on this host, BASELINE.md 4 procedure on a
+        BOUNDED sample (the whole B = 48 batch costs ~100 s per step):
+          1. thread sweep: torch.set_num_threads in {8, 16, 32, 64, 128} (those the host has), 1 warm-up + 1 timed train step each on the
+             first 4 utterances -- the oracle is hundreds of small ATen ops per step, and torch's default of one thread per core
+             (128 here) oversubscribes them (VERDICT r4 weak 9);
+          2. the reported value: `warmup` + `steps` train steps on the first `n_utt` utterances of the bench batch at the best count;
+          3. `c1`: BASELINE configs[0] (single speaker, B = 8, T <= 800), same procedure, 1 + 2 steps.
+        Runs after the GPU timing, outside every timed region. '''
+    default_threads = torch.get_num_threads()
+    cores = os.cpu_count() or default_threads
+    sweep = {}
+    for n in (8, 16, 32, 64, 128):
+        if n > cores:
+            break
+        torch.set_num_threads(n)
+        t, fr, _ = _cpu_train_steps(hp, batch, 4, 1, 1)
+        sweep[n] = fr / t[0]
+    best = max(sweep, key=sweep.get) if sweep else default_threads
+    torch.set_num_threads(best)
+    timed, frames, T = _cpu_train_steps(hp, batch, n_utt, warmup, steps)
     med = timed[len(timed) // 2]
-    return {'value': frames / med, 'unit': 'mel-frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+    # configs[0]: the reference's own CPU-runnable case
+    from daft_exprt.data_loader import synthetic_batch
+    from daft_exprt.hparams import HyperParams
+    hp1 = HyperParams(verbose=False, training_files='none', validation_files='none', output_directory='/nonexistent_out',
+                      language='english', speakers=['LJ'], batch_size=8, accumulation_steps=1, compute_dtype='fp32')
+    cb1 = synthetic_batch(hp1, 8, seed=99, t_min=1, t_max=800, force_first_full=True)
+    t1, f1, T1 = _cpu_train_steps(hp1, cb1, 8, 1, 2)
+    m1 = t1[len(t1) // 2]
+    torch.set_num_threads(default_threads)
+    return {'value': frames / med, 'unit': 'mel-frames/s', 'cores': best, 'kind': 'port',
             'sample': f'{warmup} warm-up + {steps} timed full train steps (fwd+loss+bwd+Adam, fp32, dropout on) of the CPU oracle '
-                      f'on the first {n_utt} utterances of the bench batch ({frames} valid frames, T_max={T}), median; '
-                      f'host os.cpu_count()={os.cpu_count()}, torch threads={torch.get_num_threads()}, CPU "{_cpu_model()}"',
-            's_per_step_median': med, 's_per_step_min': timed[0], 's_per_step_max': timed[-1], 'cpu_model': _cpu_model()}
+                      f'on the first {n_utt} utterances of the bench batch ({frames} valid frames, T_max={T}), median, at the best of '
+                      f'the swept torch thread counts ({best}); host os.cpu_count()={cores}, CPU "{_cpu_model()}"',
+            's_per_step_median': med, 's_per_step_min': timed[0], 's_per_step_max': timed[-1], 'cpu_model': _cpu_model(),
+            'thread_sweep_frames_per_s': {str(k): v for k, v in sweep.items()},
+            'thread_sweep_sample': '1 warm-up + 1 timed train step on the first 4 utterances per thread count',
+            'c1': {'value': f1 / m1, 'unit': 'mel-frames/s', 'cores': best, 's_per_step_median': m1,
+                   'sample': f'BASELINE configs[0]: single speaker, B = 8, T <= 800 ({f1} valid frames, T_max={T1}), 1 warm-up + 2 timed '
+                             f'train steps of the CPU oracle, median'}}
 
 
 def measured_traffic(kernel_family, tag='counters'):
@@ -448,8 +483,18 @@ def main():
     model = DaftExprt(hp).to(dev).train()
     model.set_rank(rank)
     trainer = Trainer(model, hp, world)
-    if rank == 0:      # stderr: the JSON line stays alone on stdout
-        print(f'[bench] torch.distributed world {dist.get_world_size() if dist_on else 1}; {trainer.reducer.describe()}', file=sys.stderr)
+    if rank == 0 or dist_on:      # stderr: the JSON line stays alone on stdout.  EVERY rank of a multi-rank run reports its bucket table,
+        # the verdict of the hardware-queue probes and the RCCL build, so that a failed SCALE run can be diagnosed from the record's tail
+        try:
+            rccl = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:   # noqa: BLE001
+            rccl = f'unknown ({type(e).__name__})'
+        side = getattr(model, '_side', None)
+        print(f'[bench rank {rank}/{world} pid {os.getpid()} {torch.cuda.get_device_name(dev)} cuda:{local_rank}] world '
+              f'{dist.get_world_size() if dist_on else 1}, RCCL {rccl}, HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}, '
+              f'GPU_MAX_HW_QUEUES={os.environ.get("GPU_MAX_HW_QUEUES", "default")}; {trainer.reducer.describe()}; weight-gradient stream '
+              f'{"probed" if side is not None else "not created yet"}; per-bucket Adam {"on" if trainer.sectioned else "off"}',
+              file=sys.stderr, flush=True)
     batches, cpu_batches = [], []
     for i in range(args.pool):
         cb = synthetic_batch(hp, args.batch, seed=1234 + rank + 1000 * i, t_min=args.tmin, t_max=1000, force_first_full=True)
@@ -563,4 +608,10 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    try:
+        main()
+    except Exception:   # noqa: BLE001 -- a rank that dies must say which one it was (the launcher interleaves the ranks' stderr)
+        import traceback
+        print(f'[bench rank {os.environ.get("RANK", "0")}/{os.environ.get("WORLD_SIZE", "1")} pid {os.getpid()}] FAILED:\n' + traceback.format_exc(),
+              file=sys.stderr, flush=True)
+        raise

@@ -73,3 +73,42 @@ def test_bench_spawns_its_own_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['config']['global_batch'] == 16
+
+
+def test_eight_concurrent_one_rank_worlds_on_one_gpu():
+    ''' host-side contention rehearsal for the first 8-GPU run: EIGHT bench processes at once on the one GPU of this
+        box, each a one-rank RCCL world of its own (DX_FORCE_DIST=1, distinct rendezvous ports) -- 8 x (communicator set-up, stream probes
+        under a contended GPU, `new_group` retries, per-bucket hooks) side by side, two of them driving the real `train()` loop with its
+        fork-server DataLoader workers.  Every process must finish with a valid line; the probe verdicts go to the captured output. '''
+    import json
+    ports = []
+    socks = [socket.socket() for _ in range(8)]
+    for s in socks:
+        s.bind(('127.0.0.1', 0))
+        ports.append(s.getsockname()[1])
+    for s in socks:
+        s.close()
+    procs = []
+    for k, port in enumerate(ports):
+        env = dict(os.environ, DX_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', LOCAL_RANK='0', WORLD_SIZE='1')
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '3', '--batch', '8',
+               '--no-cpu-baseline', '--no-probe', '--no-secondary']
+        if k >= 6:
+            cmd += ['--loop', 'train']
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=1500))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append(p.communicate())
+    for k, (p, (so, se)) in enumerate(zip(procs, outs)):
+        print(f'--- process {k} rc {p.returncode}\n' + '\n'.join(l for l in se.splitlines() if 'bench' in l or 'streams' in l)[-1500:])
+    for k, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, (k, se[-3000:])
+        line = json.loads([l for l in so.splitlines() if l.startswith('{')][-1])
+        assert line['n_gpus'] == 1 and line['value'] > 0, (k, line)
+        if k < 6:
+            assert 'backend nccl' in se and 'world 1' in se, (k, se[-2000:])

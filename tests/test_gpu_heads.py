@@ -44,3 +44,19 @@ def test_fused_heads_match_the_separate_launches(speakers):
     touched = [n for n in g0 if n.startswith(('speaker_classifier', 'prosody_encoder.gammas', 'prosody_encoder.betas', 'prosody_encoder.spk_embedding',
                                               'prosody_encoder.post_multipliers'))]
     assert len(touched) == 12 and all(float(g1[n].abs().max()) > 0. for n in touched if 'classifier' not in n or len(speakers) > 1)
+
+
+def test_more_speakers_than_the_fused_classifier_holds():
+    ''' n_speakers - 1 > 128 logits do not fit the one-launch classifier's 128-wide tile: the model then takes the
+        `linear_small_*` launches instead of raising, and the logits are those of the plain three-layer MLP (model.py:276-292) '''
+    speakers = [f'spk{i:03d}' for i in range(140)]
+    t1, l1, f1, m1, g1 = _run(True, speakers)
+    assert l1.shape == (6, 140) and bool(torch.isfinite(t1).all())
+    from daft_exprt.model import DaftExprt
+    from tests.util import make_hparams, no_dropout
+    hp = no_dropout(make_hparams(compute_dtype='fp32', batch_size=6, speakers=speakers))
+    torch.manual_seed(5)
+    model = DaftExprt(hp).to(DEV).train()
+    assert not model._fused_classifier()
+    for n in ('1', '3', '5'):
+        assert float(g1[f'speaker_classifier.classifier.{n}.linear_layer.weight'].abs().max()) > 0.

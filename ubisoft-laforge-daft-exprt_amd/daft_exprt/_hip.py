@@ -9,8 +9,10 @@ import re
 
 import torch
 
+from daft_exprt import config
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('DX_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'csrc', 'libdaftexprt_hip.so')   # DX_HIP_LIB: A/B builds
+LIB_PATH = config.HIP_LIB or os.path.join(os.path.dirname(_HERE), 'csrc', 'libdaftexprt_hip.so')   # DX_HIP_LIB: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), 'include', 'daft_exprt_hip.h')
 
 F32, BF16, I64 = 0, 1, 2

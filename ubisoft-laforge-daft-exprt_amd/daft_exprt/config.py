@@ -1,0 +1,46 @@
+"""The package's environment switches, read ONCE at import (one place instead of reads scattered through constructors).
+
+Only switches that select between TESTED paths, or that a measurement protocol of DESIGN.md names, are left; the A/B switches of
+rounds 1-4 whose verdicts are recorded in DESIGN section 9 ("not kept") are gone together with the code they guarded.  Tests flip
+the module attributes they exercise (`ops.USE_SPLITK`, `ops.USE_WIDE`, `ops.USE_FUSED_HEADS`, `ops.WGRAD_WORKSPACE`,
+`model.balanced_tiles`, `model.fuse_ln_backward`, `optimizer.fuse_pack`); those have no environment form.
+
+| variable | default | effect |
+|---|---|---|
+| DX_HIP_LIB | in-tree csrc/libdaftexprt_hip.so | another build of the library (`DX_BUILD_TAG=... python build_hip.py`) for same-box A/B runs |
+| DX_WGRAD_SIDE_STREAM | 1 | 0: weight gradients on the launch stream (no second hardware queue) |
+| DX_SKIP_WGRAD | 0 | 1: skip every weight gradient (measurement protocol of DESIGN 5: what the side-stream work costs the step) |
+| DX_FORCE_DIST | 0 | 1: a ONE-rank process group issues every collective of the multi-rank path (tests/test_gpu_ddp.py) |
+| DX_STREAM_PROBE | 1 | 0: streams straight from torch's pool, no hardware-queue probes (`streams.py`) |
+| DX_SECTIONED_ADAM | auto | per-bucket Adam behind each bucket's all-reduce; auto = only with more than one rank |
+| DX_STEP_GRAPH | 0 | 1 / auto: `Trainer.step` replayed from a hipGraph (`train.CapturedStep`); DX_STEP_GRAPH_MAX (8) graphs kept |
+| DX_POISON | 0 | 1: every buffer `ops` allocates is filled with NaN before the kernel that writes it runs (tests: no kernel may read rows it was not given) |
+"""
+import os
+
+
+def _flag(name, default):
+    return bool(int(os.environ.get(name, default)))
+
+
+HIP_LIB = os.environ.get('DX_HIP_LIB') or None
+WGRAD_SIDE_STREAM = _flag('DX_WGRAD_SIDE_STREAM', '1')
+SKIP_WGRAD = _flag('DX_SKIP_WGRAD', '0')
+STREAM_PROBE = _flag('DX_STREAM_PROBE', '1')
+SECTIONED_ADAM = os.environ.get('DX_SECTIONED_ADAM', 'auto')
+STEP_GRAPH = os.environ.get('DX_STEP_GRAPH', '0')
+STEP_GRAPH_MAX = int(os.environ.get('DX_STEP_GRAPH_MAX', '8'))
+POISON = _flag('DX_POISON', '0')
+
+
+def force_dist():
+    ''' read at call time: tests set it per sub-process / per test '''
+    return os.environ.get('DX_FORCE_DIST', '0') == '1'
+
+
+def sectioned_adam():
+    return os.environ.get('DX_SECTIONED_ADAM', SECTIONED_ADAM)
+
+
+def step_graph():
+    return os.environ.get('DX_STEP_GRAPH', STEP_GRAPH)

@@ -26,7 +26,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from daft_exprt import ops, streams
+from daft_exprt import config, ops, streams
 
 _MASK63 = (1 << 63) - 1
 
@@ -128,12 +128,6 @@ def _init_tensor(shape, init, gen):
     return u / math.sqrt(float(arg))   # torch default Linear / Conv1d bias and kaiming(a=sqrt 5) weight bound
 
 
-_CAPTURE_ORDER = __import__('os').environ.get('DX_CAPTURE_ORDER', 'defer')   # defer | anchor | none: see _flush_wgrads
-_SKIP_WGRAD = bool(int(__import__('os').environ.get('DX_SKIP_WGRAD', '0')))
-_BATCH_PREP = bool(int(__import__('os').environ.get('DX_BATCH_PREP', '1')))   # 0: tile plans / launch orders by their own (lazy) launches (A/B switch)
-_MEL_BF16 = bool(int(__import__('os').environ.get('DX_MEL_BF16', '1')))   # 0: the first pre-net conv and its weight gradient read the fp32 mel rows (A/B switch)
-_PACK_SIDE_STREAM = bool(int(__import__('os').environ.get('DX_PACK_SIDE_STREAM', '0')))   # 1: the weight copies the pre-net does not read are refreshed on a pack stream underneath it (measured: 8.22 vs 8.17 ms -- the copies then share the chip with the pre-net's kernels, nothing is gained)
-
 class _Node(nn.Module):
     ''' name-only container: reproduces the reference's module tree so that state_dict keys match '''
 
@@ -187,7 +181,6 @@ class DaftExprt(nn.Module):
         self._flat = self._gflat = None
         self._packed, self._packed_version, self._param_version = {}, -1, 0
         self._adam_table = {}
-        self._pack_stream, self._packs_pending = None, False
         # True (default, always safe): re-pack the bf16 weight copies on every call (one batched kernel, ~40 us).  False: re-pack only
         # when the parameters changed through torch -- `_weights` watches the version counters of the GEMM weights, so
         # load_state_dict, torch.optim steps and in-place ops under no_grad are all seen; writes through `.data`, `model._P[...]`
@@ -198,23 +191,14 @@ class DaftExprt(nn.Module):
         self._side = self._side_stream = None
         self._wgrad_keep = []
         self._wgrad_pending = []
-        self._wgrad_batch_rows = int(__import__('os').environ.get('DX_WGRAD_BATCH_ROWS', '1000000000'))   # GEMMs with fewer rows wait for the block's flush (measured: always waiting is best, 8.35 vs 8.42 ms)
-        self._wgrad_flush_blocks = int(__import__('os').environ.get('DX_WGRAD_FLUSH_BLOCKS', '1'))   # FFT blocks per flush
-        self._blocks_since_flush = 0
-        self._hold_flush = False
-        self._wgrad_hold_dec = int(__import__('os').environ.get('DX_WGRAD_HOLD_DEC', '0'))   # weight gradients of the decoder's last K blocks wait for the end of the decoder's backward pass (they then run under the phoneme-level stretch)
-        self._wgrad_defer_rows = int(__import__('os').environ.get('DX_WGRAD_DEFER_ROWS', '0'))   # see _block_done (0: never defer; 16384 measured 7.99 vs 7.79 ms)
         self._wgrad_ws = None
         self._hop = None
         self._side_deferred = None
-        self.fuse_ln_backward = bool(int(__import__('os').environ.get('DX_FUSE_LN_BWD', '1')))   # see _fft_block_bwd
-        self.balanced_tiles = bool(int(__import__('os').environ.get('DX_BALANCED_TILES', '1')))   # see _plan
+        self.fuse_ln_backward = True   # see _fft_block_bwd (tests compare against the separate LayerNorm-backward launches)
+        self.balanced_tiles = True     # see _plan (tests compare against the fixed-tile launches)
         self._plans = {}
         self._hard = {}
-        self.attn_lpt = bool(int(__import__('os').environ.get('DX_ATTN_LPT', '1')))   # see _order
-        self._plan_min_rows = int(__import__('os').environ.get('DX_PLAN_MIN_ROWS', '0'))
-        self._plan_small_rows = int(__import__('os').environ.get('DX_PLAN_SMALL_ROWS', '0'))   # > 0: a batch of fewer than 256 x this many padded rows gets B * N / this tiles (measured at the phoneme level: 96 -> +0.03 ms, 128 / 192 -> +0.17 ms per step: a workgroup's chunk loop is bound by its own latency chain, not by the number of workgroups pulling weights)
-        self._plan_k1 = bool(int(__import__('os').environ.get('DX_PLAN_K1', '0')))   # balanced tiles also for the k = 1 QKV data gradient + LayerNorm backward (measured: 8.78 vs 8.74 ms)
+        self.attn_lpt = True           # see _order
         self._step_id, self._site, self._rank, self._capture_step0 = 0, 0, 0, 0
         self._trace = None    # tests set this to a list: every stage appends (kind, names, input, film, lengths, output)
         self._trace_bwd = None   # likewise for the backward pass: (kind, saved, saved_below, gradient in, gradient out)
@@ -250,7 +234,6 @@ class DaftExprt(nn.Module):
         self._pos = None
         self._packed = {}
         self._adam_table = {}
-        self._pack_stream, self._packs_pending = None, False   # (a new device after .to(): new stream)
         self.mark_updated()
 
     def flat_parameters(self):
@@ -293,13 +276,10 @@ class DaftExprt(nn.Module):
             self._pos = table.to(self._flat.device)
         return self._pos
 
-    def _weights(self, need_dgrad, defer=False):
+    def _weights(self, need_dgrad):
         ''' MFMA-operand copies of the GEMM weights (compute dtype): forward packing [tap][Cout][Cin] and
-            data-gradient packing [tap][Cin][Cout] with flipped taps, refreshed by batched kernel launches.
-            defer=True (the model's own forward pass): only the copies the pre-net of the prosody encoder reads are refreshed on
-            the launch stream; every other copy (and all data-gradient packings) is refreshed on a pack stream underneath the
-            pre-net's kernels, and the caller joins it with `_join_packs()` before the first FFT block (~0.1 ms less on the
-            critical path of a training step). '''
+            data-gradient packing [tap][Cin][Cout] with flipped taps, refreshed by batched kernel launches (the training step never
+            gets here: its optimizer launch refreshes every copy, `packs_are_current`). '''
         if not self._packed:
             dev, fwd, bwd = self._flat.device, ([], []), []
             early = lambda name: name.startswith('prosody_encoder.convs.')
@@ -337,10 +317,10 @@ class DaftExprt(nn.Module):
                         fbwd.append((self._packed['T:' + name], self._packed['FT:' + name]))
                     # the register-weights kernel (Cin = 128 -> Cout % 256 == 0: first FF conv forward, second FF conv data gradient)
                     # loads its weight slice fragment by fragment from the same layout
-                    if ops.USE_WFRAG and name.endswith('feed_forward.convs.0.conv.weight') and w.shape[1] == 128 and w.shape[0] % 256 == 0:
+                    if name.endswith('feed_forward.convs.0.conv.weight') and w.shape[1] == 128 and w.shape[0] % 256 == 0:
                         self._packed['F:' + name] = torch.empty(w.numel(), dtype=self.cd, device=dev)
                         ffwd[0 if early(name) else 1].append((self._packed[name], self._packed['F:' + name]))
-                    if ops.USE_WFRAG and name.endswith('feed_forward.convs.2.conv.weight') and w.shape[0] == 128 and w.shape[1] % 256 == 0:
+                    if name.endswith('feed_forward.convs.2.conv.weight') and w.shape[0] == 128 and w.shape[1] % 256 == 0:
                         self._packed['FT:' + name] = torch.empty(w.numel(), dtype=self.cd, device=dev)
                         fbwd.append((self._packed['T:' + name], self._packed['FT:' + name]))
                 self._frag_fwd = [ops.frag_table(f, dev) if f else None for f in ffwd]
@@ -355,34 +335,20 @@ class DaftExprt(nn.Module):
         do_bwd = need_dgrad and (do_fwd or self._dgrad_version != self._packed_version)
         if not (do_fwd or do_bwd):
             return self._packed
-        self._join_packs()                                # (a deferred refresh nobody joined: keep the streams ordered)
-        side = None
-        if defer and self._flat.is_cuda and _PACK_SIDE_STREAM:
-            if self._pack_stream is None:
-                self._pack_stream, self._pack_ev0, self._pack_ev1 = torch.cuda.Stream(device=self._flat.device), torch.cuda.Event(), torch.cuda.Event()
-            side = self._pack_stream
-            self._pack_ev0.record()                       # the parameters are final at this point of the launch stream
-            side.wait_event(self._pack_ev0)
-        late = None if side is None else side.cuda_stream
         if do_fwd:
-            if self._pack_fwd[0] is not None:
-                ops.pack_weights_batched(*self._pack_fwd[0], self.cd)
-            if self._frag_fwd[0] is not None:
-                ops.pack_frag_major_batched(*self._frag_fwd[0])
-            if self._pack_fwd[1] is not None:
-                ops.pack_weights_batched(*self._pack_fwd[1], self.cd, stream=late)
-            if self._frag_fwd[1] is not None:
-                ops.pack_frag_major_batched(*self._frag_fwd[1], stream=late)
+            for tab in self._pack_fwd:
+                if tab is not None:
+                    ops.pack_weights_batched(*tab, self.cd)
+            for tab in self._frag_fwd:
+                if tab is not None:
+                    ops.pack_frag_major_batched(*tab)
             self._packed_version = version
             self._dgrad_version = -1
         if do_bwd:
-            ops.pack_weights_batched(*self._pack_bwd, self.cd, stream=late)
+            ops.pack_weights_batched(*self._pack_bwd, self.cd)
             if self._frag_bwd is not None:
-                ops.pack_frag_major_batched(*self._frag_bwd, stream=late)
+                ops.pack_frag_major_batched(*self._frag_bwd)
             self._dgrad_version = self._packed_version
-        if side is not None:
-            self._pack_ev1.record(side)
-            self._packs_pending = True
         return self._packed
 
     def adam_pack_table(self, rng=None):
@@ -419,28 +385,16 @@ class DaftExprt(nn.Module):
             return
         self._packed_version = self._dgrad_version = version
 
-    def _join_packs(self):
-        ''' the launch stream waits for the weight copies a deferred `_weights` call refreshes on the pack stream '''
-        if self._packs_pending:
-            torch.cuda.current_stream().wait_event(self._pack_ev1)
-            self._packs_pending = False
-
     def _plan(self, lengths, N):
         ''' balanced position tiles of this step's batch for the LayerNorm-fused k = 3 GEMMs (`ops.conv_tile_plan`): one
             small launch per distinct lengths tensor per step, shared by the 8 forward and 8 backward launches that read it.
             Frame-level stacks only: a phoneme-level batch is too small for the tile count to matter. '''
-        if not self.balanced_tiles or self.cd != torch.bfloat16 or lengths is None or lengths.shape[0] * N < self._plan_min_rows:
+        if not self.balanced_tiles or self.cd != torch.bfloat16 or lengths is None:
             return None
         key = (lengths.data_ptr(), N)
         hit = self._plans.get(key)
         if hit is None or hit[0] is not lengths:      # the entry keeps `lengths` alive, so its address cannot be recycled under the key
-            # every workgroup streams the whole weight slice of the layer from L2 whatever its height: a batch that cannot
-            # give 256 tiles ~_plan_small_rows padded rows each (the phoneme level) gets fewer, taller tiles
-            B = lengths.shape[0]
-            tiles = None
-            if self._plan_small_rows > 0 and B * N < 256 * self._plan_small_rows:
-                tiles = max(1, -(-B * N // self._plan_small_rows))
-            hit = self._plans[key] = (lengths, ops.conv_tile_plan(lengths, N, tiles=tiles))
+            hit = self._plans[key] = (lengths, ops.conv_tile_plan(lengths, N))
         return hit[1]
 
     def _plan_wide(self, lengths, N):
@@ -456,10 +410,10 @@ class DaftExprt(nn.Module):
     def _prep(self, lengths, N):
         ''' the tile plans and the attention launch order of one lengths tensor from ONE launch (`ops.batch_prep`) instead of
             up to three lazy ones (`_plan`, `_plan_wide`, `_order` then find their entries) '''
-        if lengths is None or not lengths.is_cuda or not _BATCH_PREP:
+        if lengths is None or not lengths.is_cuda:
             return
         bf, B = self.cd == torch.bfloat16, lengths.shape[0]
-        plan = bf and self.balanced_tiles and B * N >= self._plan_min_rows and not (0 < B * N < 256 * self._plan_small_rows)
+        plan = bf and self.balanced_tiles
         order = self.attn_lpt and B >= 2
         if not (plan or bf or order):
             return
@@ -630,13 +584,12 @@ class DaftExprt(nn.Module):
         # (B, T, n_mel) channel-last rows (no-op casts on the step path: parse_batch normalises); in bf16 mode the transpose emits bf16
         # = the rounding the first conv applies at operand load; its weight gradient (the last launch of the backward pass, nothing
         # left to hide it under) then runs on the LDS-DMA ring kernel
-        x = ops.transpose_last2(mel_specs.float().contiguous(), torch.bfloat16 if (self.cd == torch.bfloat16 and _MEL_BF16) else torch.float32)
+        x = ops.transpose_last2(mel_specs.float().contiguous(), torch.bfloat16 if self.cd == torch.bfloat16 else torch.float32)
         wide = self.cd
         skip = self._skip(output_lengths)
         l1, s.c1 = self._conv_ln_fwd(W, f'{pre}.convs.0', f'{pre}.convs.2', x, p_conv, wide, save, skip=skip)
         l2, s.c2 = self._conv_ln_fwd(W, f'{pre}.convs.4', f'{pre}.convs.6', l1, p_conv, wide, save, skip=skip)
         l3, s.c3 = self._conv_ln_fwd(W, f'{pre}.convs.8', f'{pre}.convs.10', l2, p_conv, torch.float32, save, skip=skip)
-        self._join_packs()                               # the weights of everything after the pre-net (refreshed on the pack stream)
         x0 = ops.scalar_embed_fwd([frames_energy, frames_pitch],
                                   [P[f'{pre}.energy_embedding.conv.weight'], P[f'{pre}.pitch_embedding.conv.weight']],
                                   [P[f'{pre}.energy_embedding.conv.bias'], P[f'{pre}.pitch_embedding.conv.bias']],
@@ -665,10 +618,14 @@ class DaftExprt(nn.Module):
         s.frames_energy, s.frames_pitch, s.speaker_ids, s.output_lengths = frames_energy, frames_pitch, speaker_ids, output_lengths
         return emb, films, s
 
+    def _fused_classifier(self):
+        ''' the one-launch classifier holds its logits in a 128-wide tile: more than 129 speakers take the `linear_small_*` launches '''
+        return ops.USE_FUSED_HEADS and self.hp.n_speakers - 1 <= 128
+
     def _classifier_fwd(self, emb):
         ''' `model.py:285-292`; the gradient reversal is an identity here and a sign flip in `_backward` '''
         P, pre = self._P, 'speaker_classifier.classifier'
-        if ops.USE_FUSED_HEADS:
+        if self._fused_classifier():
             logits, h1, h2 = ops.classifier_fwd(emb, P[f'{pre}.1.linear_layer.weight'], P[f'{pre}.1.linear_layer.bias'], P[f'{pre}.3.linear_layer.weight'],
                                                 P[f'{pre}.3.linear_layer.bias'], P[f'{pre}.5.linear_layer.weight'], P[f'{pre}.5.linear_layer.bias'])
             return logits, (emb, h1, h2)
@@ -751,7 +708,7 @@ class DaftExprt(nn.Module):
             self._hard = {input_lengths.data_ptr(): (skip_in, nmax_in), output_lengths.data_ptr(): (skip_out, nmax_out)}
         self._prep(output_lengths, mel_specs.shape[2])
         self._prep(input_lengths, symbols.shape[1])
-        W = self._weights(need_dgrad=save, defer=True)
+        W = self._weights(need_dgrad=save)
         S = _Saved() if save else None
         emb, films, s_pe = self._prosody_encoder_fwd(W, frames_energy, frames_pitch, mel_specs, speaker_ids, output_lengths, train, save)
         logits, s_cls = self._classifier_fwd(emb)
@@ -772,7 +729,7 @@ class DaftExprt(nn.Module):
         ''' weight / bias gradient on the side stream: these kernels are off the critical path of the backward pass
             (nothing downstream reads dW before the optimizer step), so they overlap with the data-gradient chain. '''
         side = self._side_stream
-        if _SKIP_WGRAD:                                 # development ablation: how much does the overlap cost the main stream?
+        if config.SKIP_WGRAD:                           # measurement protocol (DESIGN 5): what the side-stream work costs the step
             return
         if side is None:
             return ops.conv1d_wgrad(dy, x, dw, db, self.cd, lengths)
@@ -780,24 +737,13 @@ class DaftExprt(nn.Module):
         # (`_flush_wgrads`) -- an event record + wait per weight gradient cost ~10 us of host time, 54 times per step, in
         # exactly the phoneme-level stretches of the backward pass where the GPU waits for the host
         self._wgrad_pending.append((dy, x, dw, db, lengths))
-        if dy.shape[0] * dy.shape[1] >= self._wgrad_batch_rows:   # frame-level GEMMs: the GPU is the bottleneck, start right away
-            self._flush_wgrads()
 
-    def _block_done(self, rows=1 << 30):
-        ''' end of an FFT block / conv stage of the backward pass: its queued weight gradients go to the side stream.
-            `_wgrad_defer_rows` > 0 holds the launches of small stages (phoneme level) back until the end of their section: the
-            profiler shows the launch stream starved for 60-80 us at those block boundaries while the host issues the 8 side-stream
-            launches, but deferring them is WORSE (7.99 vs 7.79 ms): the phoneme-level kernels of the main stream leave most of the
-            chip idle, which is exactly where the weight gradients run for free; deferred, they land on the frame-level kernels of
-            the prosody encoder instead '''
-        if rows < self._wgrad_defer_rows or self._hold_flush:
-            return
-        self._blocks_since_flush += 1
-        if self._blocks_since_flush >= self._wgrad_flush_blocks:
-            self._flush_wgrads()
+    def _block_done(self):
+        ''' end of an FFT block / conv stage of the backward pass: its queued weight gradients go to the side stream (measured:
+            holding the phoneme-level ones back, or flushing every 2 / 4 blocks, is slower -- they run for free exactly where they are) '''
+        self._flush_wgrads()
 
     def _flush_wgrads(self):
-        self._blocks_since_flush = 0
         pend, side = self._wgrad_pending, self._side_stream
         if not pend:
             return
@@ -807,7 +753,7 @@ class DaftExprt(nn.Module):
         # `with torch.cuda.stream(side)` block per launch cost 15 us of host time
         self._hop.record()
         side.wait_event(self._hop)
-        if ops.STEP_PTR is not None and _CAPTURE_ORDER == 'defer':
+        if ops.STEP_PTR is not None:
             # CAPTURING.  The graph executor keeps the FIRST node recorded behind a fork on the forking node's hardware queue and moves
             # the others to another one: with the weight gradients recorded first, the data-gradient chain hopped queues at every
             # fork and queued up behind weight-gradient kernels (8.57 vs 7.97 ms per replayed step).  So the side-stream launches of
@@ -817,8 +763,6 @@ class DaftExprt(nn.Module):
             self._side_deferred = pend
             ops.H.AFTER_LAUNCH = self._issue_deferred
             return
-        if ops.STEP_PTR is not None and _CAPTURE_ORDER == 'anchor':   # the same with an empty launch as the first node (dx_anchor)
-            ops.H.check(ops.H.lib().dx_anchor(ops.H.stream()))
         self._issue_side(pend)
 
     def _issue_deferred(self):
@@ -837,7 +781,7 @@ class DaftExprt(nn.Module):
         for it in pend:
             dy, x, dw, db, lengths = it
             key = (dy.shape[0], dy.shape[1], None if lengths is None else lengths.data_ptr())
-            if ops.USE_WGRAD_MULTI and ops.WGRAD_WORKSPACE and groups and groups[-1][0] == key and len(groups[-1][1]) < ops.WGRAD_MULTI_MAX:
+            if ops.WGRAD_WORKSPACE and groups and groups[-1][0] == key and len(groups[-1][1]) < ops.WGRAD_MULTI_MAX:
                 groups[-1][1].append(it)
             else:
                 groups.append((key, [it]))
@@ -848,7 +792,7 @@ class DaftExprt(nn.Module):
         probe = ops.PROBE is not None
         for _, items in groups:
             lengths = items[0][4]
-            if len(items) > 1 or (ops.USE_WGRAD_MULTI and ops.WGRAD_WORKSPACE):
+            if len(items) > 1 or ops.WGRAD_WORKSPACE:
                 call = lambda **kw: ops.conv1d_wgrad_multi([(dy, x, dw, db) for dy, x, dw, db, _ in items], self.cd, lengths, ws=self._wgrad_ws, **kw)
             else:
                 dy, x, dw, db, _ = items[0]
@@ -863,18 +807,14 @@ class DaftExprt(nn.Module):
             for dy, x, dw, db, _ in items:
                 self._wgrad_keep.append((dy, x))
 
-    def _fft_stack_bwd(self, W, blocks, du, dfilms, hold=0):
-        ''' backward through a stack of FFT blocks, top block first.  dfilms: (B, nb_blocks, 2C) gradient view or None.
-            hold: the weight gradients of the LAST `hold` blocks of the walk (blocks hold-1 .. 0) stay queued until the caller's
-            next flush (`done()`): see DX_WGRAD_HOLD_DEC '''
+    def _fft_stack_bwd(self, W, blocks, du, dfilms):
+        ''' backward through a stack of FFT blocks, top block first.  dfilms: (B, nb_blocks, 2C) gradient view or None. '''
         pre = None
         for blk in reversed(range(len(blocks))):
             below = blocks[blk - 1] if blk > 0 else None
             dfilm = dfilms[:, blk, :] if dfilms is not None else None
             dfilm_below = dfilms[:, blk - 1, :] if (dfilms is not None and blk > 0) else None
-            self._hold_flush = blk < hold
             du, pre = self._fft_block_bwd(W, blocks[blk], du, dfilm, pre, below, dfilm_below)
-        self._hold_flush = False
         return du
 
     def _fft_block_bwd(self, W, s, du, dfilm, pre=None, below=None, dfilm_below=None):
@@ -925,14 +865,13 @@ class DaftExprt(nn.Module):
             dz_below = ops.conv1d_lnbwd(dqkv, W[f'T:{mha}.in_proj_weight'], dx, below.s2, below.mean2, below.rstd2,
                                         P[f'{fb}.layer_norm.weight'], P[f'{fb}.layer_norm.bias'], below.lengths,
                                         G[f'{fb}.layer_norm.weight'], G[f'{fb}.layer_norm.bias'], film=below.film, dfilm=dfilm_below,
-                                        p_pre=below.p_conv, seed_pre=below.seeds[2],
-                                        plan=self._plan(below.lengths, dqkv.shape[1]) if self._plan_k1 else None)
-            self._block_done(dqkv.shape[0] * dqkv.shape[1])
+                                        p_pre=below.p_conv, seed_pre=below.seeds[2])
+            self._block_done()
             if self._trace_bwd is not None:              # dx = dL/d(s2 of the block below): its LayerNorm backward ran in the launch above
                 self._trace_bwd.append(('fft_block', s, below, cap_in, dx.clone()))
             return dx, (dx, dz_below)
         ops.conv1d(dqkv, W[f'T:{mha}.in_proj_weight'], None, out=dx, accumulate=True, skip_lengths=s.lengths)
-        self._block_done(dqkv.shape[0] * dqkv.shape[1])
+        self._block_done()
         if self._trace_bwd is not None:                  # dx = dL/d(block input)
             self._trace_bwd.append(('fft_block', s, None, cap_in, dx.clone()))
         return dx, None
@@ -952,7 +891,7 @@ class DaftExprt(nn.Module):
                 self._trace_bwd.append(('conv_ln', s, None, dy.clone(), None))     # no data gradient: the input needs none
             return None
         self._wgrad(dc, s.x, G[f'{s.conv_name}.conv.weight'], G[f'{s.conv_name}.conv.bias'], lengths_hint)
-        self._block_done(dc.shape[0] * dc.shape[1])
+        self._block_done()
         if dx_out is not None:
             if self._trace_bwd is not None:
                 self._trace_bwd.append(('conv_ln', s, None, dy.clone(), None))     # the data gradient is accumulated into dx_out: not separable
@@ -967,15 +906,9 @@ class DaftExprt(nn.Module):
     def ensure_side_stream(self):
         ''' the weight-gradient stream (created once, with the launch stream of the first backward pass current) '''
         if self._side is None:
-            # DX_WGRAD_PRIO: stream priority of the weight-gradient stream (default: the runtime's default; 'low' = the lowest the device
-            # offers, so that the dispatcher prefers the data-gradient chain whenever both streams have workgroups waiting)
-            prio = __import__('os').environ.get('DX_WGRAD_PRIO', '')
-            lo = None
-            if prio == 'low':
-                lo, _hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, 'priority_range') else (0, 0)
             # a stream on ANOTHER hardware queue than the launch stream (probed, `streams.pick`: after RCCL has taken its streams from
             # torch's pool the next pool stream can share the launch stream's queue, and the weight gradients would run in line)
-            self._side = streams.pick([torch.cuda.current_stream()], priority=lo, what='weight-gradient stream')
+            self._side = streams.pick([torch.cuda.current_stream()], what='weight-gradient stream')
             self._hop = torch.cuda.Event()
         return self._side
 
@@ -984,7 +917,7 @@ class DaftExprt(nn.Module):
             d_mel: (B, n_mel, T) like the output, or (B, T, n_mel) when d_mel_is_bt.
             section_done(name): called as soon as every gradient of a top-level module is final, in reverse
             registration order (frame_decoder first) -- the data-parallel reducer launches that slice's all-reduce. '''
-        use_side = bool(int(__import__('os').environ.get('DX_WGRAD_SIDE_STREAM', '1')))
+        use_side = config.WGRAD_SIDE_STREAM
         if use_side:
             self.ensure_side_stream()
         self._side_stream = self._side if use_side else None
@@ -1028,7 +961,7 @@ class DaftExprt(nn.Module):
             self._wgrad(d_mel_bt, dec_x, G[f'{wname}.weight'], G[f'{wname}.bias'], S.gu.output_lengths)
             self._flush_wgrads()
             d_dec = ops.conv1d(d_mel_bt, W[f'T:{wname}.weight'], None, out_dtype=torch.float32, skip_lengths=S.gu.output_lengths)
-        d_dec = self._fft_stack_bwd(W, blocks, d_dec, dfilms[2], hold=self._wgrad_hold_dec)
+        d_dec = self._fft_stack_bwd(W, blocks, d_dec, dfilms[2])
         done('frame_decoder')
         # ---- Gaussian upsampling (ground-truth durations / energy / pitch: no gradient into the predictor here)
         g = S.gu
@@ -1069,7 +1002,7 @@ class DaftExprt(nn.Module):
         pe = S.pe
         emb, h1, h2 = S.cls
         cl = 'speaker_classifier.classifier'
-        if d_spk is not None and ops.USE_FUSED_HEADS:
+        if d_spk is not None and self._fused_classifier():
             d_emb = ops.classifier_bwd(d_spk.contiguous(), emb, h1, h2, P[f'{cl}.1.linear_layer.weight'], P[f'{cl}.3.linear_layer.weight'],
                                        P[f'{cl}.5.linear_layer.weight'], float(hp.lambda_reversal), G[f'{cl}.1.linear_layer.weight'],
                                        G[f'{cl}.1.linear_layer.bias'], G[f'{cl}.3.linear_layer.weight'], G[f'{cl}.3.linear_layer.bias'],

@@ -1,15 +1,15 @@
 """Thin Python wrappers over the C ABI (include/daft_exprt_hip.h): allocate outputs with torch
 (device-memory plumbing only), pass raw pointers + the current HIP stream.  One function per entry point."""
 import ctypes
-import os
 
 import torch
 
 from daft_exprt import _hip as H
+from daft_exprt import config
 
 _INF = float('inf')
 DETERMINISTIC_LN = False
-WGRAD_WORKSPACE = bool(int(os.environ.get('DX_WGRAD_WORKSPACE', '1')))   # 0: fp32 atomics on dW instead of partial tiles + reduce
+WGRAD_WORKSPACE = True   # False: fp32 atomics on dW instead of partial tiles + fixed-order reduce (tests compare the two)
 
 # Device pointer of the step block (DxStepScalars, include/daft_exprt_hip.h) while a step is being CAPTURED into a hipGraph
 # (`train.CapturedStep`): the dropout kernels add its salt to their by-value seeds, Adam and the loss read this iteration's learning
@@ -79,8 +79,6 @@ def pack_conv_weight(w, dtype, transpose_flip=False, out=None):
     return out
 
 
-USE_WFRAG = bool(int(os.environ.get('DX_CONV_WFRAG', '1')))   # 0: the register-weights kernel stages its weights through LDS (A/B switch)
-USE_WIDE = bool(int(os.environ.get('DX_CONV_WIDE', '1')))   # 0: the 1024 -> 1024 k = 3 GEMMs stay on conv_gemm_kernel (A/B switch)
 
 
 def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, mask_lengths=None,
@@ -96,7 +94,7 @@ def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, m
     assert Cin_w == Cin, (Cin_w, Cin)
     assert x.stride(2) == 1 and (B == 1 or x.stride(0) == N * x.stride(1))
     out_dtype = out_dtype or x.dtype
-    if (w_frag is not None and wide_plan is not None and USE_WIDE and taps == 3 and x.dtype == torch.bfloat16 and out_dtype == torch.bfloat16
+    if (w_frag is not None and wide_plan is not None and taps == 3 and x.dtype == torch.bfloat16 and out_dtype == torch.bfloat16
             and out is None and relu_gate is None and mask_lengths is None and skip_lengths is not None and not transposed_out
             and Cin % 128 == 0 and Cin >= 256 and Cout % 256 == 0):
         table, pb, pn = wide_plan
@@ -111,7 +109,7 @@ def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, m
         out = torch.empty((B, Cout, N) if transposed_out else (B, N, Cout), dtype=out_dtype, device=x.device)
     flags = (H.CONV_RELU if relu else 0) | (H.CONV_TRANSPOSED_OUT if transposed_out else 0) | (4 if accumulate else 0)
     frag = None
-    if w_frag is not None and USE_WFRAG and taps == 3 and Cin == 128 and w_packed.dtype == torch.bfloat16:
+    if w_frag is not None and taps == 3 and Cin == 128 and w_packed.dtype == torch.bfloat16:
         assert w_frag.dtype == torch.bfloat16 and w_frag.numel() == w_packed.numel()
         frag = w_frag                                 # register-weights kernel: fragments straight into registers (dx_conv1d_wfrag)
     with _probe('conv_gemm', lambda: 2. * B * N * Cin * Cout * taps, N):
@@ -120,9 +118,6 @@ def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, m
                                     H.dt(relu_gate) if relu_gate is not None else 0,
                                     H.ptr(mask_lengths), H.ptr(skip_lengths), B, N, Cin, Cout, taps, flags, H.stream()))
     return out
-
-
-USE_GEMM2_FWD = bool(int(os.environ.get('DX_LN_GEMM2', '1')))   # 0: the next block's QKV projection stays a launch of its own (A/B switch)
 
 
 def conv1d_ln(x, w_packed, bias, residual, gamma, beta, lengths, film=None, save=False, p_pre=0., seed_pre=0, lp_copy=False, plan=None,
@@ -143,7 +138,7 @@ def conv1d_ln(x, w_packed, bias, residual, gamma, beta, lengths, film=None, save
     rstd = torch.empty(B * N, dtype=torch.float32, device=dev) if save else None
     pargs = _plan_args(plan, x, w_packed, B, N, w_frag=w_frag)
     y2, n2 = None, 0
-    if (w2_packed is not None and USE_GEMM2_FWD and lp_copy and pargs[2] is not None and taps == 3 and Cin % 128 == 0 and B * N <= 65536
+    if (w2_packed is not None and lp_copy and pargs[2] is not None and taps == 3 and Cin % 128 == 0 and B * N <= 65536
             and w2_packed.dtype == torch.bfloat16 and w2_packed.shape[0] == 1 and w2_packed.shape[2] == 128 and w2_packed.shape[1] in (128, 384)):
         n2 = w2_packed.shape[1]
         y2 = torch.empty((B, N, n2), dtype=torch.bfloat16, device=dev)
@@ -156,9 +151,6 @@ def conv1d_ln(x, w_packed, bias, residual, gamma, beta, lengths, film=None, save
     if w2_packed is not None:
         return y, y_lp, s_out, mean, rstd, y2
     return y, y_lp, s_out, mean, rstd
-
-
-USE_GEMM2 = bool(int(os.environ.get('DX_LNBWD_GEMM2', '1')))   # 0: the output-projection data gradient stays a launch of its own (A/B switch)
 
 
 def conv1d_lnbwd(x, w_packed, y_inout, s_in, mean, rstd, gamma, beta, lengths, dgamma, dbeta, film=None, dfilm=None,
@@ -176,7 +168,7 @@ def conv1d_lnbwd(x, w_packed, y_inout, s_in, mean, rstd, gamma, beta, lengths, d
     lddf = dfilm.stride(0) if dfilm is not None else 0
     pargs = _plan_args(plan, x, w_packed, B, N, k1_ok=True, w_frag=w_frag)
     y2 = None
-    if (w2_packed is not None and USE_GEMM2 and pargs[2] is not None and taps == 3 and Cin % 128 == 0 and B * N <= 65536
+    if (w2_packed is not None and pargs[2] is not None and taps == 3 and Cin % 128 == 0 and B * N <= 65536
             and w2_packed.dtype == torch.bfloat16 and tuple(w2_packed.shape) == (1, 128, 128)):
         y2 = torch.empty((B, N, 128), dtype=torch.bfloat16, device=x.device)
     with _probe('conv_gemm', lambda: 2. * B * N * Cin * Cout * taps + (2. * B * N * 128 * 128 if y2 is not None else 0.), N):
@@ -242,7 +234,7 @@ def _plan_args(plan, x, w_packed, B, N, k1_ok=False, w_frag=None):
     return H.ptr(table), table.shape[0], frag
 
 
-USE_SPLITK = bool(int(os.environ.get('DX_CONV_SPLITK', '1')))   # 0: the LayerNorm-fused k = 3 GEMMs stay on the ring kernel (A/B switch)
+USE_SPLITK = True   # False: the LayerNorm-fused k = 3 GEMMs stay on the ring kernel (tests compare the two)
 
 
 def pack_frag_major(w_packed, out=None):
@@ -316,7 +308,6 @@ class _WgradDesc(ctypes.Structure):
 
 
 WGRAD_MULTI_MAX = 8
-USE_WGRAD_MULTI = bool(int(os.environ.get('DX_WGRAD_MULTI', '1')))   # 0: one dx_conv1d_wgrad call (GEMM + reduce launch) per weight (A/B switch)
 
 
 def conv1d_wgrad_multi(items, compute_dtype, lengths, stream=None, ws=None):
@@ -517,7 +508,7 @@ def film_assemble_bwd(g_raw, b_raw, post, dfilms, dpost, nb, ch):
     return dg, db
 
 
-USE_FUSED_HEADS = bool(int(os.environ.get('DX_FUSED_HEADS', '1')))   # 0: the FiLM head / speaker classifier as their separate small launches (A/B switch)
+USE_FUSED_HEADS = True   # False: the FiLM head / speaker classifier as their separate small launches (tests compare the two)
 
 
 def film_head_fwd(emb, spk_table, spk_ids, wg, bg, wb, bb, post, nb, ch):
@@ -734,6 +725,7 @@ def adam_pack_table(weights, flats, device):
     ptr = lambda t: 0 if t is None else t.data_ptr()
     arr, begin = np.zeros(len(weights), dtype=bd), 0
     for i, (off, (cout, cin, taps), fwd, tr, ffwd, ftr) in enumerate(weights):
+        assert taps in (1, 3), f'adam_pack_table: a GEMM weight with {taps} taps (the brick kernel holds 1 or 3 taps per 32 x 32 brick)'
         if ffwd is not None or ftr is not None:
             assert taps == 3 and cout % 32 == 0 and cin % 32 == 0
         arr[i] = (off, ptr(fwd), ptr(tr), ptr(ffwd), ptr(ftr), cout, cin, taps, 0, begin)

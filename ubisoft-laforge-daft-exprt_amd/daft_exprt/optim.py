@@ -21,7 +21,7 @@ class FusedAdam(object):
         self.grad_norm_sq = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self.step_count = 0
         self.grad_clip_thresh = grad_clip_thresh
-        self.fuse_pack = bool(int(__import__('os').environ.get('DX_ADAM_PACK', '1')))   # 0: flat Adam, copies refreshed by the pack launches of the next step
+        self.fuse_pack = True   # False: flat Adam launch, operand copies refreshed by the pack launches of the next step (tests compare the two)
         self.param_groups = [{'lr': lr, 'betas': tuple(betas), 'eps': eps, 'weight_decay': weight_decay, 'amsgrad': False,
                               'params': list(range(len(model._table)))}]
 

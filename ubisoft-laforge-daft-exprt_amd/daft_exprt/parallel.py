@@ -17,10 +17,10 @@ What this build does instead, with the same mathematics (sum of per-rank mean gr
 xGMI is point-to-point (7 links per GPU): a few large messages per step (3.4-30 MB) keep every link busy;
 tiny sections are merged with their neighbour so that nothing below ~1 MB goes out on its own.
 """
-import os
-
 import torch
 import torch.distributed as dist
+
+from daft_exprt import config
 
 
 class GradReducer(object):
@@ -30,7 +30,7 @@ class GradReducer(object):
         # the collectives are issued when there is more than one rank -- or, with DX_FORCE_DIST=1, also inside a ONE-rank process group:
         # a 1-GPU box can then drive the complete multi-rank code path (RCCL communicator, asynchronous all-reduce per bucket,
         # stream-ordered `work.wait()`, per-bucket Adam) on real RCCL (tests/test_gpu_ddp.py)
-        self.active = dist.is_initialized() and (self.world > 1 or os.environ.get('DX_FORCE_DIST', '0') == '1')
+        self.active = dist.is_initialized() and (self.world > 1 or config.force_dist())
         slices = model.section_slices()
         # buckets in backward order (reverse registration order); merge small sections into the next one
         order = [s for s in reversed(model.SECTIONS) if s in slices]
@@ -57,7 +57,7 @@ class GradReducer(object):
             RCCL ("nccl") only; collective over all ranks. '''
         from daft_exprt import streams
         self.queue_probe = None
-        if not self.active or dist.get_backend(self.group) != 'nccl' or os.environ.get('DX_STREAM_PROBE', '1') == '0':
+        if not self.active or dist.get_backend(self.group) != 'nccl' or not config.STREAM_PROBE:
             return None
         dev = beside[0].device
         group = self.group
@@ -69,7 +69,10 @@ class GradReducer(object):
                 self.group, self.queue_probe = group, f'own hardware queue (group {attempt + 1})'
                 return True
             if attempt + 1 < tries:
-                group = dist.new_group(backend='nccl')
+                ranks = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
+                rejected, group = group, dist.new_group(ranks=ranks, backend='nccl')    # (collective over the whole world: every rank gets here)
+                if rejected is not None and rejected is not self.group and rejected is not dist.group.WORLD:
+                    dist.destroy_process_group(rejected)     # a communicator that failed the probe: its streams and buffers go
         self.group, self.queue_probe = group, f'SHARES a hardware queue with the launch or weight-gradient stream after {tries} groups'
         return False
 

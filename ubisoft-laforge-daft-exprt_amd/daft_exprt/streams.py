@@ -14,6 +14,7 @@ import os
 import torch
 
 from daft_exprt import _hip as H
+from daft_exprt import config
 
 PROBE_US = 1500
 
@@ -43,7 +44,7 @@ def pick(beside, device=None, priority=None, tries=12, what='stream'):
         (with a warning on stderr) when none of `tries` pool streams qualifies -- e.g. GPU_MAX_HW_QUEUES=1. '''
     device = beside[0].device if device is None else device
     capturing = getattr(torch.cuda, 'is_current_stream_capturing', lambda: False)()     # (a probe synchronises: never inside a capture)
-    if os.environ.get('DX_STREAM_PROBE', '1') == '0' or capturing:
+    if not config.STREAM_PROBE or capturing:
         return torch.cuda.Stream(device=device) if priority is None else torch.cuda.Stream(device=device, priority=priority)
     cand = None
     for k in range(tries):

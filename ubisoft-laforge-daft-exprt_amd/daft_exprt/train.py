@@ -33,7 +33,7 @@ from daft_exprt.data_loader import DaftExprtDataCollate, GroupedBatch, Synthetic
 from daft_exprt.hparams import HyperParams
 from daft_exprt.loss import DaftExprtLoss, KEYS
 from daft_exprt.model import DaftExprt
-from daft_exprt import ops, streams
+from daft_exprt import config, ops, streams
 from daft_exprt.optim import FusedAdam
 from daft_exprt.parallel import GradReducer
 
@@ -108,7 +108,7 @@ class Trainer(object):
                                    grad_clip_thresh=hparams.grad_clip_thresh)
         self.reducer = GradReducer(model)     # also on one rank: its bucket table drives the per-section optimizer
         if self.reducer.active:
-            if model.flat_parameters().is_cuda and int(os.environ.get('DX_WGRAD_SIDE_STREAM', '1')):
+            if model.flat_parameters().is_cuda and config.WGRAD_SIDE_STREAM:
                 # launch stream, weight-gradient stream and RCCL's stream on three different hardware queues (probed, `streams.py`)
                 self.reducer.pick_group([torch.cuda.current_stream(), model.ensure_side_stream()])
             self.reducer.broadcast_parameters()
@@ -123,7 +123,7 @@ class Trainer(object):
         # per-bucket Adam behind each bucket's all-reduce: default on with several ranks (it hides the optimizer pass and the wait for
         # the last all-reduce); on ONE GPU the slice updates only compete with the backward kernels for HBM (measured 8.29 vs 8.08 ms
         # per step), so the whole-buffer step (one launch, gradient norm summed on the way) stays the default there
-        mode = os.environ.get('DX_SECTIONED_ADAM', 'auto')
+        mode = config.sectioned_adam()
         assert self.reducer.world == world_size, f'Trainer(world_size={world_size}) inside a process group of {self.reducer.world} ranks'
         # the per-bucket update orders itself behind the collective through `work.wait()`, which is a STREAM wait only with RCCL
         # (backend "nccl"); gloo's wait blocks the host inside the backward hook and would stall kernel issue for the rest of the
@@ -140,7 +140,7 @@ class Trainer(object):
         # from B = 16 up (7.73 vs 7.69 ms at B = 48, 13.2 vs 13.0 ms for 16 x 3): the dispatch boundaries cost the same ~2 us on the GPU
         # side whether the host or the graph executor feeds them, and at these sizes the host keeps ahead of the device.  It wins below
         # (3.88 vs 4.05 ms at B = 8).
-        use_graph = os.environ.get('DX_STEP_GRAPH', '0')
+        use_graph = config.step_graph()
         self.captured = CapturedStep(self, auto=(use_graph == 'auto')) if (not self.reducer.active and use_graph != '0' and
                                                                            model.flat_parameters().is_cuda) else None
 
@@ -178,6 +178,8 @@ class Trainer(object):
             Returns (terms (8,) device tensor summed over micro-batches / accumulation_steps, grad_norm_sq device scalar).
             The tensors may live in buffers a later call overwrites (captured steps reuse theirs): consume them -- or enqueue the
             copy that does -- before the next call. '''
+        if self.group and len(micro_batches) > 1 and self.model.flat_parameters().is_cuda:
+            micro_batches = [self._grouped(micro_batches)]     # (outside a capture: the concatenation is input staging)
         if self.captured is not None and not self.reducer.active and not self.sectioned:
             return self.captured.step(micro_batches, iteration)
         return self.step_eager(micro_batches, iteration)
@@ -196,7 +198,7 @@ class Trainer(object):
         if self._sectioned_now:
             if self._opt_stream is None:
                 # on hardware queues of their own (probed): beside the launch stream and the weight-gradient stream
-                side = model.ensure_side_stream() if int(os.environ.get('DX_WGRAD_SIDE_STREAM', '1')) else None
+                side = model.ensure_side_stream() if config.WGRAD_SIDE_STREAM else None
                 beside = [torch.cuda.current_stream()] + ([side] if side is not None else [])
                 self._opt_stream, self._sec_event = streams.pick(beside, what='optimizer stream'), torch.cuda.Event()
             self.optimizer.begin_step()     # step count, zeroed norm accumulator: on the compute stream, ahead of every slice update
@@ -236,9 +238,10 @@ class CapturedStep(object):
         rate, Adam's bias corrections, the adversarial loss weight -- `ops.STEP_PTR`), there is no host sync inside the step, the
         side-stream weight gradients fork from and join the launch stream inside the step, and every buffer the step allocates
         comes from the graph's private pool.  A graph is keyed on the ADDRESSES and shapes of the step's input tensors (it reads
-        them in place: no staging copies) and on the accumulation count; a key is captured the second time it is seen, so ragged
-        real data -- a new (L_max, T_max) almost every batch -- simply stays on the eager path, while resident batches and
-        fixed-shape loaders (whose batches cycle through a few allocator blocks) replay.  At most `max_graphs` graphs are kept, each
+        them in place: no staging copies; the graph pins them, so a key can only come back when the CALLER re-uses the same tensors)
+        and on the accumulation count; a key is captured the second time it is seen.  What replays are RESIDENT batches (bench, tests,
+        a caller that stages every batch into fixed input buffers); batches from a loader get fresh allocations and simply stay on
+        the eager path.  At most `max_graphs` graphs are kept, each
         owning its activations (~4 GB at B = 48, T = 1000); a full cache only gives up its least recently replayed graph when that
         graph has been idle for 4 x max_graphs steps (a round-robin over more keys than slots would otherwise re-capture every step).
 
@@ -247,7 +250,7 @@ class CapturedStep(object):
 
     def __init__(self, trainer, max_graphs=None, capture_after=2, auto=False):
         self.tr, self.auto = trainer, auto
-        self.max_graphs = int(os.environ.get('DX_STEP_GRAPH_MAX', '8')) if max_graphs is None else max_graphs
+        self.max_graphs = config.STEP_GRAPH_MAX if max_graphs is None else max_graphs
         self.capture_after = capture_after
         self.cache, self.seen = {}, {}
         self.block = None            # DxStepScalars on the device
@@ -256,7 +259,8 @@ class CapturedStep(object):
 
     @staticmethod
     def key(micro_batches):
-        return tuple((t.data_ptr(), tuple(t.shape)) for inputs, _ in micro_batches for t in inputs)
+        # (targets too: the loss reads them in place -- normally views of the inputs, but nothing forces a caller to pass those)
+        return tuple((t.data_ptr(), tuple(t.shape)) for mb in micro_batches for t in tuple(mb[0]) + tuple(mb[1]))
 
     def step(self, micro_batches, iteration):
         tr = self.tr
@@ -341,6 +345,13 @@ class CapturedStep(object):
             self.broken = f'{type(e).__name__}: {e}'
             _logger.warning(f'step capture failed, staying on eager launches: {self.broken}')
             torch.cuda.synchronize(dev)
+            # stream-side state the aborted capture touched: events recorded on a capturing stream are invalid outside it, the queued
+            # weight gradients and their pinned operands belong to launches that never ran
+            model._wgrad_pending, model._side_deferred = [], None
+            model._wgrad_keep.clear()
+            model._hop = torch.cuda.Event() if model._hop is not None else None
+            tr._sec_event = torch.cuda.Event() if tr._sec_event is not None else None
+            opt._all_packed, opt._covered = True, 0
             return None
         finally:
             if gc_was_on:
@@ -351,7 +362,7 @@ class CapturedStep(object):
             model.mark_updated()
         self.captures += 1
         ent = self.cache[key] = {'graph': graph, 'terms': terms, 'gnorm_sq': gnorm_sq, 'tick': self.ticks, 'outputs': model.last_outputs,
-                                 'keep': (own_ws, graph_ws, [t for mb in micro_batches for t in mb[0]])}
+                                 'keep': (own_ws, graph_ws, [t for mb in micro_batches for t in tuple(mb[0]) + tuple(mb[1])])}
         return ent
 
 
