@@ -136,7 +136,9 @@ def test_trainer_step_grouped_equals_three_passes():
     (t0, n0, p0), (t1, n1, p1) = res
     assert torch.allclose(t0, t1, rtol=1e-4, atol=1e-6), (t0.tolist(), t1.tolist())
     assert torch.allclose(n0, n1, rtol=1e-3)
-    # Adam's first steps move every weight by ~lr whatever the gradient's size: compare against that scale
-    lr = 1e-4
-    assert float((p0 - p1).abs().max()) <= 0.5 * lr, float((p0 - p1).abs().max())
-    assert float(((p0 - p1).abs() > 0.02 * lr).float().mean()) < 2e-3
+    # Adam's first steps move every weight by ~lr whatever the gradient's size, so a gradient element at atomics-noise level can flip
+    # its sign between the two schedules: bounded by 2 lr per step on a vanishing share of the weights, everything else agrees
+    lr, d = 1e-4, (p0 - p1).abs()
+    share = float((d > 0.02 * lr).float().mean())
+    assert float(d.max()) <= 2 * 2 * lr * 1.05, float(d.max())
+    assert share < 2e-3, share

@@ -186,7 +186,7 @@ def test_unsupported_widths_and_bad_ids_are_rejected_up_front():
     with pytest.raises(NotImplementedError):
         DaftExprt(hp)
     hp = make_hparams()
-    hp.prosody_encoder['attn_nb_heads'] = 4
+    hp.prosody_encoder['attn_nb_heads'] = 3      # (8, 4, 2, 1 heads have kernels)
     with pytest.raises(NotImplementedError):
         DaftExprt(hp)
     hp = make_hparams()

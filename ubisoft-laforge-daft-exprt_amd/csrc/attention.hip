@@ -1036,11 +1036,13 @@ template <typename TC>
 int launch_fwd(const AttnArgs& a0, int B, int dh, hipStream_t s) {
   AttnArgs a = a0;
   a.B = B;
-  a.gx = dx_cdiv(a.N, dh == 64 ? 128 / Split<64>::value : 128);
+  a.gx = dx_cdiv(a.N, dh >= 64 ? 128 / Split<64>::value : 128);
   dim3 grid(attn_grid(B, a.gx * a.H)), block(256);
   if (dh == 16) hipLaunchKernelGGL((attn_fwd_kernel<TC, 16>), grid, block, 0, s, a);
   else if (dh == 64) hipLaunchKernelGGL((attn_fwd_kernel<TC, 64>), grid, block, 0, s, a);
-  else { dx_set_error("attention: head dim %d unsupported (16, 64)", dh); return DX_ERR_UNSUPPORTED; }
+  else if (dh == 32) hipLaunchKernelGGL((attn_fwd_kernel<TC, 32>), grid, block, 0, s, a);      // 4 heads of a 128-wide model: the generic
+  else if (dh == 128) hipLaunchKernelGGL((attn_fwd_kernel<TC, 128>), grid, block, 0, s, a);   // templates, not tuned (1 head)
+  else { dx_set_error("attention: head dim %d unsupported (16, 32, 64, 128)", dh); return DX_ERR_UNSUPPORTED; }
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
@@ -1053,7 +1055,7 @@ template <typename TC>
 int launch_bwd(const AttnArgs& a0, int B, int dh, float* delta, int algo, hipStream_t s) {
   AttnArgs a = a0;
   a.B = B;
-  a.gx = dx_cdiv(a.N, dh == 64 ? 128 / Split<64>::value : 128);
+  a.gx = dx_cdiv(a.N, dh >= 64 ? 128 / Split<64>::value : 128);
   const bool can_fuse = std::is_same<TC, bf16_t>::value && dh == 16 && a.N <= FB_MAXN;
   if (algo == DX_ATTN_FUSED && !can_fuse) {
     dx_set_error("dx_attention_bwd: the fused kernel needs bf16, d_head 16, N <= %d (got d_head %d, N %d)", FB_MAXN, dh, a.N);
@@ -1072,7 +1074,13 @@ int launch_bwd(const AttnArgs& a0, int B, int dh, float* delta, int algo, hipStr
   } else if (dh == 64) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, 64>), grid, block, 0, s, a);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<TC, 64>), grid, block, 0, s, a);
-  } else { dx_set_error("attention: head dim %d unsupported (16, 64)", dh); return DX_ERR_UNSUPPORTED; }
+  } else if (dh == 32) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, 32>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<TC, 32>), grid, block, 0, s, a);
+  } else if (dh == 128) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<TC, 128>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<TC, 128>), grid, block, 0, s, a);
+  } else { dx_set_error("attention: head dim %d unsupported (16, 32, 64, 128)", dh); return DX_ERR_UNSUPPORTED; }
   DX_LAUNCH_CHECK();
   return DX_OK;
 }

@@ -225,6 +225,8 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
   // padding early-out: a tile that starts past length + conv halo cannot reach a valid output -> zeros, no MFMA
   if (!PLAN && p.skip_len && n0 >= (int)p.skip_len[b] + 2) {
     if (RING && tid >= NTHREADS) return;             // loader waves
+    if (!trans && n0 >= dx_fill_end((int)p.skip_len[b], N)) return;   // past the fill end: nobody reads these rows (dx_common.h); the
+                                                                        // transposed (B, C, N) form is the user-visible mel: fully padded
     if (LN == 2) {   // incoming residual gradient rows are zero there and stay; the bf16 dx_pre rows must exist as zeros
       float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       for (int c = tid; c < BM * (BN / 8); c += NTHREADS) {
@@ -355,7 +357,9 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
             const int src_lane = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
             const int fb = base + src_lane;
-            const int first = __shfl(N - dead + (int)(fs - ustart), src_lane, 64), cnt = __shfl((int)(fe - fs), src_lane, 64);
+            const int first = __shfl(N - dead + (int)(fs - ustart), src_lane, 64);
+            int cnt = __shfl((int)(fe - fs), src_lane, 64);
+            cnt = min(cnt, dx_fill_end((int)p.skip_len[fb], N) - first);   // dead rows past the fill end stay unwritten (dx_common.h)
             float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             for (int c = ltid; c < cnt * (BN / 8); c += NTHREADS) {
               const int n = first + (c >> 4), cl = (c & 15) * 8;
@@ -1134,9 +1138,10 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
     }
     const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int j = j0; j < j1; ++j) {
-      for (int c = tid; c < BM * (WR_BN / 8); c += WR_THREADS) {
+      const int fend = db < p.B ? dx_fill_end((int)p.skip_len[db], N) : 0;   // dead tiles past the fill end stay unwritten (dx_common.h)
+      for (int c = tid; c < BM * (WR_BN / 8) && dpt * BM < fend; c += WR_THREADS) {
         const int n = dpt * BM + (c >> 5), co = cblk + (c & 31) * 8;
-        if (n < N) store8<TO>(Y + ((size_t)db * N + n) * p.ldy + co, z);
+        if (n < fend) store8<TO>(Y + ((size_t)db * N + n) * p.ldy + co, z);
       }
       if (++dpt >= ptiles) { ++db; while (db < p.B && live_of(db) >= ptiles) ++db; dpt = db < p.B ? live_of(db) : 0; }
     }
@@ -1623,7 +1628,9 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
         const int src_lane = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
         const int fb = base + src_lane;
-        const int first = __shfl(N - dead + (int)(fs - ustart), src_lane, 64), cntr = __shfl((int)(fe - fs), src_lane, 64);
+        const int first = __shfl(N - dead + (int)(fs - ustart), src_lane, 64);
+        int cntr = __shfl((int)(fe - fs), src_lane, 64);
+        cntr = min(cntr, dx_fill_end((int)p.skip_len[fb], N) - first);   // dead rows past the fill end stay unwritten (dx_common.h)
         float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (p.ln.y2) {                                   // rows of the second GEMM's output (n2 channels, bf16)
           const int segs = p.ln.n2 >> 3;
@@ -1845,7 +1852,9 @@ __global__ __launch_bounds__(WD_THREADS, 1) void conv_wide_kernel(ConvArgs p) {
         const int src_lane = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
         const int fb = base + src_lane;
-        const int first = __shfl(N - dead + (int)(fs - ustart), src_lane, 64), cntr = __shfl((int)(fe - fs), src_lane, 64);
+        const int first = __shfl(N - dead + (int)(fs - ustart), src_lane, 64);
+        int cntr = __shfl((int)(fe - fs), src_lane, 64);
+        cntr = min(cntr, dx_fill_end((int)p.skip_len[fb], N) - first);   // dead rows past the fill end stay unwritten (dx_common.h)
         const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int c = tid; c < cntr * 32; c += WD_THREADS)
           store8<bf16_t>(Y + ((size_t)fb * N + first + (c >> 5)) * p.ldy + ct * 256 + (c & 31) * 8, z);

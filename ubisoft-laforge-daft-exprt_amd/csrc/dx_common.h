@@ -35,6 +35,16 @@ void dx_set_error(const char* fmt, ...);
   } while (0)
 
 __host__ __device__ static inline int dx_cdiv(int a, int b) { return (a + b - 1) / b; }
+// Dead rows -- rows of an utterance at or past its live end (length + conv halo) -- never reach a valid output; they only have to EXIST as
+// finite values (zeros) as far as a consumer's last tile can reach.  Consumers read rows in tiles of at most 256 rows (+ 1 halo row) that
+// start below length + 2, so producers zero-fill dead rows only below dx_fill_end(); rows past it are never read and stay UNWRITTEN
+// (before: every frame-level kernel wrote all padding rows of a T <= 1000 batch, 38 % of its rows, as zeros -- ~2.4 GB per step).
+// `len` is the entry of the lengths tensor the producer was handed: the true length, or min(length, n_max - 2) inside a grouped step
+// (never more than 2 below the length), hence the + 4.  User-visible outputs (mel, predictions, alignments) keep their full zero padding.
+__host__ __device__ static inline int dx_fill_end(int len, int N) {
+  const int f = (((len < 0 ? 0 : len) + 4 + 255) & ~255) + 1;
+  return f < N ? f : N;
+}
 
 // ---- device helpers -------------------------------------------------------------------
 template <typename T>

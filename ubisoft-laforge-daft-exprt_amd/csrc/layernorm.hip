@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
   const TI* x = reinterpret_cast<const TI*>(a.x) + row * C;
   const uint32_t key_pre = dx_key32(dx_seed_eff(a.seed_pre, a.step), 0), key_post = dx_key32(dx_seed_eff(a.seed_post, a.step), 1);
   if (a.skip && n >= (int)a.skip[b] + 2) {   // rows past length + conv halo never reach a valid output: zeros, no reads
+    if (n >= dx_fill_end((int)a.skip[b], a.N)) return;   // ... and past the fill end nobody reads them either (dx_common.h): unwritten
     TO* y0 = reinterpret_cast<TO*>(a.y) + row * C;
     float z[L::V];
 #pragma unroll
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(256, C >= 1024 ? (FILM ? 1 : ((sizeof(TI) == 4 || s
   const float sc_pre = a.p_pre > 0.f ? 1.f / (1.f - a.p_pre) : 1.f;
   const float sc_post = a.p_post > 0.f ? 1.f / (1.f - a.p_post) : 1.f;
   const int nskip = a.skip ? (int)a.skip[b] + 2 : a.N;
+  const int nfill = a.skip ? dx_fill_end((int)a.skip[b], a.N) : a.N;
 
   constexpr int NP = REG_PARAMS ? L::EPL : 1, NF = FILM ? L::EPL : 1;
   float gam[NP], bet[NP], fg[NF];
@@ -243,6 +245,7 @@ __global__ __launch_bounds__(256, C >= 1024 ? (FILM ? 1 : ((sizeof(TI) == 4 || s
   for (int n = n_begin + wave; n < n_end; n += 4) {
     const long row = (long)b * a.N + n;
     if (n >= nskip) {   // gradient rows past length + halo are exactly zero
+      if (n >= nfill) break;   // (past the fill end nobody reads them, dx_common.h: unwritten; rows only grow from here)
       TD* ds0 = reinterpret_cast<TD*>(a.ds) + row * C;
       TD* dxp0 = a.dx_pre ? reinterpret_cast<TD*>(a.dx_pre) + row * C : nullptr;
       float z[L::V];
@@ -380,8 +383,9 @@ int launch_fwd(const LNArgs& a, int C, hipStream_t s) {
   switch (C) {
     case 128: hipLaunchKernelGGL((ln_fwd_kernel<TI, TO, 128>), grid, block, 0, s, a); break;
     case 256: hipLaunchKernelGGL((ln_fwd_kernel<TI, TO, 256>), grid, block, 0, s, a); break;
+    case 512: hipLaunchKernelGGL((ln_fwd_kernel<TI, TO, 512>), grid, block, 0, s, a); break;     // (non-default conv widths: same template)
     case 1024: hipLaunchKernelGGL((ln_fwd_kernel<TI, TO, 1024>), grid, block, 0, s, a); break;
-    default: dx_set_error("dx_layernorm_fwd: C=%d unsupported (128, 256, 1024)", C); return DX_ERR_UNSUPPORTED;
+    default: dx_set_error("dx_layernorm_fwd: C=%d unsupported (128, 256, 512, 1024)", C); return DX_ERR_UNSUPPORTED;
   }
   DX_LAUNCH_CHECK();
   return DX_OK;
@@ -399,11 +403,15 @@ int launch_bwd(const LNBwdArgs& a, int C, hipStream_t s) {
       if (film) hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 256, true>), grid, block, 0, s, a);
       else hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 256, false>), grid, block, 0, s, a);
       break;
+    case 512:
+      if (film) hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 512, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 512, false>), grid, block, 0, s, a);
+      break;
     case 1024:
       if (film) hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 1024, true>), grid, block, 0, s, a);   // not on the model's path
       else hipLaunchKernelGGL((ln_bwd_kernel<TI, TG, TD, 1024, false>), grid, block, 0, s, a);
       break;
-    default: dx_set_error("dx_layernorm_bwd: C=%d unsupported (128, 256, 1024)", C); return DX_ERR_UNSUPPORTED;
+    default: dx_set_error("dx_layernorm_bwd: C=%d unsupported (128, 256, 512, 1024)", C); return DX_ERR_UNSUPPORTED;
   }
   if (a.ws) {
     const int chunks = dx_cdiv(a.N, a.rows_per_block), nA = dx_cdiv(2 * C, 64);

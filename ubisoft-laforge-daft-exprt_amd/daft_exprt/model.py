@@ -164,8 +164,10 @@ class DaftExprt(nn.Module):
                                       'attention head split) are built for 128 channels')
         for cfg, nm in ((hparams.prosody_encoder, 'prosody_encoder'), (hparams.phoneme_encoder, 'phoneme_encoder'),
                         (hparams.frame_decoder, 'frame_decoder')):
-            if 128 // cfg['attn_nb_heads'] not in (16, 64) or cfg['conv_kernel'] != 3:
-                raise NotImplementedError(f'{nm}: attention kernels exist for head sizes 16 and 64 (attn_nb_heads 8 or 2) and '
+            # head sizes 16 and 64 (the published 8 / 2 heads) are the tuned attention kernels; 32 and 128 (4 heads / 1 head) run on
+            # the same templates untuned (two-pass backward; the 128-wide head keeps one wave per SIMD)
+            if 128 % cfg['attn_nb_heads'] or 128 // cfg['attn_nb_heads'] not in (16, 32, 64, 128) or cfg['conv_kernel'] != 3:
+                raise NotImplementedError(f'{nm}: attention kernels exist for attn_nb_heads 8, 4, 2, 1 (head sizes 16 .. 128) and '
                                           f'conv_kernel 3, got attn_nb_heads={cfg["attn_nb_heads"]}, conv_kernel={cfg["conv_kernel"]}')
         self.cd = torch.bfloat16 if getattr(hparams, 'compute_dtype', 'bf16') == 'bf16' else torch.float32
         self._table = param_table(hparams)

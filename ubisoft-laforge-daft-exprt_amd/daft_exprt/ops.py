@@ -54,6 +54,22 @@ def _probe(family, flops_fn, n_axis):
     return _NO_PROBE if PROBE is None else _Probe(family, flops_fn(), n_axis)
 
 
+def _empty(*shape, **kw):
+    ''' torch.empty -- or, with DX_POISON=1, a buffer pre-filled with NaN (floating types) / a large negative number (integers): the
+        parity tests then prove that no kernel reads a row its producer did not write (dead rows past dx_fill_end stay unwritten) '''
+    t = torch.empty(*shape, **kw)
+    if config.POISON and t.is_cuda:
+        if t.is_floating_point():
+            t.fill_(float('nan'))
+        elif t.dtype in (torch.int32, torch.int64):
+            t.fill_(-(1 << 30))
+    return t
+
+
+def _empty_like(x, **kw):
+    return _empty(x.shape, dtype=kw.get('dtype', x.dtype), device=x.device)
+
+
 def _ptr_array(tensors):
     arr = (ctypes.c_void_p * max(1, len(tensors)))()
     for i, t in enumerate(tensors):
@@ -73,7 +89,7 @@ def pack_conv_weight(w, dtype, transpose_flip=False, out=None):
     taps = w.shape[2] if w.dim() == 3 else 1
     shape = (taps, cin, cout) if transpose_flip else (taps, cout, cin)
     if out is None:
-        out = torch.empty(shape, dtype=dtype, device=w.device)
+        out = _empty(shape, dtype=dtype, device=w.device)
     assert w.is_contiguous()
     H.check(H.lib().dx_pack_conv_weight(H.ptr(w), H.ptr(out), H.dt(out), cout, cin, taps, int(transpose_flip), H.stream()))
     return out
@@ -99,14 +115,14 @@ def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, m
             and Cin % 128 == 0 and Cin >= 256 and Cout % 256 == 0):
         table, pb, pn = wide_plan
         assert (pb, pn) == (B, N), 'tile plan built for another batch geometry'
-        y = torch.empty((B, N, Cout), dtype=torch.bfloat16, device=x.device)
+        y = _empty((B, N, Cout), dtype=torch.bfloat16, device=x.device)
         with _probe('conv_gemm', lambda: 2. * B * N * Cin * Cout * taps, N):
             H.check(H.lib().dx_conv1d_wide(H.ptr(x), x.stride(1), H.ptr(w_frag), H.ptr(bias), H.ptr(y), y.stride(1), H.ptr(skip_lengths),
                                            H.ptr(table), table.shape[0], 2, B, N, Cin, Cout, H.CONV_RELU if relu else 0, H.stream()))
         return y
     if out is None:
         assert not accumulate
-        out = torch.empty((B, Cout, N) if transposed_out else (B, N, Cout), dtype=out_dtype, device=x.device)
+        out = _empty((B, Cout, N) if transposed_out else (B, N, Cout), dtype=out_dtype, device=x.device)
     flags = (H.CONV_RELU if relu else 0) | (H.CONV_TRANSPOSED_OUT if transposed_out else 0) | (4 if accumulate else 0)
     frag = None
     if w_frag is not None and taps == 3 and Cin == 128 and w_packed.dtype == torch.bfloat16:
@@ -131,17 +147,17 @@ def conv1d_ln(x, w_packed, bias, residual, gamma, beta, lengths, film=None, save
     taps, Cout, _ = w_packed.shape
     assert Cout == 128 and x.stride(2) == 1 and residual.is_contiguous()
     dev = x.device
-    y = torch.empty((B, N, 128), dtype=torch.float32, device=dev)
-    y_lp = torch.empty((B, N, 128), dtype=torch.bfloat16, device=dev) if lp_copy else None
-    s_out = torch.empty((B, N, 128), dtype=torch.float32, device=dev) if save else None
-    mean = torch.empty(B * N, dtype=torch.float32, device=dev) if save else None
-    rstd = torch.empty(B * N, dtype=torch.float32, device=dev) if save else None
+    y = _empty((B, N, 128), dtype=torch.float32, device=dev)
+    y_lp = _empty((B, N, 128), dtype=torch.bfloat16, device=dev) if lp_copy else None
+    s_out = _empty((B, N, 128), dtype=torch.float32, device=dev) if save else None
+    mean = _empty(B * N, dtype=torch.float32, device=dev) if save else None
+    rstd = _empty(B * N, dtype=torch.float32, device=dev) if save else None
     pargs = _plan_args(plan, x, w_packed, B, N, w_frag=w_frag)
     y2, n2 = None, 0
     if (w2_packed is not None and lp_copy and pargs[2] is not None and taps == 3 and Cin % 128 == 0 and B * N <= 65536
             and w2_packed.dtype == torch.bfloat16 and w2_packed.shape[0] == 1 and w2_packed.shape[2] == 128 and w2_packed.shape[1] in (128, 384)):
         n2 = w2_packed.shape[1]
-        y2 = torch.empty((B, N, n2), dtype=torch.bfloat16, device=dev)
+        y2 = _empty((B, N, n2), dtype=torch.bfloat16, device=dev)
     with _probe('conv_gemm', lambda: 2. * B * N * Cin * Cout * taps + 2. * B * N * 128 * n2, N):
         H.check(H.lib().dx_conv1d_ln(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(bias), H.ptr(residual),
                                      H.ptr(gamma), H.ptr(beta), H.ptr(film), film.stride(0) if film is not None else 0, H.ptr(lengths),
@@ -163,14 +179,14 @@ def conv1d_lnbwd(x, w_packed, y_inout, s_in, mean, rstd, gamma, beta, lengths, d
     B, N, Cin = x.shape
     taps, Cout, _ = w_packed.shape
     assert Cout == 128 and x.stride(2) == 1 and y_inout.is_contiguous() and y_inout.dtype == torch.float32
-    dx_lp = torch.empty((B, N, 128), dtype=torch.bfloat16, device=x.device)
+    dx_lp = _empty((B, N, 128), dtype=torch.bfloat16, device=x.device)
     ldf = film.stride(0) if film is not None else 0
     lddf = dfilm.stride(0) if dfilm is not None else 0
     pargs = _plan_args(plan, x, w_packed, B, N, k1_ok=True, w_frag=w_frag)
     y2 = None
     if (w2_packed is not None and pargs[2] is not None and taps == 3 and Cin % 128 == 0 and B * N <= 65536
             and w2_packed.dtype == torch.bfloat16 and tuple(w2_packed.shape) == (1, 128, 128)):
-        y2 = torch.empty((B, N, 128), dtype=torch.bfloat16, device=x.device)
+        y2 = _empty((B, N, 128), dtype=torch.bfloat16, device=x.device)
     with _probe('conv_gemm', lambda: 2. * B * N * Cin * Cout * taps + (2. * B * N * 128 * 128 if y2 is not None else 0.), N):
         H.check(H.lib().dx_conv1d_lnbwd(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(y_inout), H.ptr(s_in),
                                         H.ptr(mean), H.ptr(rstd), H.ptr(gamma), H.ptr(beta), H.ptr(film), ldf, H.ptr(lengths),
@@ -198,7 +214,7 @@ def conv_tile_plan(lengths, N, halo=0, round_to=None, tiles=None):
     else:
         worst = B * ((N + 255) // 256)
         n = (worst + round_to - 1) // round_to * round_to
-    table = torch.empty((n, 4), dtype=torch.int32, device=lengths.device)
+    table = _empty((n, 4), dtype=torch.int32, device=lengths.device)
     H.check(H.lib().dx_conv_tile_plan(H.ptr(lengths), B, N, n, H.ptr(table), int(halo), H.stream()))
     return table, B, N
 
@@ -211,9 +227,9 @@ def batch_prep(lengths, N, plan=True, wide=True, order=True):
     n0 = H.lib().dx_conv_tile_plan_size(B, N)
     n2 = (worst + 63) // 64 * 64
     dev = lengths.device
-    t0 = torch.empty((n0, 4), dtype=torch.int32, device=dev) if plan else None
-    t2 = torch.empty((n2, 4), dtype=torch.int32, device=dev) if wide else None
-    od = torch.empty((B,), dtype=torch.int32, device=dev) if order else None
+    t0 = _empty((n0, 4), dtype=torch.int32, device=dev) if plan else None
+    t2 = _empty((n2, 4), dtype=torch.int32, device=dev) if wide else None
+    od = _empty((B,), dtype=torch.int32, device=dev) if order else None
     H.check(H.lib().dx_batch_prep(H.ptr(lengths), B, N, n0, H.ptr(t0), n2, H.ptr(t2), H.ptr(od), H.stream()))
     return (t0, B, N) if plan else None, (t2, B, N) if wide else None, od
 
@@ -241,7 +257,7 @@ def pack_frag_major(w_packed, out=None):
     ''' fragment-order copy of a packed [3][Cout][Cin] bf16 weight (dx_pack_frag_major) '''
     taps, cout, cin = w_packed.shape
     assert taps == 3 and cout % 32 == 0 and cin % 32 == 0 and w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous()
-    out = torch.empty(w_packed.numel(), dtype=torch.bfloat16, device=w_packed.device) if out is None else out
+    out = _empty(w_packed.numel(), dtype=torch.bfloat16, device=w_packed.device) if out is None else out
     H.check(H.lib().dx_pack_frag_major(H.ptr(w_packed), H.ptr(out), cin, cout, H.stream()))
     return out
 
@@ -294,7 +310,7 @@ def conv1d_wgrad(dy, x, dw, db, compute_dtype, lengths=None, stream=None, ws=Non
     if not WGRAD_WORKSPACE:
         ws = None
     elif ws is None:
-        ws = torch.empty(H.lib().dx_conv1d_wgrad_ws_floats(B, N, Cin, Cout, taps), dtype=torch.float32, device=dy.device)
+        ws = _empty(H.lib().dx_conv1d_wgrad_ws_floats(B, N, Cin, Cout, taps), dtype=torch.float32, device=dy.device)
     with _probe('conv_wgrad', lambda: 2. * B * N * Cin * Cout * taps, N):
       H.check(H.lib().dx_conv1d_wgrad(H.ptr(dy), H.dt(dy), dy.stride(1), H.ptr(x), H.dt(x), x.stride(1),
                                     H._DT[compute_dtype], H.ptr(dw), H.ptr(db), H.ptr(lengths), H.ptr(ws), B, N, Cin, Cout, taps,
@@ -327,7 +343,7 @@ def conv1d_wgrad_multi(items, compute_dtype, lengths, stream=None, ws=None):
                             H.dt(dy), H.dt(x), x.shape[2], dy.shape[2], taps, 0)
         flops += 2. * B * N * x.shape[2] * dy.shape[2] * taps
     if ws is None:
-        ws = torch.empty(H.lib().dx_conv1d_wgrad_multi_ws_floats(arr, n, B, N), dtype=torch.float32, device=items[0][0].device)
+        ws = _empty(H.lib().dx_conv1d_wgrad_multi_ws_floats(arr, n, B, N), dtype=torch.float32, device=items[0][0].device)
     with _probe('conv_wgrad', lambda: flops, N):
         H.check(H.lib().dx_conv1d_wgrad_multi(arr, n, H._DT[compute_dtype], H.ptr(lengths), H.ptr(ws), B, N,
                                               H.stream() if stream is None else stream))
@@ -349,14 +365,14 @@ def layernorm_fwd(x, gamma, beta, residual=None, film=None, lengths=None, out_dt
     ''' returns (y, s_out, mean, rstd) -- or (y, y_bf16, s_out, mean, rstd) with lp_copy '''
     B, N, C = x.shape
     assert x.is_contiguous()
-    y = torch.empty((B, N, C), dtype=out_dtype, device=x.device)
-    y_lp = torch.empty((B, N, C), dtype=torch.bfloat16, device=x.device) if lp_copy else None
+    y = _empty((B, N, C), dtype=out_dtype, device=x.device)
+    y_lp = _empty((B, N, C), dtype=torch.bfloat16, device=x.device) if lp_copy else None
     mean = rstd = s_out = None
     if save:
-        mean = torch.empty(B * N, dtype=torch.float32, device=x.device)
-        rstd = torch.empty_like(mean)
+        mean = _empty(B * N, dtype=torch.float32, device=x.device)
+        rstd = _empty_like(mean)
     if save_s:
-        s_out = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
+        s_out = _empty((B, N, C), dtype=torch.float32, device=x.device)
     ldf = film.stride(0) if film is not None else 0
     H.check(H.lib().dx_layernorm_fwd(H.ptr(x), H.dt(x), H.ptr(residual), H.ptr(gamma), H.ptr(beta), H.ptr(film), ldf,
                                      H.ptr(lengths), H.ptr(skip_lengths), H.ptr(y), H.dt(y), H.ptr(y_lp), H.ptr(s_out), H.ptr(mean), H.ptr(rstd), B, N, C,
@@ -373,14 +389,14 @@ def layernorm_bwd(dy, s_in, mean, rstd, gamma, beta, dgamma, dbeta, film=None, d
         separate: dx_pre gets its own buffer even without pre-dropout (the caller accumulates into ds in place while
         another stream still reads dx_pre). '''
     B, N, C = dy.shape
-    ds = torch.empty((B, N, C), dtype=d_dtype, device=dy.device)
-    dx_pre = torch.empty_like(ds) if ((p_pre > 0. or separate) and not lp_only) else None
-    dx_lp = torch.empty((B, N, C), dtype=torch.bfloat16, device=dy.device) if lp_only else None
+    ds = _empty((B, N, C), dtype=d_dtype, device=dy.device)
+    dx_pre = _empty_like(ds) if ((p_pre > 0. or separate) and not lp_only) else None
+    dx_lp = _empty((B, N, C), dtype=torch.bfloat16, device=dy.device) if lp_only else None
     ldf = film.stride(0) if film is not None else 0
     lddf = dfilm.stride(0) if dfilm is not None else 0
     # two-stage (atomic-free, run-to-run deterministic) reduction of dgamma/dbeta/dfilm; measured 7 % slower per step than
     # the fp32 atomics (one more dependent launch per LayerNorm), so it is opt-in
-    ws = torch.empty(H.lib().dx_layernorm_bwd_ws_floats(B, N, C), dtype=torch.float32, device=dy.device) if DETERMINISTIC_LN else None
+    ws = _empty(H.lib().dx_layernorm_bwd_ws_floats(B, N, C), dtype=torch.float32, device=dy.device) if DETERMINISTIC_LN else None
     H.check(H.lib().dx_layernorm_bwd(H.ptr(dy), H.dt(dy), H.ptr(s_in), H.dt(s_in), H.ptr(mean), H.ptr(rstd), H.ptr(gamma),
                                      H.ptr(beta), H.ptr(film), ldf, H.ptr(lengths), H.ptr(skip_lengths), H.ptr(ds), H.ptr(dx_pre), H.ptr(dx_lp), H.dt(ds),
                                      H.ptr(dgamma), H.ptr(dbeta), H.ptr(dfilm), lddf, B, N, C, float(p_pre), int(seed_pre),
@@ -393,7 +409,7 @@ def layernorm_bwd(dy, s_in, mean, rstd, gamma, beta, dgamma, dbeta, film=None, d
 # ----------------------------------------------------------------------------- attention
 def length_order(lengths):
     ''' int32 (B): utterance indices by decreasing length (dx_length_order) -- the launch order of the attention kernels '''
-    order = torch.empty((lengths.shape[0],), dtype=torch.int32, device=lengths.device)
+    order = _empty((lengths.shape[0],), dtype=torch.int32, device=lengths.device)
     H.check(H.lib().dx_length_order(H.ptr(lengths), lengths.shape[0], H.ptr(order), H.stream()))
     return order
 
@@ -402,8 +418,8 @@ def attention_fwd(qkv, lengths, nb_heads, p_drop=0., seed=0, need_lse=True, orde
     B, N, E3 = qkv.shape
     E = E3 // 3
     assert qkv.is_contiguous()
-    o = torch.empty((B, N, E), dtype=qkv.dtype, device=qkv.device)
-    lse = torch.empty((B, nb_heads, N), dtype=torch.float32, device=qkv.device) if need_lse else None
+    o = _empty((B, N, E), dtype=qkv.dtype, device=qkv.device)
+    lse = _empty((B, nb_heads, N), dtype=torch.float32, device=qkv.device) if need_lse else None
     H.check(H.lib().dx_attention_fwd(H.ptr(qkv), H.dt(qkv), H.ptr(lengths), H.ptr(order), H.ptr(o), H.ptr(lse), B, N, nb_heads, E,
                                      float(p_drop), int(seed), STEP_PTR, H.stream()))
     return o, lse
@@ -426,7 +442,7 @@ def _attn_workspace(B, N, nb_heads, device):
     if ent is None:
         ent = table[key] = [None, None]
     if ent[0] is None or ent[0].numel() < need:
-        ent[0] = torch.empty((max(need, 1 << 20),), dtype=torch.float32, device=device)
+        ent[0] = _empty((max(need, 1 << 20),), dtype=torch.float32, device=device)
     if ent[1] is None or ent[1].numel() < need_c:
         ent[1] = zeros((max(need_c, 4096),), device, dtype=torch.int32)
     return ent[0], ent[1]
@@ -436,7 +452,7 @@ def attention_bwd(qkv, o, d_o, lse, lengths, nb_heads, p_drop=0., seed=0, order=
     B, N, E3 = qkv.shape
     E = E3 // 3
     assert d_o.is_contiguous() and d_o.dtype == qkv.dtype
-    dqkv = torch.empty_like(qkv)
+    dqkv = _empty_like(qkv)
     ws, counters = _attn_workspace(B, N, nb_heads, qkv.device)
     H.check(H.lib().dx_attention_bwd(H.ptr(qkv), H.ptr(o), H.ptr(d_o), H.dt(qkv), H.ptr(lse), H.ptr(lengths), H.ptr(order), H.ptr(dqkv),
                                      H.ptr(ws), H.ptr(counters), B, N, nb_heads, E, float(p_drop), int(seed), STEP_PTR, int(algo), H.stream()))
@@ -447,7 +463,7 @@ def attention_bwd(qkv, o, d_o, lse, lengths, nb_heads, p_drop=0., seed=0, order=
 def scalar_embed_fwd(feats, ws, biases, base=None, pos_table=None, lengths=None):
     B, N = feats[0].shape
     C = ws[0].shape[0]
-    out = torch.empty((B, N, C), dtype=torch.float32, device=feats[0].device)
+    out = _empty((B, N, C), dtype=torch.float32, device=feats[0].device)
     H.check(H.lib().dx_scalar_embed_fwd(H.ptr(base), _ptr_array(feats), _ptr_array(ws), _ptr_array(biases), len(feats),
                                         H.ptr(pos_table), H.ptr(lengths), H.ptr(out), B, N, C, H.stream()))
     return out
@@ -455,7 +471,7 @@ def scalar_embed_fwd(feats, ws, biases, base=None, pos_table=None, lengths=None)
 
 def scalar_embed_bwd(dout, feats, dws, dbiases, lengths=None, need_dbase=False):
     B, N, C = dout.shape
-    dbase = torch.empty_like(dout) if need_dbase else None
+    dbase = _empty_like(dout) if need_dbase else None
     H.check(H.lib().dx_scalar_embed_bwd(H.ptr(dout), _ptr_array(feats), len(feats), H.ptr(lengths), H.ptr(dbase),
                                         _ptr_array(dws), _ptr_array(dbiases), B, N, C, H.stream()))
     return dbase
@@ -465,7 +481,7 @@ def embed_pos_fwd(ids, table, pos_table, lengths):
     B, N = ids.shape
     C = table.shape[1]
     assert pos_table.shape[1] == C and table.is_contiguous() and pos_table.is_contiguous()
-    out = torch.empty((B, N, C), dtype=torch.float32, device=ids.device)
+    out = _empty((B, N, C), dtype=torch.float32, device=ids.device)
     H.check(H.lib().dx_embed_pos_fwd(H.ptr(ids), H.ptr(table), H.ptr(pos_table), H.ptr(lengths), H.ptr(out), B, N, C, H.stream()))
     return out
 
@@ -479,21 +495,21 @@ def embed_pos_bwd(ids, dout, lengths, dtable):
 
 def masked_mean_fwd(x, lengths):
     B, N, C = x.shape
-    out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    out = _empty((B, C), dtype=torch.float32, device=x.device)
     H.check(H.lib().dx_masked_mean_fwd(H.ptr(x), H.ptr(lengths), H.ptr(out), B, N, C, H.stream()))
     return out
 
 
 def masked_mean_bwd(dy, lengths, N):
     B, C = dy.shape
-    dx = torch.empty((B, N, C), dtype=torch.float32, device=dy.device)
+    dx = _empty((B, N, C), dtype=torch.float32, device=dy.device)
     H.check(H.lib().dx_masked_mean_bwd(H.ptr(dy), H.ptr(lengths), H.ptr(dx), B, N, C, H.stream()))
     return dx
 
 
 def film_assemble_fwd(g_raw, b_raw, post, nb, ch):
     B = g_raw.shape[0]
-    films = [torch.empty((B, nb[m], 2 * ch[m]), dtype=torch.float32, device=g_raw.device) for m in range(3)]
+    films = [_empty((B, nb[m], 2 * ch[m]), dtype=torch.float32, device=g_raw.device) for m in range(3)]
     H.check(H.lib().dx_film_assemble_fwd(H.ptr(g_raw), H.ptr(b_raw), H.ptr(post), H.ptr(films[0]), H.ptr(films[1]),
                                          H.ptr(films[2]), _int_array(nb), _int_array(ch), B, H.stream()))
     return films
@@ -501,7 +517,7 @@ def film_assemble_fwd(g_raw, b_raw, post, nb, ch):
 
 def film_assemble_bwd(g_raw, b_raw, post, dfilms, dpost, nb, ch):
     B = g_raw.shape[0]
-    dg, db = torch.empty_like(g_raw), torch.empty_like(b_raw)
+    dg, db = _empty_like(g_raw), _empty_like(b_raw)
     H.check(H.lib().dx_film_assemble_bwd(H.ptr(g_raw), H.ptr(b_raw), H.ptr(post), H.ptr(dfilms[0]), H.ptr(dfilms[1]),
                                          H.ptr(dfilms[2]), H.ptr(dg), H.ptr(db), H.ptr(dpost), _int_array(nb), _int_array(ch),
                                          B, H.stream()))
@@ -516,9 +532,9 @@ def film_head_fwd(emb, spk_table, spk_ids, wg, bg, wb, bb, post, nb, ch):
     B, C = emb.shape
     W = sum(n * c for n, c in zip(nb, ch))
     dev = emb.device
-    z = torch.empty((B, C), dtype=torch.float32, device=dev)
-    g_raw, b_raw = torch.empty((B, W), dtype=torch.float32, device=dev), torch.empty((B, W), dtype=torch.float32, device=dev)
-    films = [torch.empty((B, nb[m], 2 * ch[m]), dtype=torch.float32, device=dev) for m in range(3)]
+    z = _empty((B, C), dtype=torch.float32, device=dev)
+    g_raw, b_raw = _empty((B, W), dtype=torch.float32, device=dev), _empty((B, W), dtype=torch.float32, device=dev)
+    films = [_empty((B, nb[m], 2 * ch[m]), dtype=torch.float32, device=dev) for m in range(3)]
     H.check(H.lib().dx_film_head_fwd(H.ptr(emb), H.ptr(spk_table), H.ptr(spk_ids), H.ptr(wg), H.ptr(bg), H.ptr(wb), H.ptr(bb), H.ptr(post),
                                      H.ptr(z), H.ptr(g_raw), H.ptr(b_raw), H.ptr(films[0]), H.ptr(films[1]), H.ptr(films[2]),
                                      _int_array(nb), _int_array(ch), B, C, H.stream()))
@@ -529,7 +545,7 @@ def film_head_bwd(g_raw, b_raw, post, z, spk_ids, wg, wb, dfilms, d_emb, d_spk_t
     ''' everything behind the FiLM tensors' gradients in two launches (dx_film_head_bwd); d_emb, d_spk_table, dpost and the four
         parameter gradients are accumulated '''
     B, C = z.shape
-    ws = torch.empty((2,) + tuple(g_raw.shape), dtype=torch.float32, device=z.device)
+    ws = _empty((2,) + tuple(g_raw.shape), dtype=torch.float32, device=z.device)
     H.check(H.lib().dx_film_head_bwd(H.ptr(g_raw), H.ptr(b_raw), H.ptr(post), H.ptr(z), H.ptr(spk_ids), H.ptr(wg), H.ptr(wb), H.ptr(dfilms[0]),
                                      H.ptr(dfilms[1]), H.ptr(dfilms[2]), H.ptr(ws[0]), H.ptr(ws[1]), H.ptr(d_emb), H.ptr(d_spk_table), H.ptr(dpost),
                                      H.ptr(dwg), H.ptr(dbg), H.ptr(dwb), H.ptr(dbb), _int_array(nb), _int_array(ch), B, C, H.stream()))
@@ -538,8 +554,8 @@ def film_head_bwd(g_raw, b_raw, post, z, spk_ids, wg, wb, dfilms, d_emb, d_spk_t
 def classifier_fwd(emb, w1, b1, w2, b2, w3, b3):
     B, C = emb.shape
     S = w3.shape[0]
-    h1, h2 = torch.empty_like(emb), torch.empty_like(emb)
-    logits = torch.empty((B, S), dtype=torch.float32, device=emb.device)
+    h1, h2 = _empty_like(emb), _empty_like(emb)
+    logits = _empty((B, S), dtype=torch.float32, device=emb.device)
     H.check(H.lib().dx_classifier_fwd(H.ptr(emb), H.ptr(w1), H.ptr(b1), H.ptr(w2), H.ptr(b2), H.ptr(w3), H.ptr(b3), H.ptr(h1), H.ptr(h2),
                                       H.ptr(logits), B, C, S, H.stream()))
     return logits, h1, h2
@@ -548,8 +564,8 @@ def classifier_fwd(emb, w1, b1, w2, b2, w3, b3):
 def classifier_bwd(d_logits, emb, h1, h2, w1, w2, w3, lambda_, dw1, db1, dw2, db2, dw3, db3):
     ''' returns d_emb = -lambda * dL/d(classifier input); parameter gradients accumulated (dx_classifier_bwd, two launches) '''
     B, C = emb.shape
-    ws = torch.empty((2, B, C), dtype=torch.float32, device=emb.device)
-    d_emb = torch.empty_like(emb)
+    ws = _empty((2, B, C), dtype=torch.float32, device=emb.device)
+    d_emb = _empty_like(emb)
     assert d_logits.is_contiguous()
     H.check(H.lib().dx_classifier_bwd(H.ptr(d_logits), H.ptr(emb), H.ptr(h1), H.ptr(h2), H.ptr(w1), H.ptr(w2), H.ptr(w3), H.ptr(ws[0]), H.ptr(ws[1]),
                                       H.ptr(d_emb), float(lambda_), H.ptr(dw1), H.ptr(db1), H.ptr(dw2), H.ptr(db2), H.ptr(dw3), H.ptr(db3), B, C,
@@ -562,7 +578,7 @@ def linear_small_fwd(x, w, bias, relu=False, mask_lengths=None, N=1):
     M = x.numel() // K
     O = w.shape[0]
     assert x.is_contiguous() and w.is_contiguous()
-    y = torch.empty(x.shape[:-1] + (O,), dtype=torch.float32, device=x.device)
+    y = _empty(x.shape[:-1] + (O,), dtype=torch.float32, device=x.device)
     H.check(H.lib().dx_linear_small_fwd(H.ptr(x), H.ptr(w), H.ptr(bias), H.ptr(y), H.ptr(mask_lengths), N, M, K, O, int(relu), H.stream()))
     return y
 
@@ -572,7 +588,7 @@ def linear_small_bwd(dy, y, x, w, dw, db, relu=False, mask_lengths=None, N=1, ne
     M = x.numel() // K
     O = w.shape[0]
     assert dy.is_contiguous() and x.is_contiguous()
-    dx = torch.empty_like(x) if need_dx else None
+    dx = _empty_like(x) if need_dx else None
     H.check(H.lib().dx_linear_small_bwd(H.ptr(dy), H.ptr(y), H.ptr(x), H.ptr(w), H.ptr(dx), float(dx_scale), H.ptr(dw), H.ptr(db),
                                         H.ptr(mask_lengths), N, M, K, O, int(relu), H.stream()))
     return dx
@@ -580,7 +596,7 @@ def linear_small_bwd(dy, y, x, w, dw, db, relu=False, mask_lengths=None, N=1, ne
 
 def gather_add_fwd(a, table, ids):
     B, C = a.shape
-    out = torch.empty_like(a)
+    out = _empty_like(a)
     H.check(H.lib().dx_gather_add_fwd(H.ptr(a), H.ptr(table), H.ptr(ids), H.ptr(out), B, C, H.stream()))
     return out
 
@@ -600,7 +616,7 @@ def transpose_last2(x, out_dtype=torch.float32):
     ''' (B, R, C) fp32 -> (B, C, R) in out_dtype (fp32 / bf16), contiguous '''
     B, R, C = x.shape
     assert x.is_contiguous() and x.dtype == torch.float32
-    y = torch.empty((B, C, R), dtype=out_dtype, device=x.device)
+    y = _empty((B, C, R), dtype=out_dtype, device=x.device)
     H.check(H.lib().dx_transpose_last2(H.ptr(x), H.ptr(y), H.dt(y), B, R, C, H.stream()))
     return y
 
@@ -608,7 +624,7 @@ def transpose_last2(x, out_dtype=torch.float32):
 def unstack(y, K):
     ''' (..., K) interleaved fp32 -> K contiguous tensors of shape (...) '''
     assert y.is_contiguous() and y.shape[-1] == K and y.dtype == torch.float32
-    outs = [torch.empty(y.shape[:-1], dtype=torch.float32, device=y.device) for _ in range(K)]
+    outs = [_empty(y.shape[:-1], dtype=torch.float32, device=y.device) for _ in range(K)]
     H.check(H.lib().dx_unstack(H.ptr(y), _ptr_array(outs), y.numel() // K, K, H.stream()))
     return outs
 
@@ -617,14 +633,14 @@ def stack(planes):
     ''' K contiguous fp32 tensors of one shape (...) -> (..., K) interleaved '''
     K = len(planes)
     assert all(p.is_contiguous() and p.dtype == torch.float32 and p.shape == planes[0].shape for p in planes)
-    y = torch.empty(planes[0].shape + (K,), dtype=torch.float32, device=planes[0].device)
+    y = _empty(planes[0].shape + (K,), dtype=torch.float32, device=planes[0].device)
     H.check(H.lib().dx_stack(H.ptr(y), _ptr_array(planes), planes[0].numel(), K, H.stream()))
     return y
 
 
 def zeros(shape, device, dtype=torch.float32):
     ''' device buffer cleared by a stream-ordered memset (dx_fill_zero) '''
-    t = torch.empty(shape, dtype=dtype, device=device)
+    t = _empty(shape, dtype=dtype, device=device)
     H.check(H.lib().dx_fill_zero(H.ptr(t), t.numel() * t.element_size(), H.stream()))
     return t
 
@@ -639,10 +655,10 @@ def gu_prepare(enc, dur_float, energy, pitch, in_lengths, P, save=False):
     ''' P: dict with w_dur, b_dur, w_en, b_en, w_pi, b_pi, w_range, b_range '''
     B, L, C = enc.shape
     dev = enc.device
-    xp = torch.empty((B, L, C), dtype=torch.float32, device=dev)
-    ranges = torch.empty((B, L), dtype=torch.float32, device=dev)
-    r_pre = torch.empty((B, L), dtype=torch.float32, device=dev) if save else None
-    rin = torch.empty((B, L, C), dtype=torch.float32, device=dev) if save else None
+    xp = _empty((B, L, C), dtype=torch.float32, device=dev)
+    ranges = _empty((B, L), dtype=torch.float32, device=dev)
+    r_pre = _empty((B, L), dtype=torch.float32, device=dev) if save else None
+    rin = _empty((B, L, C), dtype=torch.float32, device=dev) if save else None
     H.check(H.lib().dx_gu_prepare(H.ptr(enc), H.ptr(dur_float), H.ptr(energy), H.ptr(pitch), H.ptr(in_lengths),
                                   H.ptr(P['w_dur']), H.ptr(P['b_dur']), H.ptr(P['w_en']), H.ptr(P['b_en']), H.ptr(P['w_pi']),
                                   H.ptr(P['b_pi']), H.ptr(P['w_range']), H.ptr(P['b_range']), H.ptr(xp), H.ptr(ranges),
@@ -652,16 +668,16 @@ def gu_prepare(enc, dur_float, energy, pitch, in_lengths, P, save=False):
 
 def gu_means(durations_int):
     B, L = durations_int.shape
-    means = torch.empty((B, L), dtype=torch.float32, device=durations_int.device)
-    totals = torch.empty((B,), dtype=torch.int64, device=durations_int.device)
+    means = _empty((B, L), dtype=torch.float32, device=durations_int.device)
+    totals = _empty((B,), dtype=torch.int64, device=durations_int.device)
     H.check(H.lib().dx_gu_means(H.ptr(durations_int), H.ptr(means), H.ptr(totals), B, L, H.stream()))
     return means, totals
 
 
 def gu_upsample_fwd(xp, ranges, means, in_lengths, T, out_lengths=None, pos_table=None):
     B, L, C = xp.shape
-    weights = torch.empty((B, L, T), dtype=torch.float32, device=xp.device)
-    out = torch.empty((B, T, C), dtype=torch.float32, device=xp.device)
+    weights = _empty((B, L, T), dtype=torch.float32, device=xp.device)
+    out = _empty((B, T, C), dtype=torch.float32, device=xp.device)
     H.check(H.lib().dx_gu_upsample_fwd(H.ptr(xp), H.ptr(ranges), H.ptr(means), H.ptr(in_lengths), H.ptr(out_lengths),
                                        H.ptr(pos_table), H.ptr(weights), H.ptr(out), B, L, T, C, H.stream()))
     return out, weights
@@ -671,10 +687,10 @@ def gu_upsample_bwd(g, xp, weights, means, ranges, r_pre, w_range, in_lengths, o
     B, L, C = xp.shape
     T = weights.shape[2]
     dev = xp.device
-    dw_ws = torch.empty((B, L, T), dtype=torch.float32, device=dev)
-    dsum_ws = torch.empty((B, T), dtype=torch.float32, device=dev)
-    dxp, drin = torch.empty_like(xp), torch.empty_like(xp)
-    dr = torch.empty((B, L), dtype=torch.float32, device=dev)
+    dw_ws = _empty((B, L, T), dtype=torch.float32, device=dev)
+    dsum_ws = _empty((B, T), dtype=torch.float32, device=dev)
+    dxp, drin = _empty_like(xp), _empty_like(xp)
+    dr = _empty((B, L), dtype=torch.float32, device=dev)
     H.check(H.lib().dx_gu_upsample_bwd(H.ptr(g), H.ptr(xp), H.ptr(weights), H.ptr(means), H.ptr(ranges), H.ptr(r_pre),
                                        H.ptr(w_range), H.ptr(in_lengths), H.ptr(out_lengths), H.ptr(dw_ws), H.ptr(dsum_ws),
                                        H.ptr(dxp), H.ptr(drin), H.ptr(dr), B, L, T, C, H.stream()))
@@ -688,7 +704,7 @@ def loss_fwd_bwd(dur, energy, pitch, dur_t, energy_t, pitch_t, in_lengths, mel, 
         (d_dur, d_energy, d_pitch, d_mel, d_spk).  Returns the (8,) device tensor of loss terms. '''
     B, L = dur.shape
     n_mel, T = mel.shape[1], mel.shape[2]
-    terms = torch.empty(8, dtype=torch.float32, device=dur.device)
+    terms = _empty(8, dtype=torch.float32, device=dur.device)
     g = grads or {}
     assert mel.is_contiguous() and mel_t.is_contiguous()
     H.check(H.lib().dx_loss_fwd_bwd(H.ptr(dur), H.ptr(energy), H.ptr(pitch), H.ptr(dur_t), H.ptr(energy_t), H.ptr(pitch_t),
@@ -702,7 +718,7 @@ def loss_fwd_bwd(dur, energy, pitch, dur_t, energy_t, pitch_t, in_lengths, mel, 
 
 
 def sumsq(x, out=None):
-    out = out if out is not None else torch.empty(1, dtype=torch.float32, device=x.device)
+    out = out if out is not None else _empty(1, dtype=torch.float32, device=x.device)
     H.check(H.lib().dx_sumsq(H.ptr(x), x.numel(), H.ptr(out), H.stream()))
     return out
 
@@ -762,9 +778,9 @@ def int_durations(duration_preds, hparams, dur_factors=None):
     B, L = duration_preds.shape
     dev = duration_preds.device
     assert duration_preds.is_contiguous()
-    dint = torch.empty((B, L), dtype=torch.int64, device=dev)
-    totals = torch.empty((B,), dtype=torch.int64, device=dev)
-    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    dint = _empty((B, L), dtype=torch.int64, device=dev)
+    totals = _empty((B,), dtype=torch.int64, device=dev)
+    status = _empty((B,), dtype=torch.int32, device=dev)
     H.check(H.lib().dx_int_durations(H.ptr(duration_preds), H.ptr(dur_factors), H.ptr(dint), H.ptr(totals), H.ptr(status), B, L,
                                      float(hparams.sampling_rate), int(hparams.filter_length), int(hparams.hop_length),
                                      int(bool(hparams.centered)), H.stream()))
