@@ -42,7 +42,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import daft_exprt_cpu as O
-from tests.util import make_hparams, no_dropout, gradient_report
+from tests.util import drop_unwritten, make_hparams, no_dropout, gradient_report
 
 DEV = 'cuda:0'
 TOL = {'fp32': dict(pred=2e-4, loss=1e-4, grad=2e-3, floor=2e-5),
@@ -153,15 +153,21 @@ def _stagewise_check(trace, hp, state, rows, what):
     try:
         with torch.no_grad():
             for kind, names, x, film, lengths, out in trace:
-                xs, fs = cpu(x), cpu(film)
+                # rows past the fill end of a (B, N, C) activation are unwritten (csrc/dx_common.h dx_fill_end): dropped before the
+                # oracle sees the tensor / before the comparison
+                lfill = (lengths if lengths is not None else names[2]).cpu()[rows]
+                drop = lambda t: t if (t is None or kind == 'mel_projection' and t.shape[1] != x.shape[1]) else drop_unwritten(t, lfill)
+                xs, fs = drop(cpu(x)), cpu(film)
+                out_dtype = None if isinstance(out, tuple) else out.dtype
+                out = tuple(drop(cpu(o)) for o in out) if isinstance(out, tuple) else drop(cpu(out))
                 ls = None if lengths is None else lengths.cpu()[rows]
                 N = xs.shape[1]
                 if kind == 'fft_block':
                     pad = ~O.valid_mask(ls, N)
                     cfg = cfgs[names.split('.')[0]]
                     a = O.multi_head_attention(P, names + '.attention.', xs, pad, cfg['attn_nb_heads'], 0., False).masked_fill(pad.unsqueeze(2), 0.)
-                    u = O.conv_ff(P, names + '.feed_forward.', cpu(out[0]), fs, 0., False).masked_fill(pad.unsqueeze(2), 0.)
-                    pairs = [(names + ' attention+LN', cpu(out[0]), a), (names + ' FF+LN (HIP attention output in)', cpu(out[1]), u)]
+                    u = O.conv_ff(P, names + '.feed_forward.', out[0], fs, 0., False).masked_fill(pad.unsqueeze(2), 0.)
+                    pairs = [(names + ' attention+LN', out[0], a), (names + ' FF+LN (HIP attention output in)', out[1], u)]
                 elif kind == 'conv_ln':
                     conv_name, ln_name, skip = names
                     skip = skip.cpu()[rows]
@@ -174,13 +180,13 @@ def _stagewise_check(trace, hp, state, rows, what):
                         y = fs[:, None, :C] * y + fs[:, None, C:]
                     if ls is not None:
                         y = y.masked_fill(~O.valid_mask(ls, N).unsqueeze(2), 0.)
-                    if out.dtype == torch.bfloat16:
+                    if out_dtype == torch.bfloat16:
                         y = O._op(y)
-                    pairs = [(conv_name + ' conv+ReLU+LN', cpu(out), y)]
+                    pairs = [(conv_name + ' conv+ReLU+LN', out, y)]
                 else:
                     pad = ~O.valid_mask(ls, N)
                     mel = O.linear_mfma(xs, P[names + '.weight'], P[names + '.bias']).masked_fill(pad.unsqueeze(2), 0.).transpose(1, 2)
-                    pairs = [(names, cpu(out), mel)]
+                    pairs = [(names, out, mel)]
                 for name, got, ref in pairs:
                     # rows past len + 2 of un-masked stages are never consumed (padding early-out writes zeros there)
                     if kind == 'mel_projection':
@@ -216,7 +222,14 @@ def _stagewise_bf16_backward(model, hp, state, trace, rows, hip_grads, what):
         magnitude) with an absolute cap of 2e-2, and to have <= 1 % of its elements further than 3e-2 of the maximum -- a 5 %
         systematic error in a fused backward epilogue fails both. '''
     cfgs = {'prosody_encoder': hp.prosody_encoder, 'phoneme_encoder': hp.phoneme_encoder, 'frame_decoder': hp.frame_decoder}
-    cpu = lambda t: None if t is None else t.detach().float().cpu()[rows]
+
+    def cpu(t, lfill=None):
+        ''' kept rows on the host; with `lfill` (the stage's lengths, kept rows) the rows past the fill end -- unwritten by
+            contract, csrc/dx_common.h dx_fill_end -- are dropped '''
+        if t is None:
+            return None
+        t = t.detach().float().cpu()[rows]
+        return t if lfill is None or t.dim() != 3 else drop_unwritten(t, lfill)
     report, n_fft, n_conv = [], 0, 0
 
     def score(name, got, emu, exact, live=None):
@@ -248,7 +261,7 @@ def _stagewise_bf16_backward(model, hp, state, trace, rows, hip_grads, what):
         P = {k: v.detach().clone() for k, v in state.items()}
         for n in names:
             P[n].requires_grad_(True)
-        xin = cpu(below.s2 if below is not None else sv.x).requires_grad_(True)
+        xin = cpu(below.s2 if below is not None else sv.x, ls).requires_grad_(True)
         N = xin.shape[1]
         pad = ~O.valid_mask(ls, N)
         if below is not None:
@@ -276,7 +289,7 @@ def _stagewise_bf16_backward(model, hp, state, trace, rows, hip_grads, what):
         P = {k: v.detach().clone() for k, v in state.items()}
         for n in names:
             P[n].requires_grad_(True)
-        xin = cpu(sv.x).requires_grad_(True)
+        xin = cpu(sv.x, sv.skip.cpu()[rows]).requires_grad_(True)
         N = xin.shape[1]
         y = torch.relu(O.conv1d_cl(xin, P[names[0]], P[names[1]]))
         if y.shape[2] != 128 and mode is not None:
@@ -293,7 +306,8 @@ def _stagewise_bf16_backward(model, hp, state, trace, rows, hip_grads, what):
 
     try:
         for kind, sv, below, g_in, g_out in trace:
-            gi = cpu(g_in)
+            lfill = (sv.lengths if kind == 'fft_block' else sv.skip).cpu()[rows]
+            gi = cpu(g_in, lfill)
             if kind == 'fft_block':
                 names, g_emu, live = fft_stage(sv, below, gi, torch.bfloat16)
                 _, g_ex, _ = fft_stage(sv, below, gi, None)
@@ -305,7 +319,7 @@ def _stagewise_bf16_backward(model, hp, state, trace, rows, hip_grads, what):
                 tag = sv.conv_name
                 n_conv += 1
             if g_out is not None:
-                score(f'{tag}: data gradient', cpu(g_out), g_emu[0], g_ex[0], live)
+                score(f'{tag}: data gradient', cpu(g_out, lfill), g_emu[0], g_ex[0], live)
             for n, ge, gx in zip(names, g_emu[1:], g_ex[1:]):
                 score(f'{tag}: d {n}', hip_grads[n], ge, gx)
     finally:

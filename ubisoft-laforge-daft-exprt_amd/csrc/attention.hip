@@ -1046,11 +1046,6 @@ int launch_fwd(const AttnArgs& a0, int B, int dh, hipStream_t s) {
   DX_LAUNCH_CHECK();
   return DX_OK;
 }
-// DX_ATTN_FUSED_BWD (default 1): the fused backward kernel for bf16 / d_head = 16 / N <= 1024
-static int fused_bwd_enabled() {
-  static const int on = [] { const char* e = getenv("DX_ATTN_FUSED_BWD"); return e ? atoi(e) : 1; }();
-  return on;
-}
 template <typename TC>
 int launch_bwd(const AttnArgs& a0, int B, int dh, float* delta, int algo, hipStream_t s) {
   AttnArgs a = a0;
@@ -1061,7 +1056,7 @@ int launch_bwd(const AttnArgs& a0, int B, int dh, float* delta, int algo, hipStr
     dx_set_error("dx_attention_bwd: the fused kernel needs bf16, d_head 16, N <= %d (got d_head %d, N %d)", FB_MAXN, dh, a.N);
     return DX_ERR_UNSUPPORTED;
   }
-  if (can_fuse && (algo == DX_ATTN_FUSED || (algo == DX_ATTN_AUTO && fused_bwd_enabled()))) {
+  if (can_fuse && (algo == DX_ATTN_FUSED || algo == DX_ATTN_AUTO)) {
     if (!a.counters) { dx_set_error("dx_attention_bwd: the fused kernel needs the arrival counters (dx_attention_bwd_counters(B, H) ints, zeroed once)"); return DX_ERR_ARG; }
     hipLaunchKernelGGL(attn_bwd_fused16_kernel, dim3(attn_grid(B, 2 * a.H)), dim3(FB_T), 0, s, a, delta + (long)B * a.H * a.N);
     DX_LAUNCH_CHECK();

@@ -123,14 +123,8 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
 // flight), a 128 x 128 x (3 x 32) chunk needs 36 KB for 768 MFMA cycles = 47 B/clk, and the ablations of this kernel
 // give 306 us with the MFMA waves idle, 237 us with the loaders idle, 367 us together.  Past ~800 TFLOP/s the lever
 // is bytes per FLOP per CU (taller position tiles when the batch has enough of them), not the pipeline.
-#ifndef DX_RING
-#define DX_RING 4
-#endif
 #ifndef DX_PLAN_RING
 #define DX_PLAN_RING 3   // stages of the balanced-tile (plan) kernels: 3 x 41 KB (2: main loop 39.5 vs 36.1 us)
-#endif
-#ifndef DX_RING_ABL
-#define DX_RING_ABL 0   // compile-time ablation (development): 1 no fragment reads / MFMAs, 2 no loads, 4 no activation pieces, 8 no weight pieces
 #endif
 // RING: 0 = register-staged single-buffer pipeline; S >= 2 = S-stage LDS ring filled by four loader waves (512 threads, bf16)
 #ifndef CG_K1_BK
@@ -138,19 +132,6 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
 #endif
 #ifndef CG_K1_PF
 #define CG_K1_PF 1   // chunks in flight of the register-staged k = 1 GEMMs (2: measured +-0, 29.8 vs 30.5 us / 20.2 vs 19.6 us: the chunk period is its barrier / LDS chain, not the global round trip)
-#endif
-#ifdef CG_TIMING
-__device__ unsigned long long dx_cg_wg[1024 * 4];   // [workgroup]{start, main loop start, main loop end, end}, s_memrealtime ticks; ring kernels with LNM == CG_TIMING
-__device__ unsigned long long dx_cg_chunk[2 * 64 * 4];   // workgroup 40, loader wave 0 / MFMA wave 0: per chunk {before wait, after wait, after barrier, after issue / MFMAs} (s_memtime)
-#define CG_CHUNK(who, k, i) do { if (LNM == CG_TIMING && RING && blockIdx.x == 40 && lane == 0 && (k) < 64) dx_cg_chunk[((who) * 64 + (k)) * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#ifdef CG_TIMING_K1   // the register-staged k = 1 instantiations instead of the ring kernels (tools/cg_timing_k1.py)
-#define CG_STAMP(i) do { if (LNM == CG_TIMING && !RING && TAPS == 1 && tid == 0) dx_cg_wg[(blockIdx.x & 1023) * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define CG_STAMP(i) do { if (LNM == CG_TIMING && RING && tid == 0) dx_cg_wg[(blockIdx.x & 1023) * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#endif
-#else
-#define CG_STAMP(i)
-#define CG_CHUNK(who, k, i)
 #endif
 template <typename TA, typename TC, typename TO, typename TG, int TAPS, int MI, int BK, int LNM = 0, int RING = 0>
 // (fp32 activations feeding bf16 MFMAs at k = 3 -- instantiations off the bf16 step path, the LayerNorm kernels hand the GEMMs bf16 copies --
@@ -183,7 +164,6 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
   float* stage = reinterpret_cast<float*>(smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  CG_STAMP(0);
   const int l31 = lane & 31, g = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware, weight-stationary order.  Workgroup L runs on XCD L % 8 (observed dispatch order).  Every workgroup
@@ -314,10 +294,9 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
         dst[t] = __builtin_amdgcn_readfirstlane((isw ? AR16 / 16 + q - nA : q) * 512);
       }
       auto issue_chunk = [&](int kc, int buf) {
-        if (DX_RING_ABL & 2) return;
 #pragma unroll
         for (int t = 0; t < MAXP; ++t)
-          if (t < mine && !((DX_RING_ABL & 4) && dst[t] < (AR16 / 16) * 512) && !((DX_RING_ABL & 8) && dst[t] >= (AR16 / 16) * 512))   // ablations: 4 no activation pieces, 8 no weight pieces
+          if (t < mine)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + kc * 32),
                                              (__attribute__((address_space(3))) void*)(ring + buf * STAGE_EL + dst[t]), 16, 0, 0);
       };
@@ -343,7 +322,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
         const long lo = (long)blockIdx.x * fill_per, hi = lo + fill_per;
         const int ltid = lw * 64 + lane;
         long carry = 0;
-        for (int base = 0; base < p.B && carry < hi && !(p.flags & 256); base += 64) {
+        for (int base = 0; base < p.B && carry < hi; base += 64) {
           const int ub = base + lane;
           const int ulen = ub < p.B ? (int)p.skip_len[ub] : N;
           const int dead = ub < p.B ? N - (ulen < 0 ? 0 : (ulen > N ? N : ulen)) : 0;
@@ -380,14 +359,10 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
       int nbuf = RING - 1, k = 0;                                // buffer that chunk k + RING - 1 goes to
       for (; k + RING - 1 < nk; ++k) {
         // (the fill's stores share the counter and may retire out of order with the loads: drain everything once)
-        if (lw == 0) CG_CHUNK(0, k, 0);
         if (PLAN && k == 0 && stores_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else wait_landed(mine * (RING - 2));
-        if (lw == 0) CG_CHUNK(0, k, 1);
         __builtin_amdgcn_s_barrier();
-        if (lw == 0) CG_CHUNK(0, k, 2);
         issue_chunk(k + RING - 1, nbuf);
-        if (lw == 0) CG_CHUNK(0, k, 3);
         nbuf = nbuf + 1 == RING ? 0 : nbuf + 1;
       }
       for (; k < nk; ++k) {
@@ -406,11 +381,9 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
       constexpr int NA = decltype(na_tag)::value;
       int buf = 0;
       for (int k = 0; k < nk; ++k) {
-        if (wave == 0) CG_CHUNK(1, k, 1);
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (wave == 0) CG_CHUNK(1, k, 2);
         if constexpr (NA > 0) {
           const TC* Ar = ring + buf * STAGE_EL;
           const TC* Wr = Ar + AR16 * 32;
@@ -422,30 +395,25 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
 #pragma unroll
             for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const frag_t*>(&Wr[lds_at(tap * BN + wn * 64 + j * 32 + l31, ks * 2 + g)]);
           };
-          if (!(DX_RING_ABL & 1)) {
-            load_frags(0, a[0], bf[0]);
+          load_frags(0, a[0], bf[0]);
 #pragma unroll
-            for (int step = 0; step < NSTEP; ++step) {   // fragments of k-step s + 1 are read before the MFMAs of k-step s
-              if (step + 1 < NSTEP) load_frags(step + 1, a[(step + 1) & 1], bf[(step + 1) & 1]);
-              __builtin_amdgcn_sched_barrier(0);
+          for (int step = 0; step < NSTEP; ++step) {   // fragments of k-step s + 1 are read before the MFMAs of k-step s
+            if (step + 1 < NSTEP) load_frags(step + 1, a[(step + 1) & 1], bf[(step + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-              for (int i = 0; i < NA; ++i)
+            for (int i = 0; i < NA; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) dx_mma(acc[i][j], a[step & 1][i], bf[step & 1][j]);
-            }
+              for (int j = 0; j < 2; ++j) dx_mma(acc[i][j], a[step & 1][i], bf[step & 1][j]);
           }
         }
-        if (wave == 0) CG_CHUNK(1, k, 3);
         buf = buf + 1 == RING ? 0 : buf + 1;
       }
     };
-    CG_STAMP(1);
     if (nact >= MI) mainloop(std::integral_constant<int, MI>{});
     else if (MI > 3 && nact == 3) mainloop(std::integral_constant<int, (MI > 3 ? 3 : MI)>{});
     else if (MI > 2 && nact == 2) mainloop(std::integral_constant<int, (MI > 2 ? 2 : MI)>{});
     else if (MI > 1 && nact == 1) mainloop(std::integral_constant<int, 1>{});
     else mainloop(std::integral_constant<int, 0>{});
-    CG_STAMP(2);
     }
     __syncthreads();                                 // every MFMA wave is done with the ring: the epilogue stages through it
   } else {
@@ -512,7 +480,6 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, PF - 1>;
 
-    CG_STAMP(1);
     fetch(S0{}, 0);
     if constexpr (PF == 2) {
       if (BK < Cin) fetch(S1{}, BK);
@@ -546,7 +513,6 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
         }
       }
     }
-    CG_STAMP(2);
   }
 
   // ---- epilogue
@@ -556,7 +522,6 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
   for (int q = 0; q < NCS; ++q)
 #pragma unroll
     for (int e = 0; e < 8; ++e) csum[q][e] = 0.f;
-  if (PLAN && (p.flags & 1024)) return;
   // PLAN: two teams of 256 threads (MFMA waves / loader waves) take one 64-row slab each per round
   constexpr int ETEAMS = PLAN ? 2 : 1;
   const int team = PLAN ? tid >> 8 : 0, etid = PLAN ? tid & 255 : tid;
@@ -752,13 +717,11 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < RG; ++r) t += stage[(q * RG + r) * BN + c];
-        if (p.flags & 512) continue;
         if (q == 0) atomicAdd(p.ln.dgamma + c, t);
         else if (q == 1) atomicAdd(p.ln.dbeta + c, t);
         else atomicAdd(p.ln.dfilm + (size_t)b * p.ln.lddf + (q == 3 ? BN : 0) + c, t);
       }
     }
-    CG_STAMP(3);
     return;
   }
   // scalar path: transposed output (mel projection) or channel counts that are not multiples of 8
@@ -783,7 +746,6 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
       }
     }
   }
-  CG_STAMP(3);
 }
 
 // ---- weight-stationary variant for short contractions (Cin = 128, Cout a multiple of 256: the FF block's 128 -> 1024
@@ -801,13 +763,6 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
 // MFMAs of the next tile, so no wave waits for another between tiles.  The live position tiles of the batch
 // (skip_lengths) are split evenly over the workgroups of a channel block; dead tiles are zero-filled in a second pass.
 constexpr int WR_THREADS = 512, WR_BN = 256, WR_BM = 128;
-#ifndef WR_ABL
-#define WR_ABL 0   // compile-time ablation (development): 1 no MFMA, 2 no epilogue, 4 no global stores
-#endif
-#ifdef WR_TIMING
-__device__ unsigned long long dx_wreg_ts[8 * 64];   // [wave][stamp] of workgroup WR_TIMING - 1 (development)
-__device__ unsigned long long dx_wreg_wg[1024 * 4]; // [workgroup]{start, after prologue, end of tile loop, end} in s_memrealtime ticks (10 ns)
-#endif
 template <typename TO, typename TG, int TAPS, bool RELU, bool GATE>
 __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, int ngrp) {
   typedef bf16_t TC;
@@ -818,17 +773,11 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
   typedef typename Vec8<TC>::type frag_t;
   __shared__ __attribute__((aligned(16))) char smem[2 * A_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef WR_TIMING
-  if (tid == 0) dx_wreg_wg[blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();
-#endif
   const int l31 = lane & 31, g = lane >> 5;
   const int ztiles = p.Cout / WR_BN, ptiles = dx_cdiv(p.N, BM);
-  // workgroup -> (position group, channel slice).  WR_ZMAJOR: slice-major, so that the ztiles workgroups of one position group sit
-  // 64 indices apart = on the SAME XCD (round-robin dispatch, ngrp % 8 == 0) and read their common activation tiles through one L2
-#ifndef WR_ZMAJOR
-#define WR_ZMAJOR 1
-#endif
-  const bool zmajor = WR_ZMAJOR && (ngrp % 8 == 0);
+  // workgroup -> (position group, channel slice), slice-major: the ztiles workgroups of one position group sit 64 indices apart = on
+  // the SAME XCD (round-robin dispatch, ngrp % 8 == 0) and read their common activation tiles through one L2
+  const bool zmajor = ngrp % 8 == 0;
   const int grp = zmajor ? (int)blockIdx.x % ngrp : (int)blockIdx.x / ztiles, zt = zmajor ? (int)blockIdx.x / ngrp : (int)blockIdx.x % ztiles;
   const int co0 = zt * WR_BN + wave * 32;
   const int N = p.N, Cout = p.Cout;
@@ -982,7 +931,7 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
           for (int j = 0; j < 4; ++j) w[j] = gv[j] > 0.f ? w[j] : 0.f;
         }
         if (zero_row) w = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!(WR_ABL & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w), ry, (int)o, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w), ry, (int)o, 0, 0);
       }
     } else {
       typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -1016,7 +965,7 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
           }
         }
         if (zero_row) w = u32x4{0u, 0u, 0u, 0u};
-        if (!(WR_ABL & 4)) __builtin_amdgcn_raw_buffer_store_b128(w, ry, (int)o, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(w, ry, (int)o, 0, 0);
       }
     }
   };
@@ -1058,12 +1007,6 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   Epi prev{0, N, 0};   // n0 = N: every row out of range, nothing is stored before the first tile
-#ifdef WR_TIMING
-  if (tid == 0) dx_wreg_wg[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-  int nts = 0;
-  auto stamp = [&]() { if (blockIdx.x == WR_TIMING - 1 && lane == 0 && nts < 64) dx_wreg_ts[wave * 64 + nts] = __builtin_amdgcn_s_memtime(); ++nts; };
-  stamp();
-#endif
   while (left > 0) {
     const Epi cur{b, pt * BM, p.mask_len ? (int)p.mask_len[b] : N};
     const TC* As = reinterpret_cast<const TC*>(smem + buf * A_BYTES);
@@ -1074,9 +1017,6 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-#ifdef WR_TIMING
-      stamp();
-#endif
       // epilogue partner: phase A drains acc[2..3] of the previous tile, phase B drains acc[0..1] of this tile
       const Epi& ep = h == 0 ? prev : cur;
 #pragma unroll
@@ -1091,33 +1031,21 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
 #pragma unroll
           for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const frag_t*>(&As[(h * 64 + i * 32 + l31 + tap) * LDK + ks * 16 + g * 8]);
 #pragma unroll
-          for (int i = 0; i < 2; ++i) { if (!(WR_ABL & 1)) dx_mma(acc[h * 2 + i], wreg[tap][ks], a[i]); }
-          if (!(WR_ABL & 2)) epi_slice(tap * KSTEPS + ks, &acc[h == 0 ? 2 : 0], ep, h == 0 ? 1 : 0, cur, h);
+          for (int i = 0; i < 2; ++i) dx_mma(acc[h * 2 + i], wreg[tap][ks], a[i]);
+          epi_slice(tap * KSTEPS + ks, &acc[h == 0 ? 2 : 0], ep, h == 0 ? 1 : 0, cur, h);
         }
       }
     }
     prev = cur;
-#ifdef WR_TIMING
-    stamp();
-#endif
     if (left > 0) commit(buf ^ 1);
     buf ^= 1;
     __syncthreads();
-#ifdef WR_TIMING
-    stamp();
-#endif
   }
-#ifdef WR_TIMING
-  if (tid == 0) dx_wreg_wg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
-#endif
   {   // drain: rows 64..127 of the last tile
 #pragma unroll
     for (int kk = 0; kk < TAPS * KSTEPS; ++kk) epi_slice(kk, &acc[2], prev, 1, Epi{0, N, 0}, 0);
   }
 
-#ifdef WR_TIMING
-  if (tid == 0) dx_wreg_wg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
-#endif
   // ---- dead tiles (start past length + conv halo): zeros, no reads; split evenly like the live ones
   if (p.skip_len) {
     const int cblk = zt * WR_BN;
@@ -1148,16 +1076,6 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
   }
 }
 
-#ifdef CG_TIMING
-}  // namespace
-extern "C" int dx_debug_cg_chunk(unsigned long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dx_cg_chunk), sizeof(unsigned long long) * 2 * 64 * 4);
-}
-extern "C" int dx_debug_cg_wg(unsigned long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dx_cg_wg), sizeof(unsigned long long) * 1024 * 4);
-}
-namespace {
-#endif
 
 // ---- narrow-output k = 3 GEMM with the LayerNorm epilogues, split-K INSIDE the workgroup (conv_sk_kernel) ------------------------
 // The balanced-tile ring kernel above gives every CU one pass over the 786 KB weight slice of a 1024 -> 128 k = 3 GEMM, but its
@@ -1180,18 +1098,6 @@ namespace {
 //     backward: dx_conv1d_lnbwd), the row-wise code of conv_gemm_kernel run by one 256-thread team.
 // The padding rows of the batch (an equal share per workgroup, as in the ring kernel) are zero-filled after the epilogue.
 constexpr int SK_THREADS = 256, SK_S = 4, SK_NB = 4, SK_MAXP = 5;
-#ifndef SK_SPREAD
-#define SK_SPREAD 1   // 1: memory requests of a chunk spread through its MFMA sequence (0: clustered at the chunk start / between the taps)
-#endif
-#ifdef SK_TIMING   // development: per-workgroup stamps of the launches with LNM == SK_TIMING (tools/sk_timing.py), s_memrealtime ticks (10 ns)
-__device__ unsigned long long dx_sk_ts[1024 * 8];
-#define SK_STAMP(i) do { if (LNM == SK_TIMING && threadIdx.x == 0) dx_sk_ts[(blockIdx.x & 1023) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-__device__ unsigned long long dx_sk_chunk[4 * 64 * 8];   // workgroup 40, wave w: per chunk {start, after the DMA wait, after the barrier, after the DMA issue, end} (s_memtime)
-#define SK_CHUNK(k, i) do { if (LNM == SK_TIMING && blockIdx.x == 40 && lane == 0 && (k) < 64) dx_sk_chunk[(wave * 64 + (k)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define SK_STAMP(i)
-#define SK_CHUNK(k, i)
-#endif
 
 __device__ __forceinline__ void sk_dma16(const void* gsrc, unsigned lds_dst) {   // one 1-KiB LDS-DMA piece (16 B per lane)
   unsigned keep;
@@ -1228,7 +1134,6 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
   const int b = e.x, n0 = e.y, h = e.z, fill_per = e.w;
   const int N = p.N, Cin = p.Cin;
   const int len = p.mask_len ? (int)p.mask_len[b] : N;
-  SK_STAMP(0);
 
   if (h > 0) {
     f32x16 acc[MAXBLK][2];
@@ -1297,15 +1202,10 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
     auto chunk = [&](int it, auto slot_tag, auto na_tag) {
       constexpr int U = decltype(slot_tag)::value, NA = decltype(na_tag)::value;
       const int behind = nk - 1 - it;
-      SK_CHUNK(it, 0);
       if (counted) sk_wait_vmcnt(18 + mine * (behind > 2 ? 2 : behind));
       else sk_wait_vmcnt(0);
-      SK_CHUNK(it, 1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      SK_CHUNK(it, 2);
-      if (!SK_SPREAD) { if (it + SK_S - 1 < nk) issue_dma(kc_of(it + SK_S - 1), (it + SK_S - 1) % SK_S); }
-      SK_CHUNK(it, 3);
       const TC* Ar = ring + (it % SK_S) * STAGE_EL;
       const int knext = kc_of(it + SK_NB < nk ? it + SK_NB : nk - 1);
       frag_t a[2][NA];
@@ -1318,7 +1218,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
           for (int i = 0; i < NA; ++i) a[(tap + 1) & 1][i] = *reinterpret_cast<const frag_t*>(&Ar[lds_at(i * 32 + l31 + tap + 1, wk * 2 + g)]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (SK_SPREAD && NA >= 4) {
+        if (NA >= 4) {
           // one wave per SIMD: a vector-memory instruction that finds the CU's request queue full stalls the wave, and MFMAs it has
           // not issued yet with it.  The CU fetches ~25 B/clk from L2, a chunk is 8 KiB-instructions per wave for 24 MFMAs: spread
           // the requests through the MFMA sequence (the matrix pipe works off what was issued while the next request waits)
@@ -1339,7 +1239,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
           __builtin_amdgcn_sched_barrier(0);
           if (tap == TAPS - 1) load_b(knext, tap, bq[U][tap]);
         } else {
-          if (SK_SPREAD && tap == 0) { if (it + SK_S - 1 < nk) issue_dma(kc_of(it + SK_S - 1), (it + SK_S - 1) % SK_S); }
+          if (tap == 0) { if (it + SK_S - 1 < nk) issue_dma(kc_of(it + SK_S - 1), (it + SK_S - 1) % SK_S); }
 #pragma unroll
           for (int i = 0; i < NA; ++i)
 #pragma unroll
@@ -1348,7 +1248,6 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
           load_b(knext, tap, bq[U][tap]);              // refill the slots just read: chunk it + NB
         }
       }
-      SK_CHUNK(it, 4);
     };
     auto mainloop = [&](auto na_tag) {               // nk % 4 == 0 (launcher): four chunks per trip, the fragment ring bq[] is indexed statically
       for (int it = 0; it < nk; it += SK_NB) {
@@ -1358,14 +1257,12 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
         chunk(it + 3, std::integral_constant<int, 3>{}, na_tag);
       }
     };
-    SK_STAMP(1);
     if (nblk > 4) mainloop(std::integral_constant<int, 8>{});
     else if (nblk > 2) mainloop(std::integral_constant<int, 4>{});
     else if (nblk == 2) mainloop(std::integral_constant<int, 2>{});
     else mainloop(std::integral_constant<int, 1>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                   // the ring is dead: exchange / epilogue staging reuse it
-    SK_STAMP(2);
 
     // ---- the two K halves meet: wave (wk, wc) hands its partner (wk ^ 1, wc) the local-1 tiles and adds what it receives to its
     // local-0 tiles: channel block cb = 2 wc + wk, complete (a + b == b + a: the order of the two halves does not matter)
@@ -1387,7 +1284,6 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
         }
       __syncthreads();
     }
-    SK_STAMP(3);
     // ---- LayerNorm epilogue (the PLAN epilogue of conv_gemm_kernel with one 256-thread team)
     constexpr int NCS = LNM == 2 ? 4 : (LNM == 3 ? 2 : 1);
     float csum[NCS][8];
@@ -1607,7 +1503,6 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
       }
     }
   }
-  SK_STAMP(4);
   // ---- padding fill: the batch's padding rows, flattened utterance by utterance, are split evenly over the workgroups; this one
   // owns [lo, hi).  Each wave finds the utterances its range touches with a wave scan over the lengths, and the 256 threads share
   // the 16-byte segments of those rows.
@@ -1653,7 +1548,6 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
       carry += __shfl(incl, 63, 64);
     }
   }
-  SK_STAMP(5);
 }
 
 
@@ -1667,9 +1561,6 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
 // L2 -> CU traffic per launch = 2 bytes x M N K x (1 / 256 + 1 / 256): half of what 256 x 128 tiles fetch.
 // Epilogue: bias, ReLU, rows past length + 2 zeroed; a wave stages one 32-row x 128-channel slab at a time through its own LDS
 // region and stores whole 256-byte row segments in bf16.
-#ifndef WD_KOFF_PT
-#define WD_KOFF_PT 1
-#endif
 constexpr int WD_THREADS = 256, WD_S = 3, WD_RING = 6, WD_MAXP = 5;
 __device__ __forceinline__ void wd_wait_vmcnt(int n) {
   switch (n) {
@@ -1735,7 +1626,7 @@ __global__ __launch_bounds__(WD_THREADS, 1) void conv_wide_kernel(ConvArgs p) {
   // XCD (plan_tiles % 8 == 0) at the same time and read the same activation chunks -- in the same chunk order the first one
   // pulls a chunk into the XCD's L2 and the others hit it (with the rotation keyed on blockIdx they walked the chunks 8 apart and
   // each fetched the activation tile for itself: FETCH_SIZE 188 MB per launch for 61 MB of activations)
-  const int koff = WD_KOFF_PT ? (int)((pt >> 3) % (unsigned)nk) : (int)((blockIdx.x >> 3) % (unsigned)nk);
+  const int koff = (int)((pt >> 3) % (unsigned)nk);
   auto kc_of = [&](int it) { const int k = it + koff; return k >= nk ? k - nk : k; };
   // fragment (k-step q = chunk * 6 + tap * 2 + half, channel block c) at q * (Cout / 32) * 512 + c * 512 elements
   const size_t qstride = (size_t)(Cout >> 5) * 512;
@@ -1887,8 +1778,7 @@ template <typename TA, typename TC, typename TO, typename TG>
 bool try_weight_stationary(const ConvArgs& a, int B, int taps, hipStream_t s) {
   if constexpr (sizeof(TC) != 2 || sizeof(TA) != 2) return false;
   else {
-    static int enabled = getenv("DX_CONV_WST") ? atoi(getenv("DX_CONV_WST")) : 1;
-    if (!enabled || a.ln.enabled || (a.flags & (DX_CONV_TRANSPOSED_OUT | DX_CONV_ACCUMULATE))) return false;
+    if (a.ln.enabled || (a.flags & (DX_CONV_TRANSPOSED_OUT | DX_CONV_ACCUMULATE))) return false;
     if (a.Cin != 128 || a.Cout % WR_BN || a.ldy % 8 || a.ldx % 8) return false;
     const int ztiles = a.Cout / WR_BN;
     // about one workgroup per CU; more position groups than tiles only adds weight loads
@@ -1912,20 +1802,13 @@ bool try_weight_stationary(const ConvArgs& a, int B, int taps, hipStream_t s) {
   }
 }
 
-static bool ring_ok(const ConvArgs& a) {
-  static int enabled = getenv("DX_CONV_RING") ? atoi(getenv("DX_CONV_RING")) : 0;
-  static int min_cin = getenv("DX_CONV_RING_MIN_CIN") ? atoi(getenv("DX_CONV_RING_MIN_CIN")) : 256;
-  return enabled && a.Cin % 32 == 0 && a.Cin >= min_cin && a.Cin <= DX_ZERO_PAGE_EL && a.ldx % 8 == 0;
-}
-
 template <typename TA, typename TC, typename TO, typename TG, int LN = 0>
 int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
   const int ztiles = dx_cdiv(a.Cout, BN);
   // Narrow-output GEMMs (Cout <= 128, k = 3): 128-row tiles stage the weight chunk once per 128 rows (the LDS write of the
   // weight tile is the busiest part of the kernel: 818 vs 609 TFLOP/s on a dense B = 256 problem) but need enough tiles to
   // fill the chip; 64-row tiles otherwise.  Measured in the training step: B = 48 equal, B = 128 +2 % for 128 rows.
-  static int forced_mi = getenv("DX_CONV_NARROW_MI") ? atoi(getenv("DX_CONV_NARROW_MI")) : 0;
-  const int narrow_mi = forced_mi ? forced_mi : ((long)B * a.N > 64000 ? 2 : 1);
+  const int narrow_mi = (long)B * a.N > 64000 ? 2 : 1;
   if constexpr (LN != 0) {   // LayerNorm epilogues: one channel tile (Cout = 128)
     constexpr int LNB = LN == 2 ? 3 : LN;             // backward without FiLM gradients: fewer registers
     const bool film = LN == 2 && a.ln.film != nullptr;
@@ -1956,14 +1839,6 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
           return DX_OK;
         }
       }
-      if (ring_ok(a) && taps == 3) {
-        const long pt2 = (long)dx_cdiv(a.N, 128) * B;
-        dim3 grid2((unsigned)(((pt2 + 7) / 8) * 8));
-        if (film) hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 2, 32, LN, DX_RING>), grid2, dim3(2 * NTHREADS), 0, s, a);
-        else hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 2, 32, LNB, DX_RING>), grid2, dim3(2 * NTHREADS), 0, s, a);
-        DX_LAUNCH_CHECK();
-        return DX_OK;
-      }
     }
     if (narrow_mi == 2 && taps == 3) {
       const long pt2 = (long)dx_cdiv(a.N, 128) * B;
@@ -1986,18 +1861,9 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
     return DX_OK;
   } else {
     if (try_weight_stationary<TA, TC, TO, TG>(a, B, taps, s)) { DX_LAUNCH_CHECK(); return DX_OK; }
-    if constexpr (sizeof(TA) == 2 && sizeof(TC) == 2) {
-      if (ring_ok(a) && taps == 3 && !(a.flags & DX_CONV_TRANSPOSED_OUT)) {
-        const long pt2 = (long)dx_cdiv(a.N, 128) * B;
-        dim3 grid2((unsigned)(((pt2 + 7) / 8) * 8 * ztiles));
-        hipLaunchKernelGGL((conv_gemm_kernel<TA, TC, TO, TG, 3, 2, 32, 0, DX_RING>), grid2, dim3(2 * NTHREADS), 0, s, a);
-        DX_LAUNCH_CHECK();
-        return DX_OK;
-      }
-    }
     // Wide k = 3 GEMMs with a long contraction (prenet 1024 -> 1024): 256-row tiles (MI = 4, a wave owns 128 x 64) when
-    // that still leaves >= 4 workgroups per CU.  The kernel is bound by what a CU can fetch from L2 (~30 B/clk, see
-    // ring_ok), and a taller tile re-uses the taps x 128-channel weight chunk for twice the positions: 930 vs 810 TFLOP/s.
+    // that still leaves >= 4 workgroups per CU.  The kernel is bound by what a CU can fetch from L2 (~30 B/clk),
+    // and a taller tile re-uses the taps x 128-channel weight chunk for twice the positions: 930 vs 810 TFLOP/s.
     static int forced_wide = getenv("DX_CONV_WIDE_MI") ? atoi(getenv("DX_CONV_WIDE_MI")) : 0;
     const int wide_mi = forced_wide ? forced_wide : ((long)dx_cdiv(a.N, 256) * B * ztiles >= 1024 ? 4 : 2);
     const int mi = ztiles == 1 ? (taps == 3 ? narrow_mi : 1) : ((taps == 3 && a.Cin >= 512 && sizeof(TC) == 2) ? wide_mi : 2);
@@ -2043,7 +1909,6 @@ struct WgradArgs {
   const void* dy; long lddy; const void* x; long ldx;
   float* dw; float* db; const int64_t* lengths; float* ws;
   int B, N, Cin, Cout, nsplit, tiles_ci;
-  int debug;   // development ablation switches (DX_WGRAD_DEBUG): 1 = no output, 2 = no gathers/MFMA, 4 = no bias sums
 };
 
 template <typename TC, int TAPS> struct WgradSmem {
@@ -2107,7 +1972,7 @@ __global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wg
       for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
   // bias gradient = dY^T . 1: one extra MFMA per k-step against an all-ones B fragment (published only by the
   // ci0 == 0 tiles' wn == 0 waves) instead of a serial LDS column-sum loop
-  const bool do_bias = p.db && ci0 == 0 && wn == 0 && !(p.debug & 4);
+  const bool do_bias = p.db && ci0 == 0 && wn == 0;
   f32x16 bacc[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -2169,7 +2034,6 @@ __global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wg
         if (n0 >= nlim) { ++b; n0 = 0; nlim = nlim_of(b); }
         fetch(b, n0, nlim);
       }
-      if (!(p.debug & 2))
 #pragma unroll
       for (int ks = 0; ks < WG_P / 16; ++ks) {
         const int kA = ks * 16 + 8 * g, kB = kA + 4;
@@ -2196,28 +2060,26 @@ __global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wg
   };
   if (__builtin_amdgcn_readfirstlane((int)do_bias)) items(std::true_type{});
   else items(std::false_type{});
-  if (!(p.debug & 1)) {
-    if (p.ws) {
-      float* out = p.ws + ((size_t)split * ntiles + tile) * SM::TILE_FLOATS;
+  if (p.ws) {
+    float* out = p.ws + ((size_t)split * ntiles + tile) * SM::TILE_FLOATS;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[((t * 2 + i) * 16 + r) * WG_THREADS + tid] = acc[t][i][r];
+  } else {
+    const int ci = ci0 + wn * 32 + l31;
+    if (ci < Cin) {
 #pragma unroll
       for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) out[((t * 2 + i) * 16 + r) * WG_THREADS + tid] = acc[t][i][r];
-    } else {
-      const int ci = ci0 + wn * 32 + l31;
-      if (ci < Cin) {
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int co = co0 + wm * 64 + i * 32 + dx_acc_row(r, g);
-              if (co < Cout) atomicAdd(p.dw + ((size_t)co * Cin + ci) * TAPS + t, acc[t][i][r]);
-            }
-      }
+          for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 64 + i * 32 + dx_acc_row(r, g);
+            if (co < Cout) atomicAdd(p.dw + ((size_t)co * Cin + ci) * TAPS + t, acc[t][i][r]);
+          }
     }
   }
   if (do_bias && l31 == 0) {   // every column of bacc holds the same row sums; column 0 publishes them
@@ -2266,18 +2128,6 @@ __device__ __forceinline__ bf16x8 gather8_swz(const bf16_t* tile, int kA, int kB
 // register-staged kernel spent 4800 cycles per item on 2048 cycles of MFMA work (two barriers, ds_write staging, and
 // the bias MFMAs in every wave); here the bias gradient is a column sum the loader waves take from the LDS tile.
 constexpr int WGR_THREADS = 768, WGR_RING = 4;
-#ifndef WGR_XCD_BLOCKS
-#define WGR_XCD_BLOCKS 1
-#endif
-#ifndef WGR_AHEAD
-#define WGR_AHEAD 1   // 0: one barrier per item in front of its first fragment reads (A/B build)
-#endif
-#ifndef WGR_BIAS_IN_MFMA_WAVES
-#define WGR_BIAS_IN_MFMA_WAVES 1   // 0: bias column sums by the loader waves from the LDS tile (A/B build)
-#endif
-#ifndef WGR_TAP_SHIFT
-#define WGR_TAP_SHIFT 1   // 0: every tap operand by its own transposed LDS read (A/B build)
-#endif
 template <int TAPS>
 __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradArgs p) {
   constexpr int HALO = TAPS / 2, XROWS = WG_P + TAPS - 1;
@@ -2291,7 +2141,7 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
   // XCD-aware tile order for the 8 x 8 tile grid of a 1024 x 1024 weight (workgroup L runs on XCD L % 8, ntiles % 8 == 0): in index
   // order an XCD owns one ci column of tiles and reads ALL of dY (8 x 61 MB per launch over the chip); dealt as 4 (co) x 2 (ci)
   // blocks it reads half of dY and a quarter of X.  Only the assignment of tile ids to workgroups changes.
-  if (WGR_XCD_BLOCKS && ntiles == 64 && p.tiles_ci == 8) {
+  if (ntiles == 64 && p.tiles_ci == 8) {
     const int x = tile & 7, k8 = tile >> 3;
     tile = (4 * (x >> 2) + (k8 & 3)) * 8 + 2 * (x & 3) + (k8 >> 2);
   }
@@ -2351,7 +2201,7 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
       const int xlim = ilim < N - 1 ? ilim : N - 1;          // X rows are valid for 0 <= n <= min(ilim, N - 1)
 #pragma unroll
       for (int t = 0; t < MAXP; ++t) {
-        if (lw + 4 * t < NP && !(p.debug & 8)) {   // debug 8: no loads (MFMA waves alone)
+        if (lw + 4 * t < NP) {
           const bool isx = t >= TA_SLOTS;
           const int n = in0 + roff[t];
           const bool ok = cok[t] && (isx ? (unsigned)n <= (unsigned)xlim : n < ilim);
@@ -2364,58 +2214,22 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
       in0 += WG_P;                                     // advance to the next item of the list
       if (in0 >= ilim) { ++ib; in0 = 0; ilim = ib < p.B ? nlim_of(ib) : 0; }
     };
-    const bool bias_wg = p.db && ci0 == 0 && !(p.debug & 4);
-    float bs0 = 0.f, bs1 = 0.f;                        // bias gradient: channels 2 * lane, 2 * lane + 1 over rows 16 lw .. 16 lw + 15
-    auto bias_rows = [&](int buf) {
-      const bf16_t* A = ring + buf * ITEM_EL;
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr) {
-        const int r = lw * 16 + rr, c16 = (lane >> 2) ^ ((r & 3) << 2);
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(A + r * 128 + c16 * 8 + (lane & 3) * 2);
-        bs0 += __uint_as_float(v << 16);
-        bs1 += __uint_as_float(v & 0xffff0000u);
-      }
-    };
 #pragma unroll
     for (int st = 0; st < WGR_RING - 1; ++st)
       if (st < count) issue_item(st);
-    if constexpr (WGR_AHEAD) {
-      // Barrier j (j = 0 .. count) promises the MFMA waves that items <= j + 1 have landed and that item j - 1's slot is free: one item
-      // of slack, so that they can read the NEXT item's first fragments during the last k-step of the current one (no LDS round trip
-      // and no barrier wait in the open at every item boundary: that was ~40 % of their loop).  Two items in flight instead of three.
-      if (count > 2) dx_wait_vmcnt(mine); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Barrier j (j = 0 .. count) promises the MFMA waves that items <= j + 1 have landed and that item j - 1's slot is free: one item
+    // of slack, so that they can read the NEXT item's first fragments during the last k-step of the current one (no LDS round trip
+    // and no barrier wait in the open at every item boundary: that was ~40 % of their loop).  Two items in flight instead of three.
+    // (The bias gradient -- column sums of the dY tile -- is taken by the MFMA waves from the fragments they hold.)
+    if (count > 2) dx_wait_vmcnt(mine); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int nbuf = WGR_RING - 1;
+    for (int k = 0; k < count; ++k) {
+      const bool more = k + WGR_RING - 1 < count;
+      if (more) issue_item(nbuf);
+      if (more) dx_wait_vmcnt(mine); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      int nbuf = WGR_RING - 1, buf = 0;
-      for (int k = 0; k < count; ++k) {
-        const bool more = k + WGR_RING - 1 < count;
-        if (more) issue_item(nbuf);
-        if (bias_wg && !WGR_BIAS_IN_MFMA_WAVES) bias_rows(buf);
-        if (more) dx_wait_vmcnt(mine); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        nbuf = nbuf + 1 == WGR_RING ? 0 : nbuf + 1;
-        buf = buf + 1 == WGR_RING ? 0 : buf + 1;
-      }
-    } else {
-    int nbuf = WGR_RING - 1, buf = 0, k = 0;
-    for (; k + WGR_RING - 1 < count; ++k) {
-      dx_wait_vmcnt(mine * (WGR_RING - 2));
-      __builtin_amdgcn_s_barrier();
-      issue_item(nbuf);
-      if (bias_wg) bias_rows(buf);
       nbuf = nbuf + 1 == WGR_RING ? 0 : nbuf + 1;
-      buf = buf + 1 == WGR_RING ? 0 : buf + 1;
-    }
-    for (; k < count; ++k) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (bias_wg) bias_rows(buf);
-      buf = buf + 1 == WGR_RING ? 0 : buf + 1;
-    }
-    }
-    if (bias_wg && !(WGR_AHEAD && WGR_BIAS_IN_MFMA_WAVES && (TAPS == 1 || WGR_TAP_SHIFT))) {
-      const int co = co0 + 2 * lane;
-      if (co < Cout) atomicAdd(p.db + co, bs0);
-      if (co + 1 < Cout) atomicAdd(p.db + co + 1, bs1);
     }
     return;
   }
@@ -2447,9 +2261,9 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
     return __builtin_bit_cast(bf16x8, r);
   };
   constexpr int NKS = WG_P / 16;
-  if (!(p.debug & 16)) __builtin_amdgcn_s_setprio(2);   // the loader wave of this SIMD takes the issue slots the MFMA waves leave (debug 16: equal priority)
+  __builtin_amdgcn_s_setprio(2);   // the loader wave of this SIMD takes the issue slots the MFMA waves leave
   int buf = 0;
-  if constexpr (WGR_AHEAD && (TAPS == 1 || WGR_TAP_SHIFT)) {
+  {
     // software pipeline ACROSS items (see the loader loop: barrier j guarantees item j + 1): the fragments of (item k + 1, k-step 0)
     // are requested in front of the MFMAs of (item k, last k-step); NKS is even, so the fragment double-buffer keeps its parity
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -2464,7 +2278,7 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
     // reads + 32 adds per item ON THE LOADERS' critical path: 5 us of a 41 us launch, 10 us of the MFMA-waves-only ablation).  The four
     // waves of a channel-row group hold the same dY fragments: wave wn sums the fragments of k-step ks == wn (8 positions of one channel
     // per lane and fragment: 16 VALU ops per fragment beside the MFMAs), one register per channel block.
-    const bool bias_here = WGR_BIAS_IN_MFMA_WAVES && p.db && ci0 == 0 && !(p.debug & 4);
+    const bool bias_here = p.db && ci0 == 0;
     float bsum[2] = {0.f, 0.f};
     if (count > 0) {
 #pragma unroll
@@ -2481,8 +2295,7 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         uint32_t tail0 = 0;
-        if (p.debug & 64) {   // (debug 64: no fragment reads inside the loop -- the MFMA sequence alone)
-        } else if (ks + 1 < NKS) {
+        if (ks + 1 < NKS) {
 #pragma unroll
           for (int i = 0; i < 2; ++i) a[(ks + 1) & 1][i] = tr8(A, offA[i], ks + 1);
           f[(ks + 1) & 1] = __builtin_bit_cast(u32x4, tr8(Xs, offX[0], ks + 1));
@@ -2506,26 +2319,22 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
             for (int d = 0; d < 4; ++d) bsum[i] += __uint_as_float(av[d] << 16) + __uint_as_float(av[d] & 0xffff0000u);
           }
         }
-        if (!(p.debug & 2)) {
-          const u32x4 c = f[ks & 1];
-          const bf16x8 bx0 = __builtin_bit_cast(bf16x8, c);
+        const u32x4 c = f[ks & 1];
+        const bf16x8 bx0 = __builtin_bit_cast(bf16x8, c);
 #pragma unroll
-          for (int i = 0; i < 2; ++i) dx_mma(acc[0][i], a[ks & 1][i], bx0);
-          if constexpr (TAPS == 3) {
-            const uint32_t nxt = ks + 1 < NKS ? f[(ks + 1) & 1][0] : tail0;
-            const u32x2v sw = __builtin_amdgcn_permlane32_swap(c[0], nxt, false, false);
-            const uint32_t n0 = g ? sw[0] : sw[1];        // first two positions of the next 8-position block of this lane's channel
-            const u32x4 t1 = {__builtin_amdgcn_alignbit(c[1], c[0], 16), __builtin_amdgcn_alignbit(c[2], c[1], 16),
-                              __builtin_amdgcn_alignbit(c[3], c[2], 16), __builtin_amdgcn_alignbit(n0, c[3], 16)};
-            const u32x4 t2 = {c[1], c[2], c[3], n0};
-            const bf16x8 bx1 = __builtin_bit_cast(bf16x8, t1), bx2 = __builtin_bit_cast(bf16x8, t2);
-            if (!(p.debug & 32)) {
+        for (int i = 0; i < 2; ++i) dx_mma(acc[0][i], a[ks & 1][i], bx0);
+        if constexpr (TAPS == 3) {
+          const uint32_t nxt = ks + 1 < NKS ? f[(ks + 1) & 1][0] : tail0;
+          const u32x2v sw = __builtin_amdgcn_permlane32_swap(c[0], nxt, false, false);
+          const uint32_t n0 = g ? sw[0] : sw[1];        // first two positions of the next 8-position block of this lane's channel
+          const u32x4 t1 = {__builtin_amdgcn_alignbit(c[1], c[0], 16), __builtin_amdgcn_alignbit(c[2], c[1], 16),
+                            __builtin_amdgcn_alignbit(c[3], c[2], 16), __builtin_amdgcn_alignbit(n0, c[3], 16)};
+          const u32x4 t2 = {c[1], c[2], c[3], n0};
+          const bf16x8 bx1 = __builtin_bit_cast(bf16x8, t1), bx2 = __builtin_bit_cast(bf16x8, t2);
 #pragma unroll
-              for (int i = 0; i < 2; ++i) dx_mma(acc[TAPS > 1 ? 1 : 0][i], a[ks & 1][i], bx1);
+          for (int i = 0; i < 2; ++i) dx_mma(acc[TAPS > 1 ? 1 : 0][i], a[ks & 1][i], bx1);
 #pragma unroll
-              for (int i = 0; i < 2; ++i) dx_mma(acc[TAPS > 2 ? 2 : 0][i], a[ks & 1][i], bx2);
-            }
-          }
+          for (int i = 0; i < 2; ++i) dx_mma(acc[TAPS > 2 ? 2 : 0][i], a[ks & 1][i], bx2);
         }
       }
       asm volatile("" ::: "memory");
@@ -2541,81 +2350,8 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
         if (g == 0 && co < Cout) atomicAdd(p.db + co, t);
       }
     }
-  } else
-  for (int k = 0; k < count; ++k) {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const bf16_t* A = ring + buf * ITEM_EL;
-    const bf16_t* Xs = A + A_PIECES * 512;
-    if (!(p.debug & 2)) {
-      if constexpr (TAPS == 3 && WGR_TAP_SHIFT) {
-        // The three tap operands of a k-step are the SAME 8-position window of the X tile moved by 0 / 1 / 2 rows, and a lane holds its
-        // 8 positions as 4 dwords: tap 2 is a register renaming plus one dword of the next 8-position block, tap 1 a 16-bit funnel
-        // shift over the same five dwords.  The next block's first dword sits in the other half-wave (g = 0: lane + 32, same k-step;
-        // g = 1: lane - 32, next k-step) -- one v_permlane32_swap + one select.  One transposed read pair per k-step instead of three:
-        // 0.54 instead of 0.83 KB of LDS reads per MFMA (the kernel is LDS-bound: 2500 cycles per item for 1546 cycles of MFMA work).
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
-        bf16x8 a[2][2];
-        u32x4 f[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[0][i] = tr8(A, offA[i], 0);
-        f[0] = __builtin_bit_cast(u32x4, tr8(Xs, offX[0], 0));
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-          if (ks + 1 < NKS) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[(ks + 1) & 1][i] = tr8(A, offA[i], ks + 1);
-            f[(ks + 1) & 1] = __builtin_bit_cast(u32x4, tr8(Xs, offX[0], ks + 1));
-          } else {   // rows 64 .. 67 of the haloed tile (64, 65 are its last two rows; the piece they sit in is 4 rows tall)
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Xs + offX[0] + NKS * 16 * 128 - g * 8 * 128));   // (both half-waves read rows 64 + lj: only lanes 0 - 31 are consumed)
-            const u32x2v lo2 = __builtin_bit_cast(u32x2v, lo);
-            f[(ks + 1) & 1] = u32x4{lo2[0], lo2[1], 0u, 0u};
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          const u32x4 c = f[ks & 1];
-          const u32x2v sw = __builtin_amdgcn_permlane32_swap(c[0], f[(ks + 1) & 1][0], false, false);
-          const uint32_t n0 = g ? sw[0] : sw[1];        // first two positions of the next 8-position block of this lane's channel
-          const u32x4 t1 = {__builtin_amdgcn_alignbit(c[1], c[0], 16), __builtin_amdgcn_alignbit(c[2], c[1], 16),
-                            __builtin_amdgcn_alignbit(c[3], c[2], 16), __builtin_amdgcn_alignbit(n0, c[3], 16)};
-          const u32x4 t2 = {c[1], c[2], c[3], n0};
-          const bf16x8 bx0 = __builtin_bit_cast(bf16x8, c), bx1 = __builtin_bit_cast(bf16x8, t1), bx2 = __builtin_bit_cast(bf16x8, t2);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) dx_mma(acc[0][i], a[ks & 1][i], bx0);
-          if (!(p.debug & 32)) {   // (debug 32: one tap's MFMAs only -- does the item time follow the MFMA count?)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) dx_mma(acc[1][i], a[ks & 1][i], bx1);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) dx_mma(acc[2][i], a[ks & 1][i], bx2);
-          }
-        }
-      } else {
-      bf16x8 a[2][2], bx[2][TAPS];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[0][i] = tr8(A, offA[i], 0);
-#pragma unroll
-      for (int t = 0; t < TAPS; ++t) bx[0][t] = tr8(Xs, offX[t], 0);
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        if (ks + 1 < NKS) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i) a[(ks + 1) & 1][i] = tr8(A, offA[i], ks + 1);
-#pragma unroll
-          for (int t = 0; t < TAPS; ++t) bx[(ks + 1) & 1][t] = tr8(Xs, offX[t], ks + 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) dx_mma(acc[t][i], a[ks & 1][i], bx[ks & 1][t]);
-      }
-      }
-    }
-    buf = buf + 1 == WGR_RING ? 0 : buf + 1;
   }
   __builtin_amdgcn_s_setprio(0);
-  if (p.debug & 1) return;
   if (p.ws) {
     float* out = p.ws + ((size_t)split * ntiles + tile) * (TAPS * 2 * 16 * WG_THREADS);
 #pragma unroll
@@ -2756,22 +2492,20 @@ template <typename TA, typename TB, typename TC>
 int launch_wgrad(const WgradArgs& a, int taps, hipStream_t s, bool reduce = true) {
   const int ntiles = dx_cdiv(a.Cout, WG_CO) * a.tiles_ci;
   dim3 grid(ntiles * a.nsplit), block(WG_THREADS);
-  static int use_ring = getenv("DX_WGRAD_RING") ? atoi(getenv("DX_WGRAD_RING")) : 1;
-  const bool ring = use_ring && sizeof(TA) == 2 && sizeof(TB) == 2 && sizeof(TC) == 2 && a.lddy % 8 == 0 && a.ldx % 8 == 0 &&
+  const bool ring = sizeof(TA) == 2 && sizeof(TB) == 2 && sizeof(TC) == 2 && a.lddy % 8 == 0 && a.ldx % 8 == 0 &&
                     a.Cout % 8 == 0 && a.Cin % 8 == 0;
   // k = 1 (QKV / output projections): round 3 kept the register-staged kernel at 192 workgroups (the ring kernel at 192 was 0.15 % slower).
   // With FEWER, longer-lived workgroups the ring kernel wins: a 64-split launch has 7 items per workgroup and is all prologue + partial
   // tile; 64 workgroups (21 splits of the 3 QKV tiles) on the 4-deep ring: 7.61 vs 7.64 ms per step, a third of the partial-tile traffic
-  static int ring_k1 = getenv("DX_WGRAD_RING_K1") ? atoi(getenv("DX_WGRAD_RING_K1")) : 1;
   if (taps == 1) {
-    if (ring && ring_k1) hipLaunchKernelGGL((conv_wgrad_ring_kernel<1>), grid, dim3(WGR_THREADS), 0, s, a);
+    if (ring) hipLaunchKernelGGL((conv_wgrad_ring_kernel<1>), grid, dim3(WGR_THREADS), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 1>), grid, block, 0, s, a);
-    if (reduce && a.ws && !(a.debug & 1))
+    if (reduce && a.ws)
       hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(ntiles * (1 * 2 * 16 * WG_THREADS / 4 / 64)), dim3(256), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
   } else {
     if (ring) hipLaunchKernelGGL((conv_wgrad_ring_kernel<3>), grid, dim3(WGR_THREADS), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<TA, TB, TC, 3>), grid, block, 0, s, a);
-    if (reduce && a.ws && !(a.debug & 1))
+    if (reduce && a.ws)
       hipLaunchKernelGGL((wgrad_reduce_kernel<3>), dim3(ntiles * (3 * 2 * 16 * WG_THREADS / 4 / 64)), dim3(256), 0, s, a.ws, a.dw, a.nsplit, ntiles, a.tiles_ci, a.Cout, a.Cin);
   }
   DX_LAUNCH_CHECK();
@@ -2918,9 +2652,7 @@ static int wgrad_nsplit(int B, int N, int Cin, int Cout, int taps) {
   // how fast they finish alone but how little they slow the main stream down.  Measured per training step with the
   // 128 x 128 tiles (B = 48, T <= 1000): 64 -> 10.73 ms, 128 -> 10.46, 160 -> 10.45, 192 -> 10.30, 224 -> 10.35,
   // 256 -> 10.42, 320 -> 10.69; B = 128: 192 -> 22.1, 256 -> 22.5, 384 -> 23.2.  3/4 of the CUs, 8 waves each.
-  static int fixed = getenv("DX_WGRAD_BLOCKS") ? atoi(getenv("DX_WGRAD_BLOCKS")) : 0;
-  static int fixed_k1 = getenv("DX_WGRAD_BLOCKS_K1") ? atoi(getenv("DX_WGRAD_BLOCKS_K1")) : 0;
-  const int target = taps == 1 ? (fixed_k1 > 0 ? fixed_k1 : (fixed > 0 ? fixed : 64)) : (fixed > 0 ? fixed : 192);   // k = 1: see launch_wgrad
+  const int target = taps == 1 ? 64 : 192;   // k = 1: see launch_wgrad (24: +0.2 ms per step, 96 / 128: +0.02, 192: +0.05)
   const int tiles = dx_cdiv(Cout, WG_CO) * dx_cdiv(Cin, WG_CI);
   // every split costs one more partial tile to write and re-read: keep >= ~8 items (64 positions each) per workgroup,
   // 16 for the linear layers (a third of the MFMA work per item)
@@ -2943,11 +2675,8 @@ static int wgrad_one(const void* dy, int dy_dtype, long lddy, const void* x, int
   DX_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0, DX_ERR_SHAPE,
              "dx_conv1d_wgrad: Cin, Cout and the row strides must be multiples of 8");
   DX_REQUIRE(taps == 1 || taps == 3, DX_ERR_UNSUPPORTED, "dx_conv1d_wgrad: taps=%d (only 1 and 3)", taps);
-  static int dbg = getenv("DX_WGRAD_DEBUG") ? atoi(getenv("DX_WGRAD_DEBUG")) : 0;
   // k = 1 weight gradients (QKV / output projections, 16 k - 49 k elements): partial tiles + reduce launch, or fp32 atomics on dW
-  static int k1_atomic = getenv("DX_WGRAD_K1_ATOMIC") ? atoi(getenv("DX_WGRAD_K1_ATOMIC")) : 0;
-  if (taps == 1 && k1_atomic) ws = nullptr;
-  WgradArgs a{dy, lddy, x, ldx, dw, db, lengths, ws, B, N, Cin, Cout, wgrad_nsplit(B, N, Cin, Cout, taps), dx_cdiv(Cin, WG_CI), dbg};
+  WgradArgs a{dy, lddy, x, ldx, dw, db, lengths, ws, B, N, Cin, Cout, wgrad_nsplit(B, N, Cin, Cout, taps), dx_cdiv(Cin, WG_CI)};
   if (out) *out = a;
   if (compute_dtype == DX_BF16) {
     if (dy_dtype == DX_F32 && x_dtype == DX_F32) return launch_wgrad<float, float, bf16_t>(a, taps, s, reduce);
@@ -2987,7 +2716,7 @@ extern "C" int dx_conv1d_wgrad_multi(const DxWgradDesc* d, int n, int compute_dt
     if (int rc = wgrad_one(d[i].dy, d[i].dy_dtype, d[i].lddy, d[i].x, d[i].x_dtype, d[i].ldx, compute_dtype, d[i].dw, d[i].db, lengths, wsp, B, N,
                            d[i].Cin, d[i].Cout, d[i].taps, s, false, &a)) return rc;
     const int ntiles = dx_cdiv(a.Cout, WG_CO) * a.tiles_ci;
-    if (a.ws && !(a.debug & 1)) {          // (k = 1 with DX_WGRAD_K1_ATOMIC went straight to dW)
+    if (a.ws) {
       const int k = m.n++;
       m.ws[k] = a.ws; m.dw[k] = a.dw; m.nsplit[k] = a.nsplit; m.ntiles[k] = ntiles; m.tiles_ci[k] = a.tiles_ci; m.Cout[k] = a.Cout; m.Cin[k] = a.Cin;
       m.taps[k] = d[i].taps; m.begin[k] = blocks;
@@ -3132,7 +2861,6 @@ extern "C" int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_
                "taps = 3, plan + fragment-order weights, Cin %% 128 == 0, B * N <= 65536)");
     a.ln.w2 = w2_packed; a.ln.y2 = y2; a.ln.b2 = b2; a.ln.n2 = n2;
   }
-  { static int dbg = getenv("DX_PLAN_DEBUG") ? atoi(getenv("DX_PLAN_DEBUG")) : 0; a.flags |= dbg; }
   hipStream_t s = (hipStream_t)stream;
   if (w_dtype == DX_BF16 && x_dtype == DX_BF16) return launch_taps<bf16_t, bf16_t, float, float, 1>(a, B, taps, s);
   if (w_dtype == DX_BF16 && x_dtype == DX_F32) return launch_taps<float, bf16_t, float, float, 1>(a, B, taps, s);
@@ -3166,7 +2894,6 @@ extern "C" int dx_conv1d_lnbwd(const void* x, int x_dtype, long ldx, const void*
                "Cin %% 128 == 0, B * N <= 65536)");
     a.ln.w2 = w2_packed; a.ln.y2 = y2; a.ln.b2 = nullptr; a.ln.n2 = BN;
   }
-  { static int dbg = getenv("DX_PLAN_DEBUG") ? atoi(getenv("DX_PLAN_DEBUG")) : 0; a.flags |= dbg; }
   hipStream_t s = (hipStream_t)stream;
   if (w_dtype == DX_BF16 && x_dtype == DX_BF16) return launch_taps<bf16_t, bf16_t, float, float, 2>(a, B, taps, s);
   if (w_dtype == DX_BF16 && x_dtype == DX_F32) return launch_taps<float, bf16_t, float, float, 2>(a, B, taps, s);
@@ -3185,14 +2912,6 @@ __global__ void pack_frag_major_batched_kernel(const FragDesc* __restrict__ desc
 }
 }  // namespace
 
-#ifdef SK_TIMING
-extern "C" int dx_debug_sk_chunk(unsigned long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dx_sk_chunk), sizeof(unsigned long long) * 4 * 64 * 8);
-}
-extern "C" int dx_debug_sk_ts(unsigned long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dx_sk_ts), sizeof(unsigned long long) * 1024 * 8);
-}
-#endif
 extern "C" int dx_frag_desc_size(void) { return (int)sizeof(FragDesc); }
 
 extern "C" int dx_pack_frag_major_batched(const void* descs_dev, int n, long max_elems, void* stream) {
