@@ -4,7 +4,7 @@
 # kernel trace + step timeline, three separate PMC passes (FETCH_SIZE / WRITE_SIZE / MFMA busy: they do not fit the TCC
 # slots together, and gpurun refuses --pmc combined with the other trace domains), bench lines of C2 / C5 / C4.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

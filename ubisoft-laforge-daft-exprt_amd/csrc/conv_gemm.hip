@@ -2129,15 +2129,15 @@ __device__ __forceinline__ bf16x8 gather8_swz(const bf16_t* tile, int kA, int kB
 // the bias MFMAs in every wave); here the bias gradient is a column sum the loader waves take from the LDS tile.
 constexpr int WGR_THREADS = 768, WGR_RING = 4;
 template <int TAPS>
-__global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradArgs p) {
+__device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, const int bid) {
   constexpr int HALO = TAPS / 2, XROWS = WG_P + TAPS - 1;
   constexpr int A_PIECES = WG_P / 4, X_PIECES = (XROWS + 3) / 4, NP = A_PIECES + X_PIECES, ITEM_EL = NP * 512, MAXP = (NP + 3) / 4;
   static_assert(MAXP * (WGR_RING - 2) <= 36, "vmcnt switch too short");
   __shared__ __attribute__((aligned(16))) bf16_t ring[WGR_RING * ITEM_EL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
   const int ntiles = dx_cdiv(p.Cout, WG_CO) * p.tiles_ci;
-  const int split = blockIdx.x / ntiles;
-  int tile = blockIdx.x % ntiles;
+  const int split = bid / ntiles;
+  int tile = bid % ntiles;
   // XCD-aware tile order for the 8 x 8 tile grid of a 1024 x 1024 weight (workgroup L runs on XCD L % 8, ntiles % 8 == 0): in index
   // order an XCD owns one ci column of tiles and reads ALL of dY (8 x 61 MB per launch over the chip); dealt as 4 (co) x 2 (ci)
   // blocks it reads half of dY and a quarter of X.  Only the assignment of tile ids to workgroups changes.
@@ -2374,6 +2374,18 @@ __global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradAr
           }
     }
   }
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_kernel(WgradArgs p) { wgrad_ring_body<TAPS>(p, (int)blockIdx.x); }
+// TWO weight gradients over the same rows in one launch: workgroups [0, na) run problem a, the rest problem b (the k = 1 pair of an FFT
+// block -- output projection, 48 workgroups, and QKV projection, 63 -- used to run back to back on the side queue, each on a fifth of
+// the CUs; side by side they take the time of the longer one).  One call site of the body: one LDS ring.
+struct WgradPair { WgradArgs a, b; int na; };
+template <int TAPS>
+__global__ __launch_bounds__(WGR_THREADS, 3) void conv_wgrad_ring_pair_kernel(WgradPair q) {
+  const bool second = (int)blockIdx.x >= q.na;
+  wgrad_ring_body<TAPS>(second ? q.b : q.a, second ? (int)blockIdx.x - q.na : (int)blockIdx.x);
 }
 
 // dW += sum over the splits of the partial tiles (register order, see conv_wgrad_kernel).  One thread per 4 consecutive
@@ -2669,7 +2681,8 @@ extern "C" long dx_conv1d_wgrad_ws_floats(int B, int N, int Cin, int Cout, int t
 }
 
 static int wgrad_one(const void* dy, int dy_dtype, long lddy, const void* x, int x_dtype, long ldx, int compute_dtype, float* dw, float* db,
-                     const int64_t* lengths, float* ws, int B, int N, int Cin, int Cout, int taps, hipStream_t s, bool reduce, WgradArgs* out) {
+                     const int64_t* lengths, float* ws, int B, int N, int Cin, int Cout, int taps, hipStream_t s, bool reduce, WgradArgs* out,
+                     bool launch = true) {
   DX_REQUIRE(dy && x && dw, DX_ERR_ARG, "dx_conv1d_wgrad: null pointer");
   DX_REQUIRE(B > 0 && N > 0 && Cin > 0 && Cout > 0, DX_ERR_SHAPE, "dx_conv1d_wgrad: empty shape");
   DX_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0, DX_ERR_SHAPE,
@@ -2678,6 +2691,12 @@ static int wgrad_one(const void* dy, int dy_dtype, long lddy, const void* x, int
   // k = 1 weight gradients (QKV / output projections, 16 k - 49 k elements): partial tiles + reduce launch, or fp32 atomics on dW
   WgradArgs a{dy, lddy, x, ldx, dw, db, lengths, ws, B, N, Cin, Cout, wgrad_nsplit(B, N, Cin, Cout, taps), dx_cdiv(Cin, WG_CI)};
   if (out) *out = a;
+  if (!launch) {   // (the caller launches: only the dtype combination is checked here)
+    const bool ok = compute_dtype == DX_BF16 ? ((dy_dtype == DX_F32 || dy_dtype == DX_BF16) && (x_dtype == DX_F32 || x_dtype == DX_BF16))
+                                             : (compute_dtype == DX_F32 && dy_dtype == DX_F32 && x_dtype == DX_F32);
+    DX_REQUIRE(ok, DX_ERR_DTYPE, "dx_conv1d_wgrad: unsupported dtype combination dy=%d x=%d compute=%d", dy_dtype, x_dtype, compute_dtype);
+    return DX_OK;
+  }
   if (compute_dtype == DX_BF16) {
     if (dy_dtype == DX_F32 && x_dtype == DX_F32) return launch_wgrad<float, float, bf16_t>(a, taps, s, reduce);
     if (dy_dtype == DX_F32 && x_dtype == DX_BF16) return launch_wgrad<float, bf16_t, bf16_t>(a, taps, s, reduce);
@@ -2711,10 +2730,26 @@ extern "C" int dx_conv1d_wgrad_multi(const DxWgradDesc* d, int n, int compute_dt
   MultiReduceArgs m{};
   int blocks = 0;
   float* wsp = ws;
+  auto ring1 = [&](int i) {   // a k = 1 weight gradient the ring kernel takes (launch_wgrad's condition)
+    return i < n && d[i].taps == 1 && compute_dtype == DX_BF16 && d[i].dy_dtype == DX_BF16 && d[i].x_dtype == DX_BF16 && d[i].lddy % 8 == 0 &&
+           d[i].ldx % 8 == 0 && d[i].Cout % 8 == 0 && d[i].Cin % 8 == 0;
+  };
+  bool paired = false;   // descriptor i was launched together with i - 1
   for (int i = 0; i < n; ++i) {
     WgradArgs a;
+    const bool pair = !paired && ring1(i) && ring1(i + 1);
     if (int rc = wgrad_one(d[i].dy, d[i].dy_dtype, d[i].lddy, d[i].x, d[i].x_dtype, d[i].ldx, compute_dtype, d[i].dw, d[i].db, lengths, wsp, B, N,
-                           d[i].Cin, d[i].Cout, d[i].taps, s, false, &a)) return rc;
+                           d[i].Cin, d[i].Cout, d[i].taps, s, false, &a, !(pair || paired))) return rc;
+    if (pair) {
+      WgradArgs b2;
+      float* wsb = wsp + dx_conv1d_wgrad_ws_floats(B, N, d[i].Cin, d[i].Cout, d[i].taps);
+      if (int rc = wgrad_one(d[i + 1].dy, d[i + 1].dy_dtype, d[i + 1].lddy, d[i + 1].x, d[i + 1].x_dtype, d[i + 1].ldx, compute_dtype, d[i + 1].dw,
+                             d[i + 1].db, lengths, wsb, B, N, d[i + 1].Cin, d[i + 1].Cout, d[i + 1].taps, s, false, &b2, false)) return rc;
+      WgradPair q{a, b2, dx_cdiv(a.Cout, WG_CO) * a.tiles_ci * a.nsplit};
+      const int nb = dx_cdiv(b2.Cout, WG_CO) * b2.tiles_ci * b2.nsplit;
+      hipLaunchKernelGGL((conv_wgrad_ring_pair_kernel<1>), dim3(q.na + nb), dim3(WGR_THREADS), 0, s, q);
+    }
+    paired = pair;
     const int ntiles = dx_cdiv(a.Cout, WG_CO) * a.tiles_ci;
     if (a.ws) {
       const int k = m.n++;
