@@ -45,6 +45,6 @@ python bench.py --workload synth --batch 256 --steps 10 --warmup 3 > $OUT/${TAG}
 # the multi-rank code path on real RCCL through a one-rank world: what the process group, the per-bucket all-reduce
 # hooks and the per-bucket optimizer cost before any byte crosses xGMI
 DX_FORCE_DIST=1 python bench.py --no-secondary --no-cpu-baseline 2> $OUT/bench_rccl.err | grep "^{" > $OUT/${TAG}_bench_one_rank_rccl.json
-grep "bench\]" $OUT/bench_rccl.err > $OUT/${TAG}_one_rank_rccl_reducer.txt
+grep "bench rank" $OUT/bench_rccl.err > $OUT/${TAG}_one_rank_rccl_reducer.txt
 cat $OUT/counters_summary.txt
 head -c 400 $OUT/${TAG}_bench.json; echo
