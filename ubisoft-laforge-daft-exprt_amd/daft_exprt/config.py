@@ -9,7 +9,7 @@ the module attributes they exercise (`ops.USE_SPLITK`, `ops.USE_WIDE`, `ops.USE_
 |---|---|---|
 | DX_HIP_LIB | in-tree csrc/libdaftexprt_hip.so | another build of the library (`DX_BUILD_TAG=... python build_hip.py`) for same-box A/B runs |
 | DX_WGRAD_SIDE_STREAM | 1 | 0: weight gradients on the launch stream (no second hardware queue) |
-| DX_SKIP_WGRAD | 0 | 1: skip every weight gradient (measurement protocol of DESIGN 5: what the side-stream work costs the step) |
+| DX_SKIP_WGRAD | 0 | measurement protocol of DESIGN 5 (what the side-stream work costs the step): 1 skips every weight gradient, 2 only the FF ones (128 <-> 1024), 3 only the 1024 x 1024 pre-net one, 4 only the k = 1 ones |
 | DX_FORCE_DIST | 0 | 1: a ONE-rank process group issues every collective of the multi-rank path (tests/test_gpu_ddp.py) |
 | DX_STREAM_PROBE | 1 | 0: streams straight from torch's pool, no hardware-queue probes (`streams.py`) |
 | DX_SECTIONED_ADAM | auto | per-bucket Adam behind each bucket's all-reduce; auto = only with more than one rank |
@@ -25,7 +25,7 @@ def _flag(name, default):
 
 HIP_LIB = os.environ.get('DX_HIP_LIB') or None
 WGRAD_SIDE_STREAM = _flag('DX_WGRAD_SIDE_STREAM', '1')
-SKIP_WGRAD = _flag('DX_SKIP_WGRAD', '0')
+SKIP_WGRAD = int(os.environ.get('DX_SKIP_WGRAD', '0'))   # 1: all; 2 / 3 / 4: only the FF / the 1024 x 1024 pre-net / the k = 1 ones (where does the cost sit?)
 STREAM_PROBE = _flag('DX_STREAM_PROBE', '1')
 SECTIONED_ADAM = os.environ.get('DX_SECTIONED_ADAM', 'auto')
 STEP_GRAPH = os.environ.get('DX_STEP_GRAPH', '0')

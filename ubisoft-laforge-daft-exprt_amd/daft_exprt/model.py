@@ -732,7 +732,10 @@ class DaftExprt(nn.Module):
             (nothing downstream reads dW before the optimizer step), so they overlap with the data-gradient chain. '''
         side = self._side_stream
         if config.SKIP_WGRAD:                           # measurement protocol (DESIGN 5): what the side-stream work costs the step
-            return
+            wide = (dy.shape[2] >= 1024) + (x.shape[2] >= 1024)
+            if config.SKIP_WGRAD == 1 or (config.SKIP_WGRAD == 2 and wide == 1) or (config.SKIP_WGRAD == 3 and wide == 2) or \
+                    (config.SKIP_WGRAD == 4 and dw.dim() == 2):
+                return
         if side is None:
             return ops.conv1d_wgrad(dy, x, dw, db, self.cd, lengths)
         # queued: the launches of a whole FFT block (or conv + LayerNorm stage) go out together behind ONE event hop
