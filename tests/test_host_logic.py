@@ -212,3 +212,31 @@ def test_dropout_seeds_differ_between_ranks():
     sa = [a._seed() for _ in range(4)]
     sb = [b._seed() for _ in range(4)]
     assert len(set(sa + sb)) == 8 and all(0 <= v < 2 ** 63 for v in sa + sb)
+
+
+def test_grouped_micro_batches_host_side():
+    ''' `data_loader.group_host_batches` / `group_micro_batches`: the micro-batches of an optimizer step concatenated and padded to the
+        group's maxima, every utterance carrying the padded length of its OWN micro-batch (n_max) and the skip length
+        min(len, n_max - 2) the kernels need; contents of every micro-batch preserved, padding zero '''
+    from daft_exprt.data_loader import group_host_batches, group_micro_batches, synthetic_batch
+    hp = make_hparams(batch_size=3, accumulation_steps=3)
+    bs = [synthetic_batch(hp, 3, seed=10 + k, t_max=t, force_first_full=True, l_range=(5 + 4 * k, 12 + 4 * k)) for k, t in enumerate((90, 40, 61))]
+    merged, (nmax_in, nmax_out), sizes = group_host_batches(bs)
+    assert sizes == [3, 3, 3] and len(merged) == 13 and len(merged[11]) == 9 and len(merged[12]) == 9
+    Lg, Tg = max(b[0].shape[1] for b in bs), 90
+    assert merged[0].shape == (9, Lg) and merged[8].shape == (9, 80, Tg) and merged[6].shape == (9, Tg)
+    assert nmax_out.tolist() == [90] * 3 + [40] * 3 + [61] * 3
+    assert nmax_in.tolist() == sum(([b[0].shape[1]] * 3 for b in bs), [])
+    row = 0
+    for b in bs:
+        L, T = b[0].shape[1], b[8].shape[2]
+        assert torch.equal(merged[0][row:row + 3, :L], b[0]) and not merged[0][row:row + 3, L:].any()
+        assert torch.equal(merged[8][row:row + 3, :, :T], b[8]) and not merged[8][row:row + 3, :, T:].any()
+        assert torch.equal(merged[9][row:row + 3], b[9]) and torch.equal(merged[5][row:row + 3], b[5])
+        row += 3
+    g = group_micro_batches([(b[:11], None) for b in bs])
+    skip_in, n_in, skip_out, n_out = g.bounds
+    assert torch.equal(n_out, nmax_out) and torch.equal(n_in, nmax_in) and g.accum == 3
+    assert torch.equal(skip_out, torch.clamp(torch.minimum(merged[9], nmax_out - 2), min=0))
+    assert int((merged[9] - skip_out).max()) == 2        # the utterance that fills its micro-batch: rows len - 2 .. are its last live ones
+    assert all(t is u for t, u in zip(g.targets, (g.inputs[1], g.inputs[3], g.inputs[4], g.inputs[8], g.inputs[10])))

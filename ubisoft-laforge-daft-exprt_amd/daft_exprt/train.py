@@ -479,10 +479,11 @@ def train(gpu, hparams, log_file):
 
     group = trainer.group and hparams.accumulation_steps > 1
 
+    held = []     # micro-batches of an unfinished group: carried over an epoch boundary like the reference's accumulation counter (train.py:391-397)
+
     def host_units():
         ''' collate outputs, one per forward / backward pass: the loader's batches, or -- grouped micro-batches -- the
             `accumulation_steps` batches of an optimizer step merged on the host (`group_host_batches`) '''
-        held = []
         for batch in loader:
             if not group:
                 yield batch, None
@@ -490,7 +491,7 @@ def train(gpu, hparams, log_file):
             held.append(batch)
             if len(held) == hparams.accumulation_steps:
                 merged, nmax, sizes = group_host_batches(held)
-                held = []
+                held.clear()
                 yield merged, (nmax, sizes)
 
     def device_batches():
