@@ -14,6 +14,15 @@
  *   - return 0 on success, a negative DX_ERR_* code otherwise; dx_last_error() gives the message
  *     (thread-local).  Argument violations mirror the reference's asserts as errors, never UB.
  *   - dtype codes: DX_F32 / DX_BF16 / DX_I64.
+ *   - DEAD ROWS (ABI v11).  Rows of an utterance at or past length + conv halo (`skip_lengths[b] + 2`, or the length of a
+ *     masked output) never reach a valid output.  Producers write them as zeros only below
+ *         dx_fill_end(len, N) = min(N, roundup(len + 4, 256) + 1)
+ *     -- as far as a consumer's last tile (<= 256 rows + 1 halo row, starting below length + 2) can reach; rows at or past
+ *     that index are never read by any entry point and are left UNWRITTEN (up to v10 they were written as zeros).  Callers
+ *     that inspect whole (B, N, C) intermediate tensors must not look past it.  User-visible outputs -- the transposed
+ *     (B, C, N) form of dx_conv1d (the mel), dx_linear_small_*, dx_gu_upsample_fwd -- keep their full zero padding.
+ *     A hard sequence end n_max[b] < N (an utterance that belongs to a shorter-padded micro-batch of a grouped step) is
+ *     expressed with the same arguments: skip_lengths[b] = min(length, n_max - 2), mask_lengths[b] = n_max.
  */
 #ifndef DAFT_EXPRT_HIP_H
 #define DAFT_EXPRT_HIP_H
@@ -24,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DX_ABI_VERSION 10
+#define DX_ABI_VERSION 11
 
 enum { DX_F32 = 0, DX_BF16 = 1, DX_I64 = 2 };
 enum { DX_OK = 0, DX_ERR_ARG = -1, DX_ERR_SHAPE = -2, DX_ERR_DTYPE = -3, DX_ERR_LAUNCH = -4, DX_ERR_UNSUPPORTED = -5 };
@@ -70,7 +79,7 @@ int dx_step_scalars_set(DxStepScalars* dev, uint64_t seed_salt, float lr, float 
  *            (masked_fill of model.py:259,262,569,707)
  *   skip_lengths NULL, or int64 (B): padding early-out -- 128-row tiles that start at n0 >= skip_lengths[b] + 2 are
  *            written as zeros without touching the MFMA pipe (rows past length + conv halo never reach a valid
- *            output)
+ *            output) -- and not written at all from dx_fill_end on (DEAD ROWS above)
  * Positions outside [0, N) are zero padding (N = the batch's max length).  Cin % 8 == 0.
  */
 int dx_conv1d(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const float* bias,
@@ -212,7 +221,7 @@ int dx_conv1d_wgrad_multi(const DxWgradDesc* descs, int n, int compute_dtype, co
  * residual / film / lengths / s_out / mean+rstd may be NULL (feature off).  s_out, mean, rstd (fp32) are what
  * dx_layernorm_bwd needs.  Dropout masks are a counter-based hash of (seed, element index), regenerated
  * identically by the backward kernel; p = 0 disables.  skip_lengths (NULL = off): rows n >= skip_lengths[b] + 2 are
- * written as zeros without being read (padding early-out, same rule as dx_conv1d). */
+ * written as zeros without being read (padding early-out, same rule as dx_conv1d: unwritten from dx_fill_end on).  C in {128, 256, 512, 1024}. */
 int dx_layernorm_fwd(const void* x, int x_dtype, const float* residual, const float* gamma, const float* beta,
                      const float* film, long ldf, const int64_t* lengths, const int64_t* skip_lengths, void* y,
                      int y_dtype, void* y_lp /* optional bf16 copy of y */, float* s_out, float* mean, float* rstd, int B, int N, int C, float p_pre,
@@ -233,7 +242,8 @@ int dx_layernorm_bwd(const void* dy, int dy_dtype, const void* s_in, int s_dtype
                      const DxStepScalars* step, void* stream);
 long dx_layernorm_bwd_ws_floats(int B, int N, int C);
 
-/* ---- K4: multi-head self-attention with key-padding mask, flash-style on MFMA (d_head in {16, 64}).
+/* ---- K4: multi-head self-attention with key-padding mask, flash-style on MFMA (d_head 16 and 64: the tuned kernels of the
+ * published 8- / 2-head configurations; 32 and 128 -- 4 heads / 1 head of a 128-wide model -- run the same templates untuned).
  * Replaces nn.MultiheadAttention's core (model.py:182-186): S = (q/sqrt(d)) k^T, pad keys -> -inf, softmax,
  * dropout on the probabilities, P v -- without materialising (B, H, N, N).
  *   qkv (B, N, 3E) = in-projection output [q | k | v], dtype = MFMA operand type (DX_BF16 or DX_F32)
