@@ -260,7 +260,12 @@ class CapturedStep(object):
     @staticmethod
     def key(micro_batches):
         # (targets too: the loss reads them in place -- normally views of the inputs, but nothing forces a caller to pass those)
-        return tuple((t.data_ptr(), tuple(t.shape)) for mb in micro_batches for t in tuple(mb[0]) + tuple(mb[1]))
+        return tuple((t.data_ptr(), tuple(t.shape)) for mb in micro_batches for t in CapturedStep._tensors(mb))
+
+    @staticmethod
+    def _tensors(mb):
+        ''' every tensor a captured step reads in place: inputs, targets and -- grouped micro-batches -- the per-utterance bounds '''
+        return tuple(mb[0]) + tuple(mb[1]) + (tuple(mb.bounds) if isinstance(mb, GroupedBatch) else ())
 
     def step(self, micro_batches, iteration):
         tr = self.tr
@@ -362,7 +367,7 @@ class CapturedStep(object):
             model.mark_updated()
         self.captures += 1
         ent = self.cache[key] = {'graph': graph, 'terms': terms, 'gnorm_sq': gnorm_sq, 'tick': self.ticks, 'outputs': model.last_outputs,
-                                 'keep': (own_ws, graph_ws, [t for mb in micro_batches for t in tuple(mb[0]) + tuple(mb[1])])}
+                                 'keep': (own_ws, graph_ws, [t for mb in micro_batches for t in self._tensors(mb)])}
         return ent
 
 
