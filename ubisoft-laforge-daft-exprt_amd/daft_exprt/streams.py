@@ -66,6 +66,9 @@ def collective_runs_beside(busy, group=None, probe_us=PROBE_US):
     helper = pick([busy], what='probe stream')
     with torch.cuda.stream(helper):
         dist.all_reduce(x, group=group)            # communicator set-up and first launch outside the measurement
+        if dist.get_world_size(group) > 1:
+            dist.all_reduce(x, group=group)        # a second one brings the ranks within microseconds of each other: a rank that enters the
+                                                   # timed collective late would make every other rank's probe look queued behind the spin
     torch.cuda.synchronize(dev)
     t0, t_busy, t_coll = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     t0.record(busy)
