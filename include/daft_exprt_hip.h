@@ -391,12 +391,16 @@ int dx_gu_upsample_bwd(const float* g, const float* xp, const float* weights, co
 /* ---- K13: the 7-term training loss and its gradients in one pass (DaftExprtLoss.forward, loss.py:54-99).
  * terms (8 floats, device): speaker, post_mult, duration, energy, pitch, mel_l1, mel_l2 (weighted), total.
  * mel / mel_t are (B, n_mel, T).  Gradient outputs (NULL to skip) are d(total * grad_scale)/d(pred);
- * d_post_mult is ACCUMULATED.  w_spk is the ramped adversarial weight (loss.py:22-28). */
+ * d_post_mult is ACCUMULATED.  w_spk is the ramped adversarial weight (loss.py:22-28).
+ * ws: NULL, or dx_loss_ws_floats(B, T) floats of scratch (no initialisation): with it (and the transposed mel gradient) the
+ * per-workgroup terms are added in a fixed order by the last of THREE launches -- run-to-run identical loss terms, no same-address
+ * atomics; without it four launches and fp32 atomics on terms[2..6]. */
+long dx_loss_ws_floats(int B, int T);
 int dx_loss_fwd_bwd(const float* dur, const float* energy, const float* pitch, const float* dur_t,
                     const float* energy_t, const float* pitch_t, const int64_t* in_lengths, const float* mel,
                     const float* mel_t, const int64_t* out_lengths, const float* spk_logits,
                     const int64_t* spk_ids, const float* post_mult, float* d_dur, float* d_energy,
-                    float* d_pitch, float* d_mel, float* d_spk_logits, float* d_post_mult, float* terms,
+                    float* d_pitch, float* d_mel, float* d_spk_logits, float* d_post_mult, float* terms, float* ws,
                     int B, int L, int T, int n_mel, int n_spk_classes, int n_post, float w_spk, float w_post,
                     float w_dur, float w_energy, float w_pitch, float w_mel, float grad_scale,
                     int d_mel_transposed /* write d_mel as (B, T, n_mel) */,

@@ -547,3 +547,38 @@ def test_wgrad_multi_equals_separate_calls():
     for (_, _, dw, db), (rw, rb), sh in zip(items, ref, shapes):
         assert torch.equal(dw, rw), sh
         assert float((db - rb).abs().max()) <= 1e-4 * float(rb.abs().max()), sh       # bias sums: fp32 atomics
+
+
+def test_loss_partials_form_matches_atomics_form_and_is_reproducible():
+    ''' dx_loss_fwd_bwd with a workspace (the training step's form: per-workgroup terms added in a fixed order by the last of three
+        launches) == the atomics form (four launches) to fp32 summation order; the workspace form is bit-reproducible; gradients
+        identical (the transposed mel gradient is the plain one transposed) '''
+    from daft_exprt import ops
+    g = torch.Generator().manual_seed(3)
+    B, L, T, C, S = 7, 33, 301, 80, 10
+    in_len = torch.tensor([33, 20, 1, 33, 7, 15, 30]).to(DEV)
+    out_len = torch.tensor([301, 150, 3, 64, 65, 200, 300]).to(DEV)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    dur, en, pi, dur_t, en_t, pi_t = (r(B, L) for _ in range(6))
+    mel, mel_t = r(B, C, T), r(B, C, T)
+    logits, ids, post = r(B, S), torch.randint(0, S, (B,), generator=g).to(DEV), r(2, 9)
+    w = (1e-2, 1e-3, 1., 1., 1., 1.)
+
+    def run(transposed):
+        gr = {'d_dur': torch.empty_like(dur), 'd_energy': torch.empty_like(en), 'd_pitch': torch.empty_like(pi),
+              'd_mel': torch.empty((B, T, C) if transposed else (B, C, T), device=DEV), 'd_spk': torch.empty_like(logits)}
+        dpost = torch.zeros_like(post)
+        t = ops.loss_fwd_bwd(dur, en, pi, dur_t, en_t, pi_t, in_len, mel, mel_t, out_len, logits, ids, post, w, grads=gr, d_post_mult=dpost,
+                             grad_scale=0.5, d_mel_transposed=transposed)
+        torch.cuda.synchronize()
+        return t.clone(), gr, dpost
+    t_ws, g_ws, p_ws = run(True)
+    t_ws2, _, _ = run(True)
+    t_at, g_at, p_at = run(False)
+    assert torch.equal(t_ws, t_ws2)
+    assert torch.allclose(t_ws, t_at, rtol=2e-6, atol=1e-7), (t_ws.tolist(), t_at.tolist())
+    assert abs(float(t_ws[7]) - float(t_ws[:7].sum())) <= 1e-5 * abs(float(t_ws[7]))
+    assert torch.equal(g_ws['d_mel'].transpose(1, 2), g_at['d_mel'])
+    for k in ('d_dur', 'd_energy', 'd_pitch', 'd_spk'):
+        assert torch.equal(g_ws[k], g_at[k]), k
+    assert torch.equal(p_ws, p_at)

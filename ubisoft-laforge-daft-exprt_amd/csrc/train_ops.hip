@@ -17,6 +17,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 struct SeqLossArgs {
   const float* pred[3]; const float* tgt[3]; float* dpred[3]; float w[3];
   const int64_t* lengths; float* terms; int B, L; float gscale;
+  float* part;     // NULL: atomics on terms[2 + f]; else part[f * B + b] = this block's term (summed in a fixed order by the last launch)
 };
 // grid (B, 3)
 __global__ __launch_bounds__(256) void seq_loss_kernel(SeqLossArgs a) {
@@ -32,7 +33,10 @@ __global__ __launch_bounds__(256) void seq_loss_kernel(SeqLossArgs a) {
     if (dp) dp[l] = a.gscale * a.w[f] * 2.f * d * inv;
   }
   acc = block_sum_256(acc, red);
-  if (threadIdx.x == 0) atomicAdd(a.terms + 2 + f, a.w[f] * acc * inv);
+  if (threadIdx.x == 0) {
+    if (a.part) a.part[f * a.B + b] = a.w[f] * acc * inv;
+    else atomicAdd(a.terms + 2 + f, a.w[f] * acc * inv);
+  }
 }
 
 // mel: pred/target (B, C, T); grid (chunks, B)
@@ -61,7 +65,10 @@ __global__ __launch_bounds__(256) void mel_loss_kernel(const float* __restrict__
 constexpr int MT_T = 64, MT_CMAX = 128, MT_TPW = 4;
 __global__ __launch_bounds__(256) void mel_loss_t_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
                                                          float* __restrict__ dpred, const int64_t* __restrict__ out_len,
-                                                         float* terms, int B, int C, int T, float w, float gscale) {
+                                                         float* terms, int B, int C, int T, float w, float gscale, float* part, int tpw) {
+  // part == NULL: `tpw` tiles per workgroup, two atomics on terms[5], terms[6] at the end (same-address atomics serialise at ~50 ns:
+  // few, fat workgroups); part != NULL: one tile per workgroup (4x the workgroups for the 46 MB it streams), its two sums go to
+  // part[2 * (b * gridDim.x + blockIdx.x)] and the last launch of dx_loss_fwd_bwd adds them in a fixed order
   __shared__ float tile[MT_CMAX][MT_T + 1];
   __shared__ float red[4];
   const int b = blockIdx.y;
@@ -71,8 +78,8 @@ __global__ __launch_bounds__(256) void mel_loss_t_kernel(const float* __restrict
   constexpr int U = 10;                                 // loads in flight per thread and operand (80 bins: two rounds)
   // MT_TPW tiles of 64 frames per workgroup: every workgroup ends with two atomics on the SAME two addresses, and same-address atomics
   // serialise at ~50 ns each -- 768 one-tile workgroups spent more time queueing there (~30 us) than reading their 46 MB
-  for (int tile_i = 0; tile_i < MT_TPW; ++tile_i) {
-    const int t0 = (blockIdx.x * MT_TPW + tile_i) * MT_T;
+  for (int tile_i = 0; tile_i < tpw; ++tile_i) {
+    const int t0 = (blockIdx.x * tpw + tile_i) * MT_T;
     if (t0 >= T) break;
     for (int i0 = threadIdx.x; i0 < C * MT_T; i0 += 256 * U) {
       float pv[U], tv[U];
@@ -102,16 +109,22 @@ __global__ __launch_bounds__(256) void mel_loss_t_kernel(const float* __restrict
   }
   a1 = block_sum_256(a1, red);
   a2 = block_sum_256(a2, red);
-  if (threadIdx.x == 0) { atomicAdd(terms + 5, w * a1 * inv); atomicAdd(terms + 6, w * a2 * inv); }
+  if (threadIdx.x == 0) {
+    if (part) { part[2 * (b * gridDim.x + blockIdx.x)] = w * a1 * inv; part[2 * (b * gridDim.x + blockIdx.x) + 1] = w * a2 * inv; }
+    else { atomicAdd(terms + 5, w * a1 * inv); atomicAdd(terms + 6, w * a2 * inv); }
+  }
 }
 
 // speaker cross-entropy (mean over the batch) and post-multiplier L2 norm; one block
 __global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ ids,
                                                         float* __restrict__ dlogits, int B, int S, float w_spk,
                                                         const float* __restrict__ post, float* __restrict__ dpost, int npost,
-                                                        float w_post, float* terms, float gscale, const DxStepScalars* step) {
-  // FIRST launch of dx_loss_fwd_bwd: writes terms[0..1] and zeroes the accumulators terms[2..7] of the kernels behind it (this
-  // replaces a hipMemsetAsync = one more dispatch per step)
+                                                        float w_post, float* terms, float gscale, const DxStepScalars* step,
+                                                        const float* seq_part, const float* mel_part, int n_mel_part) {
+  // seq_part == NULL: FIRST launch of dx_loss_fwd_bwd: writes terms[0..1] and zeroes the accumulators terms[2..7] of the kernels behind
+  // it (this replaces a hipMemsetAsync = one more dispatch per step).  seq_part != NULL: LAST launch: the other kernels left their
+  // per-workgroup terms in seq_part [3][B] / mel_part [n_mel_part][2]; they are added here in a fixed order (run-to-run identical loss
+  // terms, no same-address atomics) and the total is written: one launch less than the atomics form
   __shared__ float red[4];
   if (step) w_spk = step->w_speaker;   // captured steps: the adversarial weight of this iteration lives in device memory
   float ce = 0.f;
@@ -133,11 +146,30 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict_
   sq = block_sum_256(sq, red);
   const float nrm = sqrtf(sq);
   if (post && dpost) for (int i = threadIdx.x; i < npost; i += 256) dpost[i] += nrm > 0.f ? gscale * w_post * post[i] / nrm : 0.f;
+  float t5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (seq_part) {
+    for (int f = 0; f < 3; ++f) {
+      float v = 0.f;
+      for (int b = threadIdx.x; b < B; b += 256) v += seq_part[f * B + b];
+      t5[f] = block_sum_256(v, red);
+    }
+    float v1 = 0.f, v2 = 0.f;
+    for (int i = threadIdx.x; i < n_mel_part; i += 256) { v1 += mel_part[2 * i]; v2 += mel_part[2 * i + 1]; }
+    t5[3] = block_sum_256(v1, red);
+    t5[4] = block_sum_256(v2, red);
+  }
   if (threadIdx.x == 0) {
     terms[0] = w_spk * ce / (float)B;
     terms[1] = post ? w_post * nrm : 0.f;
+    if (seq_part) {
+      float tot = terms[0] + terms[1];
 #pragma unroll
-    for (int i = 2; i < 8; ++i) terms[i] = 0.f;
+      for (int i = 0; i < 5; ++i) { terms[2 + i] = t5[i]; tot += t5[i]; }
+      terms[7] = tot;
+    } else {
+#pragma unroll
+      for (int i = 2; i < 8; ++i) terms[i] = 0.f;
+    }
   }
 }
 __global__ void loss_total_kernel(float* terms) {
@@ -307,11 +339,13 @@ inline int grid_for(long total, int cap = 2048) {
 
 }  // namespace
 
+extern "C" long dx_loss_ws_floats(int B, int T) { return (B <= 0 || T <= 0) ? 0 : 3L * B + 2L * B * dx_cdiv(T, MT_T); }
+
 extern "C" int dx_loss_fwd_bwd(const float* dur, const float* energy, const float* pitch, const float* dur_t,
                                const float* energy_t, const float* pitch_t, const int64_t* in_lengths, const float* mel,
                                const float* mel_t, const int64_t* out_lengths, const float* spk_logits,
                                const int64_t* spk_ids, const float* post_mult, float* d_dur, float* d_energy,
-                               float* d_pitch, float* d_mel, float* d_spk_logits, float* d_post_mult, float* terms,
+                               float* d_pitch, float* d_mel, float* d_spk_logits, float* d_post_mult, float* terms, float* ws,
                                int B, int L, int T, int n_mel, int n_spk_classes, int n_post, float w_spk, float w_post,
                                float w_dur, float w_energy, float w_pitch, float w_mel, float grad_scale,
                                int d_mel_transposed, const DxStepScalars* step, void* stream) {
@@ -319,18 +353,31 @@ extern "C" int dx_loss_fwd_bwd(const float* dur, const float* energy, const floa
              spk_ids && terms, DX_ERR_ARG, "dx_loss_fwd_bwd: null pointer");
   DX_REQUIRE(B > 0 && L > 0 && T > 0, DX_ERR_SHAPE, "dx_loss_fwd_bwd: empty shape");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(256), 0, s, spk_logits, spk_ids, d_spk_logits, B, n_spk_classes, w_spk,
-                     post_mult, d_post_mult, n_post, w_post, terms, grad_scale, step);
+  // ws (dx_loss_ws_floats(B, T) floats, no initialisation): per-workgroup terms added in a fixed order by the last launch (3 launches, no
+  // atomics, 4x the workgroups on the mel term); only with the transposed mel gradient (the training step's form).  NULL: atomics, 4 launches.
+  const bool part = ws && d_mel && d_mel_transposed && n_mel <= MT_CMAX;
+  float* seq_part = part ? ws : nullptr;
+  float* mel_part = part ? ws + 3L * B : nullptr;
+  if (!part)
+    hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(256), 0, s, spk_logits, spk_ids, d_spk_logits, B, n_spk_classes, w_spk,
+                       post_mult, d_post_mult, n_post, w_post, terms, grad_scale, step, nullptr, nullptr, 0);
   SeqLossArgs a{{dur, energy, pitch}, {dur_t, energy_t, pitch_t}, {d_dur, d_energy, d_pitch}, {w_dur, w_energy, w_pitch},
-                in_lengths, terms, B, L, grad_scale};
+                in_lengths, terms, B, L, grad_scale, seq_part};
   hipLaunchKernelGGL(seq_loss_kernel, dim3(B, 3), dim3(256), 0, s, a);
   int chunks = dx_cdiv(n_mel * T, 256 * 8);
   if (chunks > 64) chunks = 64;
-  if (d_mel && d_mel_transposed && n_mel <= MT_CMAX)
-    hipLaunchKernelGGL(mel_loss_t_kernel, dim3(dx_cdiv(T, MT_T * MT_TPW), B), dim3(256), 0, s, mel, mel_t, d_mel, out_lengths, terms, B, n_mel, T, w_mel, grad_scale);
-  else
+  if (d_mel && d_mel_transposed && n_mel <= MT_CMAX) {
+    const int tpw = part ? 1 : MT_TPW;
+    hipLaunchKernelGGL(mel_loss_t_kernel, dim3(dx_cdiv(T, MT_T * tpw), B), dim3(256), 0, s, mel, mel_t, d_mel, out_lengths, terms, B, n_mel, T, w_mel,
+                       grad_scale, mel_part, tpw);
+  } else {
     hipLaunchKernelGGL(mel_loss_kernel, dim3(chunks, B), dim3(256), 0, s, mel, mel_t, d_mel, out_lengths, terms, B, n_mel, T, w_mel, grad_scale, d_mel_transposed);
-  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, s, terms);
+  }
+  if (part)
+    hipLaunchKernelGGL(head_loss_kernel, dim3(1), dim3(256), 0, s, spk_logits, spk_ids, d_spk_logits, B, n_spk_classes, w_spk,
+                       post_mult, d_post_mult, n_post, w_post, terms, grad_scale, step, seq_part, mel_part, B * dx_cdiv(T, MT_T));
+  else
+    hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, s, terms);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }

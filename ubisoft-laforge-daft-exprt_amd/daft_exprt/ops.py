@@ -707,11 +707,13 @@ def loss_fwd_bwd(dur, energy, pitch, dur_t, energy_t, pitch_t, in_lengths, mel, 
     terms = _empty(8, dtype=torch.float32, device=dur.device)
     g = grads or {}
     assert mel.is_contiguous() and mel_t.is_contiguous()
+    # per-workgroup terms + a fixed-order sum in the last launch (3 launches, no atomics) when the mel gradient is written transposed
+    ws = _empty(H.lib().dx_loss_ws_floats(B, T), dtype=torch.float32, device=dur.device) if (d_mel_transposed and g.get('d_mel') is not None) else None
     H.check(H.lib().dx_loss_fwd_bwd(H.ptr(dur), H.ptr(energy), H.ptr(pitch), H.ptr(dur_t), H.ptr(energy_t), H.ptr(pitch_t),
                                     H.ptr(in_lengths), H.ptr(mel), H.ptr(mel_t), H.ptr(out_lengths), H.ptr(spk_logits),
                                     H.ptr(spk_ids), H.ptr(post_mult), H.ptr(g.get('d_dur')), H.ptr(g.get('d_energy')),
                                     H.ptr(g.get('d_pitch')), H.ptr(g.get('d_mel')), H.ptr(g.get('d_spk')), H.ptr(d_post_mult),
-                                    H.ptr(terms), B, L, T, n_mel, spk_logits.shape[1],
+                                    H.ptr(terms), H.ptr(ws), B, L, T, n_mel, spk_logits.shape[1],
                                     post_mult.numel() if post_mult is not None else 0, *[float(w) for w in weights],
                                     float(grad_scale), int(d_mel_transposed), STEP_PTR, H.stream()))
     return terms
