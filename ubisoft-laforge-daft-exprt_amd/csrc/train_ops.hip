@@ -235,19 +235,16 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long 
 // ------------------------------------------------------------------ integer durations (model.py:789-812 + extract_features.py:69-111)
 __device__ __forceinline__ long floordiv(long a, long b) { long q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
 
-// one thread per utterance; fp64 + integer arithmetic in the reference's order of operations
-__global__ void int_durations_kernel(float* __restrict__ dur, const float* __restrict__ dur_factors, int64_t* __restrict__ out, int64_t* __restrict__ totals,
-                                     int* __restrict__ status, int B, int L, double sr, int fl, int hop, int centered) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  float* d = dur + (long)b * L;
-  int64_t* o = out + (long)b * L;
-  const float dmin = (float)((double)fl / sr / 2.0);   // compared in fp32, like `tensor < python_float`
+// fp64 + integer arithmetic in the reference's order of operations: the walk over the symbols is SERIAL by definition (a running fp64
+// sum whose rounding the integer frame counts depend on), so one lane per utterance does it -- but on a copy of the row in LDS: the
+// first version walked global memory, one dependent ~1 us round trip per symbol and loop (207 us for B = 256, L = 160: 2 % of a
+// synthesis call).  One wave per utterance: coalesced load (+ duration factors + threshold), lane 0 walks LDS, coalesced write-back.
+constexpr int ID_LMAX = 2048;     // symbols per utterance held in LDS (24 KB); longer rows walk global memory as before
+template <typename DP, typename OP>
+__device__ __forceinline__ void int_durations_walk(DP d, OP o, int L, double sr, int fl, int hop, int centered, int64_t* total_out, int* status_out) {
   double end_prev = 0.0, total = 0.0;
   int nspans = 0;
   for (int l = 0; l < L; ++l) {
-    if (dur_factors) d[l] *= dur_factors[(long)b * L + l];   // model.py:891
-    if (d[l] < dmin) d[l] = 0.f;
     o[l] = 0;
     if (d[l] != 0.f) {
       const double e = end_prev + (double)d[l];
@@ -291,8 +288,35 @@ __global__ void int_durations_kernel(float* __restrict__ dur, const float* __res
   if (!st && consumed != nspans) st = 2;                 // shape mismatch in the reference's index_put
   int64_t tot = 0;
   for (int i = 0; i < L; ++i) tot += o[i];
-  totals[b] = tot;
-  status[b] = st;
+  *total_out = tot;
+  *status_out = st;
+}
+
+__global__ __launch_bounds__(64) void int_durations_kernel(float* __restrict__ dur, const float* __restrict__ dur_factors, int64_t* __restrict__ out,
+                                                           int64_t* __restrict__ totals, int* __restrict__ status, int B, int L, double sr, int fl,
+                                                           int hop, int centered) {
+  __shared__ float ds[ID_LMAX];
+  __shared__ int64_t os[ID_LMAX];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float* d = dur + (long)b * L;
+  int64_t* o = out + (long)b * L;
+  const float dmin = (float)((double)fl / sr / 2.0);   // compared in fp32, like `tensor < python_float`
+  const bool in_lds = L <= ID_LMAX;
+  for (int l = lane; l < L; l += 64) {                   // model.py:891 (duration factors) and the threshold of extract_features.py:69-111
+    float v = d[l];
+    if (dur_factors) v *= dur_factors[(long)b * L + l];
+    if (v < dmin) v = 0.f;
+    d[l] = v;
+    if (in_lds) ds[l] = v;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    if (in_lds) int_durations_walk(ds, os, L, sr, fl, hop, centered, totals + b, status + b);
+    else int_durations_walk(d, o, L, sr, fl, hop, centered, totals + b, status + b);
+  }
+  __syncthreads();
+  if (in_lds)
+    for (int l = lane; l < L; l += 64) o[l] = os[l];
 }
 
 
@@ -428,7 +452,7 @@ extern "C" int dx_int_durations(float* duration_preds, const float* dur_factors,
                                 double sampling_rate, int filter_length, int hop_length, int centered, void* stream) {
   DX_REQUIRE(duration_preds && durations_int && totals && status, DX_ERR_ARG, "dx_int_durations: null pointer");
   DX_REQUIRE(B > 0 && L > 0 && hop_length > 0 && filter_length > 0, DX_ERR_SHAPE, "dx_int_durations: bad shape");
-  hipLaunchKernelGGL(int_durations_kernel, dim3(dx_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, duration_preds, dur_factors,
+  hipLaunchKernelGGL(int_durations_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, duration_preds, dur_factors,
                      durations_int, totals, status, B, L, sampling_rate, filter_length, hop_length, centered);
   DX_LAUNCH_CHECK();
   return DX_OK;
