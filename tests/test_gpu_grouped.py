@@ -142,3 +142,32 @@ def test_trainer_step_grouped_equals_three_passes():
     share = float((d > 0.02 * lr).float().mean())
     assert float(d.max()) <= 2 * 2 * lr * 1.05, float(d.max())
     assert share < 2e-3, share
+
+
+def test_grouped_pass_at_the_reference_schedule_size_fp32():
+    ''' the reference's own schedule at full size -- 16 utterances x 3 micro-batches, T <= 1000 -- with micro-batch paddings that sit ON
+        the kernels' tile boundaries (768 = 3 x 256 = 6 x 128 frames: the hard sequence end of the utterance that fills its micro-batch
+        coincides with the start of a dead tile) and off them (1000, 901): predictions bit-equal to the three passes, loss and gradients
+        to summation order '''
+    from daft_exprt.data_loader import group_micro_batches, synthetic_batch
+    from daft_exprt.loss import DaftExprtLoss
+    from daft_exprt.model import DaftExprt
+    from tests.util import make_hparams, no_dropout
+    hp = no_dropout(make_hparams(batch_size=16, accumulation_steps=3, compute_dtype='fp32'))
+    dev = torch.device('cuda:0')
+    torch.manual_seed(hp.seed)
+    model = DaftExprt(hp).to(dev).train()
+    weights = DaftExprtLoss(dev, hp).weights(20000)
+    mbs = []
+    for k, t_max in enumerate((768, 1000, 901)):
+        cb = synthetic_batch(hp, 16, seed=900 + k, t_min=1, t_max=t_max, force_first_full=True)
+        inputs, targets, _ = model.parse_batch(dev, cb)
+        assert inputs[8].shape[2] == t_max
+        mbs.append((inputs, targets))
+    p_seq, t_seq, g_seq = _sequential(model, mbs, weights)
+    p_grp, t_grp, g_grp = _grouped(model, mbs, weights)
+    for k, (a, b) in enumerate(zip(p_seq, p_grp)):
+        for nm, x, y in zip(('mel', 'dur', 'energy', 'pitch', 'speaker logits'), a, b):
+            assert torch.equal(x, y), (k, nm, float((x - y).abs().max()))
+    assert torch.allclose(t_seq, t_grp, rtol=2e-5, atol=1e-7)
+    assert float((g_seq - g_grp).norm()) <= 2e-4 * float(g_seq.norm()), float((g_seq - g_grp).norm()) / float(g_seq.norm())
