@@ -2669,7 +2669,8 @@ static int wgrad_nsplit(int B, int N, int Cin, int Cout, int taps) {
   // every split costs one more partial tile to write and re-read: keep >= ~8 items (64 positions each) per workgroup,
   // 16 for the linear layers (a third of the MFMA work per item)
   int ns = target / tiles;
-  const long by_work = (long)B * dx_cdiv(N, WG_P) / (taps == 1 ? 16 : 8);      // (B * N rows is an upper bound of the valid rows)
+  const long by_work = (long)B * dx_cdiv(N, WG_P) / 16;      // (B * N rows is an upper bound of the valid rows; round 5: 16 for k = 3 too -- the phoneme-level
+  // gradients had 18 splits of ~4 items each, i.e. 28 MB of partial tiles for 11 MB of operands: 9 splits, time-neutral, -0.2 GB per step)
   if (ns > by_work) ns = (int)by_work;
   return ns < 1 ? 1 : ns;
 }
