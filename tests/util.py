@@ -118,12 +118,14 @@ def install_unwritten_shim(monkeypatch):
         about padding rows -- exact zeros -- is the contract for the dead rows BELOW the fill end; what lies past it is dropped. '''
     from daft_exprt import ops
 
-    def clean(t, lengths):
+    def clean(t, lengths, N=None):
         if lengths is None or not torch.is_tensor(t):
             return t
         B = lengths.shape[0]
-        if t.dim() == 3 and t.shape[0] == B:
+        if t.dim() == 3 and t.shape[0] == B and (N is None or t.shape[1] == N):
             return t.copy_(drop_unwritten(t, lengths))
+        if t.dim() == 3:
+            return t                                # (e.g. the (B, H, N) log-sum-exp of the attention forward: not row-major over N)
         if t.dim() == 1 and t.numel() % B == 0 and t.numel() > B:     # mean / rstd: (B * N,)
             return t.copy_(drop_unwritten(t.view(B, -1), lengths).view(-1))
         return t
@@ -134,12 +136,15 @@ def install_unwritten_shim(monkeypatch):
             lengths = pick(a, kw)
             if kw.get('out') is not None or kw.get('transposed_out'):
                 return out
+            N = a[0].shape[1] if (a and torch.is_tensor(a[0]) and a[0].dim() == 3) else None
             if isinstance(out, tuple):
-                return tuple(clean(t, lengths) for t in out)
-            return clean(out, lengths)
+                return tuple(clean(t, lengths, N) for t in out)
+            return clean(out, lengths, N)
         return f
     monkeypatch.setattr(ops, 'conv1d', wrap(ops.conv1d, lambda a, kw: kw.get('skip_lengths')))
     monkeypatch.setattr(ops, 'conv1d_ln', wrap(ops.conv1d_ln, lambda a, kw: kw.get('lengths', a[6] if len(a) > 6 else None)))
     monkeypatch.setattr(ops, 'conv1d_lnbwd', wrap(ops.conv1d_lnbwd, lambda a, kw: kw.get('lengths', a[8] if len(a) > 8 else None)))
     monkeypatch.setattr(ops, 'layernorm_fwd', wrap(ops.layernorm_fwd, lambda a, kw: kw.get('skip_lengths')))
     monkeypatch.setattr(ops, 'layernorm_bwd', wrap(ops.layernorm_bwd, lambda a, kw: kw.get('skip_lengths')))
+    monkeypatch.setattr(ops, 'attention_fwd', wrap(ops.attention_fwd, lambda a, kw: kw.get('lengths', a[1] if len(a) > 1 else None)))
+    monkeypatch.setattr(ops, 'attention_bwd', wrap(ops.attention_bwd, lambda a, kw: kw.get('lengths', a[4] if len(a) > 4 else None)))

@@ -163,8 +163,9 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
   TC* O = reinterpret_cast<TC*>(a.o) + (long)b * N * E + h * DH;
   float* lse = a.lse ? a.lse + ((long)b * a.H + h) * N : nullptr;
 
+  const int fend = dx_fill_end(len, N);   // dead rows are written (as zeros) only below it: nobody reads past it (dx_common.h)
   if (bx * QB >= len) {  // whole tile of pad queries: their rows are zeroed after the LayerNorm anyway
-    if (q < N && kh == 0) {
+    if (q < fend && kh == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int d = dx_acc_row(r, g);
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? DX_ATTN_OCC16 : 
     }
     if (kh) return;
   }
-  if (q < N) {
+  if (q < fend) {
     const float inv_l = wave_live ? inv_keep / l : 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(256, sizeof(TC) == 2 ? (DH <= 16 ? 4 : DX_ATTN_OCC6
       }
     }
   }
-  if (q < N && kh == 0) {
+  if (q < dx_fill_end(len, N) && kh == 0) {   // (dead rows past the fill end stay unwritten, dx_common.h)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : (sizeof(TC) == 4 ? 1 : 2)) void
       }
     }
   }
-  if (key < N && kh == 0) {
+  if (key < dx_fill_end(len, N) && kh == 0) {   // (dead rows past the fill end stay unwritten, dx_common.h)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -810,7 +811,7 @@ __global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, f
   int* counter = a.counters + (b * H + h);
   if (!half) {   // rows past the last live block: dQ | dK | dV are zero (this head's 16 columns of each)
     const frag_t z = zero8<TC>();
-    const int nz = (N - rows_live) * 6;
+    const int nz = (max(dx_fill_end(len, N), rows_live) - rows_live) * 6;   // (only below the fill end: nobody reads past it, dx_common.h)
     for (int c = tid; c < nz; c += FB_T) {
       const int row = rows_live + c / 6, pt = c % 6;
       *reinterpret_cast<frag_t*>(dQ + (long)row * ld_g + (pt >> 1) * E + (pt & 1) * 8) = z;
