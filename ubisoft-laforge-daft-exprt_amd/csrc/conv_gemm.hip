@@ -2136,8 +2136,13 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, const int bi
   __shared__ __attribute__((aligned(16))) bf16_t ring[WGR_RING * ITEM_EL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
   const int ntiles = dx_cdiv(p.Cout, WG_CO) * p.tiles_ci;
-  const int split = bid / ntiles;
-  int tile = bid % ntiles;
+  // Workgroup L runs on XCD L % 8, and every XCD has its own L2.  The 8 tiles of one split of a 128 <-> 1024 gradient walk the SAME rows of
+  // the narrow operand (dz / a: 128 channels): in (split, tile) index order they sat on 8 different XCDs and the narrow operand was fetched
+  // 8 times (~54 MB per frame-level launch, 0.9 GB per step of FETCH_SIZE).  With the split index fastest (nsplit % 8 == 0) all tiles of a
+  // split share an XCD.  Only the assignment of (split, tile) to workgroups changes: same partial tiles, same sums.
+  const bool by_split = ntiles == 8 && (p.nsplit & 7) == 0;
+  const int split = by_split ? bid % p.nsplit : bid / ntiles;
+  int tile = by_split ? bid / p.nsplit : bid % ntiles;
   // XCD-aware tile order for the 8 x 8 tile grid of a 1024 x 1024 weight (workgroup L runs on XCD L % 8, ntiles % 8 == 0): in index
   // order an XCD owns one ci column of tiles and reads ALL of dY (8 x 61 MB per launch over the chip); dealt as 4 (co) x 2 (ci)
   // blocks it reads half of dY and a quarter of X.  Only the assignment of tile ids to workgroups changes.
