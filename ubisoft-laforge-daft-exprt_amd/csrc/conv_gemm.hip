@@ -1934,7 +1934,8 @@ __global__ __launch_bounds__(WG_THREADS, DX_WGRAD_WPS) void conv_wgrad_kernel(Wg
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
   const int wm = wave >> 2, wn = wave & 3;
   const int ntiles = dx_cdiv(p.Cout, WG_CO) * p.tiles_ci;
-  const int split = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+  const bool by_split = ntiles > 1 && (p.nsplit & 7) == 0;      // the tiles of a split on one XCD (see wgrad_ring_body)
+  const int split = by_split ? (int)blockIdx.x % p.nsplit : (int)blockIdx.x / ntiles, tile = by_split ? (int)blockIdx.x / p.nsplit : (int)blockIdx.x % ntiles;
   const int co0 = (tile / p.tiles_ci) * WG_CO, ci0 = (tile % p.tiles_ci) * WG_CI;
   const int N = p.N, Cin = p.Cin, Cout = p.Cout;
 
@@ -2138,9 +2139,11 @@ __device__ __forceinline__ void wgrad_ring_body(const WgradArgs& p, const int bi
   const int ntiles = dx_cdiv(p.Cout, WG_CO) * p.tiles_ci;
   // Workgroup L runs on XCD L % 8, and every XCD has its own L2.  The 8 tiles of one split of a 128 <-> 1024 gradient walk the SAME rows of
   // the narrow operand (dz / a: 128 channels): in (split, tile) index order they sat on 8 different XCDs and the narrow operand was fetched
-  // 8 times (~54 MB per frame-level launch, 0.9 GB per step of FETCH_SIZE).  With the split index fastest (nsplit % 8 == 0) all tiles of a
-  // split share an XCD.  Only the assignment of (split, tile) to workgroups changes: same partial tiles, same sums.
-  const bool by_split = ntiles == 8 && (p.nsplit & 7) == 0;
+  // 8 times (~54 MB per frame-level launch, 0.9 GB per step of FETCH_SIZE).  With the split index fastest (nsplit % 8 == 0, see
+  // wgrad_nsplit) all tiles of a split share an XCD -- also the 3 tiles of a QKV gradient's split (and, in the pair launch, whatever the
+  // first problem's workgroup count is: the offset moves all tiles of a split alike).  Only the assignment of (split, tile) to workgroups
+  // changes: same partial tiles, same sums.
+  const bool by_split = ntiles > 1 && ntiles != 64 && (p.nsplit & 7) == 0;
   const int split = by_split ? bid % p.nsplit : bid / ntiles;
   int tile = by_split ? bid / p.nsplit : bid % ntiles;
   // XCD-aware tile order for the 8 x 8 tile grid of a 1024 x 1024 weight (workgroup L runs on XCD L % 8, ntiles % 8 == 0): in index
@@ -2677,6 +2680,7 @@ static int wgrad_nsplit(int B, int N, int Cin, int Cout, int taps) {
   const long by_work = (long)B * dx_cdiv(N, WG_P) / 16;      // (B * N rows is an upper bound of the valid rows; round 5: 16 for k = 3 too -- the phoneme-level
   // gradients had 18 splits of ~4 items each, i.e. 28 MB of partial tiles for 11 MB of operands: 9 splits, time-neutral, -0.2 GB per step)
   if (ns > by_work) ns = (int)by_work;
+  if (ns >= 8) ns = (ns + 3) / 8 * 8;   // a multiple of 8: the tiles of a split then share an XCD (see wgrad_ring_body)
   return ns < 1 ? 1 : ns;
 }
 
