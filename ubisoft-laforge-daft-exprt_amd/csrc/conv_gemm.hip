@@ -634,10 +634,10 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
             for (int e = 0; e < 8; ++e) v[e] = rstd * (v[e] - s1 - xh[e] * s2);
             store8<float>(p.ln.y + offl, v);                      // ds, in place of the residual gradient
             if (p.ln.p_pre > 0.f) {
-              const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(dx_seed_eff(p.ln.seed_pre, p.ln.step), 0);
-              const float sc = 1.f / (1.f - p.ln.p_pre);
+              const uint32_t th = dx_drop_th8(p.ln.p_pre), key = dx_key32(dx_seed_eff(p.ln.seed_pre, p.ln.step), 0);
+              const float sc = dx_drop_inv_keep8(th);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = dx_keep(key, (uint32_t)rowg * BN + cl + e, th) ? v[e] * sc : 0.f;
+              for (int e = 0; e < 8; ++e) v[e] = dx_keep8(key, (uint32_t)rowg * BN + cl + e, th) ? v[e] * sc : 0.f;
             }
             store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + offl, v);
             continue;
@@ -645,10 +645,10 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
           if (LN == 1) {        // fused LayerNorm: 16 lanes hold one complete 128-channel row
             const size_t rowg = (size_t)b * N + n, offl = rowg * BN + cl;
             if (p.ln.p_pre > 0.f) {
-              const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(dx_seed_eff(p.ln.seed_pre, p.ln.step), 0);
-              const float sc = 1.f / (1.f - p.ln.p_pre);
+              const uint32_t th = dx_drop_th8(p.ln.p_pre), key = dx_key32(dx_seed_eff(p.ln.seed_pre, p.ln.step), 0);
+              const float sc = dx_drop_inv_keep8(th);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = dx_keep(key, (uint32_t)rowg * BN + cl + e, th) ? v[e] * sc : 0.f;
+              for (int e = 0; e < 8; ++e) v[e] = dx_keep8(key, (uint32_t)rowg * BN + cl + e, th) ? v[e] * sc : 0.f;
             }
             {
               const f32x8 r = pf_a[pass];
@@ -1395,19 +1395,19 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
             for (int e2 = 0; e2 < 8; ++e2) v[e2] = rstd * (v[e2] - s1 - xh[e2] * s2);
             store8<float>(p.ln.y + offl, v);                      // ds, in place of the residual gradient
             if (p.ln.p_pre > 0.f) {
-              const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(dx_seed_eff(p.ln.seed_pre, p.ln.step), 0);
-              const float sc = 1.f / (1.f - p.ln.p_pre);
+              const uint32_t th = dx_drop_th8(p.ln.p_pre), key = dx_key32(dx_seed_eff(p.ln.seed_pre, p.ln.step), 0);
+              const float sc = dx_drop_inv_keep8(th);
 #pragma unroll
-              for (int e2 = 0; e2 < 8; ++e2) v[e2] = dx_keep(key, (uint32_t)rowg * BN + cl + e2, th) ? v[e2] * sc : 0.f;
+              for (int e2 = 0; e2 < 8; ++e2) v[e2] = dx_keep8(key, (uint32_t)rowg * BN + cl + e2, th) ? v[e2] * sc : 0.f;
             }
             store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + offl, v);
             if (gemm2) store8<bf16_t>(a2 + sr * A2_LD + cl, v);
           } else {              // fused LayerNorm: 16 lanes hold one complete 128-channel row
             if (p.ln.p_pre > 0.f) {
-              const uint32_t th = (uint32_t)(p.ln.p_pre * 4294967296.0), key = dx_key32(dx_seed_eff(p.ln.seed_pre, p.ln.step), 0);
-              const float sc = 1.f / (1.f - p.ln.p_pre);
+              const uint32_t th = dx_drop_th8(p.ln.p_pre), key = dx_key32(dx_seed_eff(p.ln.seed_pre, p.ln.step), 0);
+              const float sc = dx_drop_inv_keep8(th);
 #pragma unroll
-              for (int e2 = 0; e2 < 8; ++e2) v[e2] = dx_keep(key, (uint32_t)rowg * BN + cl + e2, th) ? v[e2] * sc : 0.f;
+              for (int e2 = 0; e2 < 8; ++e2) v[e2] = dx_keep8(key, (uint32_t)rowg * BN + cl + e2, th) ? v[e2] * sc : 0.f;
             }
             {
               const f32x8 r = pf_a[pass];

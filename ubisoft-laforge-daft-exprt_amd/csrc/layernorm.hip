@@ -66,7 +66,8 @@ __device__ __forceinline__ void store_vec<bf16_t, 4>(bf16_t* p, const float* in)
   *reinterpret_cast<bf16x4*>(p) = v;
 }
 
-__device__ __forceinline__ uint32_t drop_thresh(float p) { return p <= 0.f ? 0u : (uint32_t)(p * 4294967296.0); }
+// Dropout in front of / behind a LayerNorm: dx_keep8 (dx_common.h) -- one hash per 4 consecutive channels.  One murmur hash per
+// element (3 quarter-rate 32-bit multiplies) was 40 % of ln_fwd<1024> and a fifth of its backward.
 
 template <typename TI, typename TO, int C>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
@@ -93,8 +94,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
     return;
   }
   float v[L::EPL];
-  const uint32_t th_pre = drop_thresh(a.p_pre);
-  const float sc_pre = a.p_pre > 0.f ? 1.f / (1.f - a.p_pre) : 1.f;
+  const uint32_t th_pre = dx_drop_th8(a.p_pre);
+  const float sc_pre = th_pre ? dx_drop_inv_keep8(th_pre) : 1.f;
 #pragma unroll
   for (int k = 0; k < L::NV; ++k) {
     const int c0 = L::col(lane, k);
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
     if (th_pre) {
 #pragma unroll
       for (int i = 0; i < L::V; ++i)
-        v[k * L::V + i] = dx_keep(key_pre, (uint32_t)row * C + c0 + i, th_pre) ? v[k * L::V + i] * sc_pre : 0.f;
+        v[k * L::V + i] = dx_keep8(key_pre, (uint32_t)row * C + c0 + i, th_pre) ? v[k * L::V + i] * sc_pre : 0.f;
     }
     if (a.res) {
       float r[L::V];
@@ -122,8 +123,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
   const float rstd = rsqrtf(dx_wave_sum(sq) * (1.f / C) + 1e-5f);
   if (a.mean && lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
   const bool pad = a.lengths && n >= (int)a.lengths[b];
-  const uint32_t th_post = drop_thresh(a.p_post);
-  const float sc_post = a.p_post > 0.f ? 1.f / (1.f - a.p_post) : 1.f;
+  const uint32_t th_post = dx_drop_th8(a.p_post);
+  const float sc_post = th_post ? dx_drop_inv_keep8(th_post) : 1.f;
   TO* y = reinterpret_cast<TO*>(a.y) + row * C;
 #pragma unroll
   for (int k = 0; k < L::NV; ++k) {
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
 #pragma unroll
     for (int i = 0; i < L::V; ++i) {
       float t = (v[k * L::V + i] - mean) * rstd * g[i] + bt[i];
-      if (th_post) t = dx_keep(key_post, (uint32_t)row * C + c0 + i, th_post) ? t * sc_post : 0.f;
+      if (th_post) t = dx_keep8(key_post, (uint32_t)row * C + c0 + i, th_post) ? t * sc_post : 0.f;
       o[i] = t;
     }
     if (a.film) {
@@ -198,10 +199,10 @@ __global__ __launch_bounds__(256, C >= 1024 ? (FILM ? 1 : ((sizeof(TI) == 4 || s
   const int n_begin = blockIdx.x * a.rows_per_block;
   const int n_end = min(a.N, n_begin + a.rows_per_block);
   const int len = a.lengths ? (int)a.lengths[b] : a.N;
-  const uint32_t th_pre = drop_thresh(a.p_pre), th_post = drop_thresh(a.p_post);
+  const uint32_t th_pre = dx_drop_th8(a.p_pre), th_post = dx_drop_th8(a.p_post);
   const uint32_t key_pre = dx_key32(dx_seed_eff(a.seed_pre, a.step), 0), key_post = dx_key32(dx_seed_eff(a.seed_post, a.step), 1);
-  const float sc_pre = a.p_pre > 0.f ? 1.f / (1.f - a.p_pre) : 1.f;
-  const float sc_post = a.p_post > 0.f ? 1.f / (1.f - a.p_post) : 1.f;
+  const float sc_pre = th_pre ? dx_drop_inv_keep8(th_pre) : 1.f;
+  const float sc_post = th_post ? dx_drop_inv_keep8(th_post) : 1.f;      // (quantised with the threshold: see dx_keep8)
   const int nskip = a.skip ? (int)a.skip[b] + 2 : a.N;
   const int nfill = a.skip ? dx_fill_end((int)a.skip[b], a.N) : a.N;
 
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256, C >= 1024 ? (FILM ? 1 : ((sizeof(TI) == 4 || s
         pos |= (xh[j] > 0.f ? 1u : 0u) << j;
         xh[j] = (xh[j] - mean) * rstd;
         float keep_post = 1.f;
-        if (th_post) keep_post = dx_keep(key_post, (uint32_t)row * C + c, th_post) ? sc_post : 0.f;
+        if (th_post) keep_post = dx_keep8(key_post, (uint32_t)row * C + c, th_post) ? sc_post : 0.f;
         if (FILM) {                                         // y = fg * (ln * keep) + fb
           const float ln = xh[j] * gmj + btj;               // LayerNorm output before dropout_post / FiLM
           acc_fg[FILM ? j : 0] += gy * ln * keep_post;
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256, C >= 1024 ? (FILM ? 1 : ((sizeof(TI) == 4 || s
         o[i] = rstd * (g[j] - m1 - xh[j] * m2);
         if (a.relu_input && !((pos >> j) & 1u)) o[i] = 0.f;
         o2[i] = o[i];
-        if (th_pre) o2[i] = dx_keep(key_pre, (uint32_t)row * C + c0 + i, th_pre) ? o[i] * sc_pre : 0.f;
+        if (th_pre) o2[i] = dx_keep8(key_pre, (uint32_t)row * C + c0 + i, th_pre) ? o[i] * sc_pre : 0.f;
       }
       store_vec<TD, L::V>(ds + c0, o);
       if (dxp) store_vec<TD, L::V>(dxp + c0, o2);
