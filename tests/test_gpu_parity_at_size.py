@@ -113,7 +113,7 @@ def _oracle_slice_impl(hp, state, inputs, rows, B, iteration):
     return preds, t, {k: (g if g is not None else torch.zeros_like(P[k])) for k, g in zip(P, grads)}
 
 
-def _compare(mode, hip, ora, what):
+def _compare(mode, hip, ora, what, sigma_factor=None):
     tol = TOL[mode]
     (hp_preds, hp_terms, hp_grads), (or_preds, or_terms, or_grads) = hip, ora
     errs = {k: _rel(hp_preds[k], or_preds[k]) for k in or_preds}
@@ -122,7 +122,7 @@ def _compare(mode, hip, ora, what):
     lerr = float((hp_terms - or_terms).abs().max() / or_terms.abs().max())
     print(what, mode, 'loss terms', hp_terms.tolist(), or_terms.tolist())
     assert lerr <= tol['loss'], (what, mode, lerr)
-    worst = gradient_report(hp_grads, or_grads, tol['grad'], tol['floor'], sigma_factor=2. if mode == 'fp32' else 3.5)
+    worst = gradient_report(hp_grads, or_grads, tol['grad'], tol['floor'], sigma_factor=sigma_factor or (2. if mode == 'fp32' else 3.5))
     print(what, mode, 'worst gradient tensors (err / bound, name, max abs err, max abs ref):')
     for w in worst[:6]:
         print('   ', f'{w[0]:.3f}', w[1], f'{w[2]:.3e}', f'{w[3]:.3e}')
@@ -143,8 +143,10 @@ def _stagewise_bf16(model, hp, state, inputs, rows, what):
     _stagewise_check(trace, hp, state, rows, what)
 
 
-def _stagewise_check(trace, hp, state, rows, what):
-    ''' the recorded stages of a HIP forward pass (training `_forward` or `inference`) against the bf16-emulating oracle '''
+def _stagewise_check(trace, hp, state, rows, what, train=False):
+    ''' the recorded stages of a HIP forward pass (training `_forward` or `inference`) against the bf16-emulating oracle.
+        train = True: dropout on -- the caller has replaced `O.dropout` by a feed of the HIP pass's own masks
+        (tests/test_gpu_dropout_parity.py), consumed in stage order '''
     P = state
     cfgs = {'prosody_encoder': hp.prosody_encoder, 'phoneme_encoder': hp.phoneme_encoder, 'frame_decoder': hp.frame_decoder}
     cpu = lambda t: None if t is None else t.detach().float().cpu()[rows]
@@ -165,8 +167,9 @@ def _stagewise_check(trace, hp, state, rows, what):
                 if kind == 'fft_block':
                     pad = ~O.valid_mask(ls, N)
                     cfg = cfgs[names.split('.')[0]]
-                    a = O.multi_head_attention(P, names + '.attention.', xs, pad, cfg['attn_nb_heads'], 0., False).masked_fill(pad.unsqueeze(2), 0.)
-                    u = O.conv_ff(P, names + '.feed_forward.', out[0], fs, 0., False).masked_fill(pad.unsqueeze(2), 0.)
+                    a = O.multi_head_attention(P, names + '.attention.', xs, pad, cfg['attn_nb_heads'], cfg['attn_dropout'] if train else 0.,
+                                               train).masked_fill(pad.unsqueeze(2), 0.)
+                    u = O.conv_ff(P, names + '.feed_forward.', out[0], fs, cfg['conv_dropout'] if train else 0., train).masked_fill(pad.unsqueeze(2), 0.)
                     pairs = [(names + ' attention+LN', out[0], a), (names + ' FF+LN (HIP attention output in)', out[1], u)]
                 elif kind == 'conv_ln':
                     conv_name, ln_name, skip = names
@@ -175,6 +178,8 @@ def _stagewise_check(trace, hp, state, rows, what):
                     if y.shape[2] != 128:
                         y = O._stored_lp(y)
                     y = O.layer_norm(y, P[ln_name + '.weight'], P[ln_name + '.bias'])
+                    if train:
+                        y = O.dropout(y, (hp.prosody_encoder if conv_name.startswith('prosody_encoder') else hp.local_prosody_predictor)['conv_dropout'], True)
                     if fs is not None:
                         C = fs.shape[1] // 2
                         y = fs[:, None, :C] * y + fs[:, None, C:]

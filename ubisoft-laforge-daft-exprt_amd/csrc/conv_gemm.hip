@@ -637,7 +637,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
               const uint32_t th = dx_drop_th8(p.ln.p_pre), key = dx_key32(dx_seed_eff(p.ln.seed_pre, p.ln.step), 0);
               const float sc = dx_drop_inv_keep8(th);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = dx_keep8(key, (uint32_t)rowg * BN + cl + e, th) ? v[e] * sc : 0.f;
+              for (int e = 0; e < 8; ++e) v[e] = dx_keep_elem(key, (uint32_t)rowg * BN + cl + e, th) ? v[e] * sc : 0.f;
             }
             store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + offl, v);
             continue;
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
               const uint32_t th = dx_drop_th8(p.ln.p_pre), key = dx_key32(dx_seed_eff(p.ln.seed_pre, p.ln.step), 0);
               const float sc = dx_drop_inv_keep8(th);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = dx_keep8(key, (uint32_t)rowg * BN + cl + e, th) ? v[e] * sc : 0.f;
+              for (int e = 0; e < 8; ++e) v[e] = dx_keep_elem(key, (uint32_t)rowg * BN + cl + e, th) ? v[e] * sc : 0.f;
             }
             {
               const f32x8 r = pf_a[pass];
@@ -1398,7 +1398,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
               const uint32_t th = dx_drop_th8(p.ln.p_pre), key = dx_key32(dx_seed_eff(p.ln.seed_pre, p.ln.step), 0);
               const float sc = dx_drop_inv_keep8(th);
 #pragma unroll
-              for (int e2 = 0; e2 < 8; ++e2) v[e2] = dx_keep8(key, (uint32_t)rowg * BN + cl + e2, th) ? v[e2] * sc : 0.f;
+              for (int e2 = 0; e2 < 8; ++e2) v[e2] = dx_keep_elem(key, (uint32_t)rowg * BN + cl + e2, th) ? v[e2] * sc : 0.f;
             }
             store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + offl, v);
             if (gemm2) store8<bf16_t>(a2 + sr * A2_LD + cl, v);
@@ -1407,7 +1407,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
               const uint32_t th = dx_drop_th8(p.ln.p_pre), key = dx_key32(dx_seed_eff(p.ln.seed_pre, p.ln.step), 0);
               const float sc = dx_drop_inv_keep8(th);
 #pragma unroll
-              for (int e2 = 0; e2 < 8; ++e2) v[e2] = dx_keep8(key, (uint32_t)rowg * BN + cl + e2, th) ? v[e2] * sc : 0.f;
+              for (int e2 = 0; e2 < 8; ++e2) v[e2] = dx_keep_elem(key, (uint32_t)rowg * BN + cl + e2, th) ? v[e2] * sc : 0.f;
             }
             {
               const f32x8 r = pf_a[pass];

@@ -336,7 +336,7 @@ __device__ __forceinline__ void dx_drop4x2_var(float* a, float* b, uint32_t w0, 
 // element-wise dropout of the (row, channel) activations: one hash per 4 consecutive channels, one byte each, p quantised like
 // the attention-weight dropout (dx_drop_th8 / dx_drop_inv_keep8).  Every site of one stream key -- forward and backward, whichever
 // kernel they live in -- must use this form.
-__device__ __forceinline__ bool dx_keep8(uint32_t key, uint32_t idx, uint32_t th8) {
+__device__ __forceinline__ bool dx_keep_elem(uint32_t key, uint32_t idx, uint32_t th8) {
   const uint32_t h = dx_mix32((idx >> 2) * 0x9E3779B1u + key);
   return ((h >> ((idx & 3u) * 8u)) & 0xffu) >= th8;
 }

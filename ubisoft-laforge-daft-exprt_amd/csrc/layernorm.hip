@@ -66,7 +66,7 @@ __device__ __forceinline__ void store_vec<bf16_t, 4>(bf16_t* p, const float* in)
   *reinterpret_cast<bf16x4*>(p) = v;
 }
 
-// Dropout in front of / behind a LayerNorm: dx_keep8 (dx_common.h) -- one hash per 4 consecutive channels.  One murmur hash per
+// Dropout in front of / behind a LayerNorm: dx_keep_elem (dx_common.h) -- one hash per 4 consecutive channels.  One murmur hash per
 // element (3 quarter-rate 32-bit multiplies) was 40 % of ln_fwd<1024> and a fifth of its backward.
 
 template <typename TI, typename TO, int C>
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
     if (th_pre) {
 #pragma unroll
       for (int i = 0; i < L::V; ++i)
-        v[k * L::V + i] = dx_keep8(key_pre, (uint32_t)row * C + c0 + i, th_pre) ? v[k * L::V + i] * sc_pre : 0.f;
+        v[k * L::V + i] = dx_keep_elem(key_pre, (uint32_t)row * C + c0 + i, th_pre) ? v[k * L::V + i] * sc_pre : 0.f;
     }
     if (a.res) {
       float r[L::V];
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNArgs a) {
 #pragma unroll
     for (int i = 0; i < L::V; ++i) {
       float t = (v[k * L::V + i] - mean) * rstd * g[i] + bt[i];
-      if (th_post) t = dx_keep8(key_post, (uint32_t)row * C + c0 + i, th_post) ? t * sc_post : 0.f;
+      if (th_post) t = dx_keep_elem(key_post, (uint32_t)row * C + c0 + i, th_post) ? t * sc_post : 0.f;
       o[i] = t;
     }
     if (a.film) {
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, C >= 1024 ? (FILM ? 1 : ((sizeof(TI) == 4 || s
   const uint32_t th_pre = dx_drop_th8(a.p_pre), th_post = dx_drop_th8(a.p_post);
   const uint32_t key_pre = dx_key32(dx_seed_eff(a.seed_pre, a.step), 0), key_post = dx_key32(dx_seed_eff(a.seed_post, a.step), 1);
   const float sc_pre = th_pre ? dx_drop_inv_keep8(th_pre) : 1.f;
-  const float sc_post = th_post ? dx_drop_inv_keep8(th_post) : 1.f;      // (quantised with the threshold: see dx_keep8)
+  const float sc_post = th_post ? dx_drop_inv_keep8(th_post) : 1.f;      // (quantised with the threshold: see dx_keep_elem)
   const int nskip = a.skip ? (int)a.skip[b] + 2 : a.N;
   const int nfill = a.skip ? dx_fill_end((int)a.skip[b], a.N) : a.N;
 
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, C >= 1024 ? (FILM ? 1 : ((sizeof(TI) == 4 || s
         pos |= (xh[j] > 0.f ? 1u : 0u) << j;
         xh[j] = (xh[j] - mean) * rstd;
         float keep_post = 1.f;
-        if (th_post) keep_post = dx_keep8(key_post, (uint32_t)row * C + c, th_post) ? sc_post : 0.f;
+        if (th_post) keep_post = dx_keep_elem(key_post, (uint32_t)row * C + c, th_post) ? sc_post : 0.f;
         if (FILM) {                                         // y = fg * (ln * keep) + fb
           const float ln = xh[j] * gmj + btj;               // LayerNorm output before dropout_post / FiLM
           acc_fg[FILM ? j : 0] += gy * ln * keep_post;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, C >= 1024 ? (FILM ? 1 : ((sizeof(TI) == 4 || s
         o[i] = rstd * (g[j] - m1 - xh[j] * m2);
         if (a.relu_input && !((pos >> j) & 1u)) o[i] = 0.f;
         o2[i] = o[i];
-        if (th_pre) o2[i] = dx_keep8(key_pre, (uint32_t)row * C + c0 + i, th_pre) ? o[i] * sc_pre : 0.f;
+        if (th_pre) o2[i] = dx_keep_elem(key_pre, (uint32_t)row * C + c0 + i, th_pre) ? o[i] * sc_pre : 0.f;
       }
       store_vec<TD, L::V>(ds + c0, o);
       if (dxp) store_vec<TD, L::V>(dxp + c0, o2);

@@ -202,6 +202,7 @@ class DaftExprt(nn.Module):
         self._hard = {}
         self.attn_lpt = True           # see _order
         self._step_id, self._site, self._rank, self._capture_step0 = 0, 0, 0, 0
+        self._seed_log = None
         self._trace = None    # tests set this to a list: every stage appends (kind, names, input, film, lengths, output)
         self._trace_bwd = None   # likewise for the backward pass: (kind, saved, saved_below, gradient in, gradient out)
         self._pos = None
@@ -454,15 +455,18 @@ class DaftExprt(nn.Module):
             (torch's per-process Philox streams in the reference are independent as well) '''
         self._rank = int(rank)
 
-    def _seed(self):
+    def _seed(self, kind=None):
         ''' dropout seed of the next site of this forward pass: a function of (hparams seed, step, site, rank).  While a step is being
             captured (`ops.STEP_PTR` set) the absolute step stays out of the by-value seed -- only the micro-batch's offset from the
             capture's first one goes in -- and the kernels add `step_salt()` from the device-side step block: same sum mod 2^63, so
             a replayed step draws the masks the eager step with the same step id draws. '''
         self._site += 1
         step = self._step_id if ops.STEP_PTR is None else self._step_id - self._capture_step0
-        return (int(self.hp.seed) * 0x9E3779B1 + step * 0x85EBCA77 + self._site * 0xC2B2AE3D +
+        seed = (int(self.hp.seed) * 0x9E3779B1 + step * 0x85EBCA77 + self._site * 0xC2B2AE3D +
                 self._rank * 0x27D4EB2F165667C5) & _MASK63
+        if self._seed_log is not None:      # tests/test_gpu_dropout_parity.py: the oracle draws the same masks from these
+            self._seed_log.append((kind, seed))
+        return seed
 
     def step_salt(self, step_id=None):
         ''' the step's share of every dropout seed, for the device-side step block (see `_seed`) '''
@@ -529,7 +533,7 @@ class DaftExprt(nn.Module):
         p_attn = cfg['attn_dropout'] if train else 0.
         p_conv = cfg['conv_dropout'] if train else 0.
         s = _Saved() if save else None
-        seeds = [self._seed() for _ in range(3)]
+        seeds = [self._seed(k) for k in ('attention weights', 'attention output', 'feed-forward output')]
         xin = x_lp if x_lp is not None else x
         if qkv is None:
             qkv = ops.conv1d(xin, W[f'{a_pre}.multi_head_attention.in_proj_weight'], P[f'{a_pre}.multi_head_attention.in_proj_bias'],
@@ -566,7 +570,7 @@ class DaftExprt(nn.Module):
         c_dtype = torch.float32 if (self.cd == torch.float32 or cout == 128) else self.cd   # wide tensors in the MFMA operand type
         c = ops.conv1d(x, W[f'{conv_name}.conv.weight'], P[f'{conv_name}.conv.bias'], relu=True, out_dtype=c_dtype, skip_lengths=skip,
                        w_frag=W.get(f'F:{conv_name}.conv.weight'), wide_plan=self._plan_wide(skip, x.shape[1]) if f'F:{conv_name}.conv.weight' in W else None)
-        seed = self._seed()
+        seed = self._seed('behind LayerNorm')
         y, _, mean, rstd = ops.layernorm_fwd(c, P[f'{ln_name}.weight'], P[f'{ln_name}.bias'], film=film, lengths=lengths,
                                              out_dtype=out_dtype, save=save, p_post=p_drop, seed_post=seed, skip_lengths=skip)
         s = None
