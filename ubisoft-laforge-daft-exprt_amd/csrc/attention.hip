@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : (sizeof(TC) == 4 ? 1 : 2)) void
 // =============================================================================== backward, fused (bf16, d_head = 16)
 // ONE recomputation of S and dP for dQ, dK and dV (the two kernels above recompute them once each, and the d_head = 16 kernels
 // are bound by that VALU work, not by their MFMAs).  A workgroup (4 waves, two resident per CU) owns the KEYS of one (utterance,
-// head) -- all of them up to 512, one half each of a longer utterance -- and walks ALL of its queries:
+// head) -- all of them up to FB_KEYS, an even share of a longer utterance -- and walks ALL of its queries:
 //   * wave w keeps the K / V fragments of its <= 4 key blocks (32 keys each) in registers for the whole kernel together with
 //     their dK^T / dV^T accumulators (16x16x32 MFMAs: 16 d x 16 keys per accumulator, no padding);
 //   * the queries stream through LDS in stages of 128 rows (Q and dO, next stage prefetched in registers; delta = rowsum(dO * O)
@@ -721,11 +721,18 @@ __global__ __launch_bounds__(256, DH <= 16 ? 3 : (sizeof(TC) == 4 ? 1 : 2)) void
 //     wave-private 32 x 32 bf16 LDS tile and come back key-major with ds_read_b64_tr_b16 (8 b64 writes + 8 transposed reads
 //     per tile instead of a second softmax recomputation);
 //   * the 4 partial dQ^T of a query block (one per wave) meet in LDS and are summed in wave order: deterministic, no atomics;
-//   * an utterance of more than 512 keys has two workgroups: each leaves its fp32 dQ partial in the workspace, and the one that
-//     arrives second (an arrival counter per (utterance, head), release / acquire fences at agent scope) adds the two in key order
-//     and writes dQ -- two terms, so the sum does not depend on who arrives first.
+//   * an utterance of more than FB_KEYS keys has up to FB_PARTS workgroups (even shares of its key blocks): each leaves its fp32 dQ
+//     partial in the workspace, and the one that arrives LAST (an arrival counter per (utterance, head), release / acquire fences at
+//     agent scope) adds them in key order and writes dQ -- a fixed order, so the sum does not depend on who arrives when.
+//     FB_KB = 4 key blocks per wave = 512 keys per workgroup.  Measured with 2 (256 keys, up to 4 workgroups per (utterance, head):
+//     the longest workgroup half as long): 170 vs 120 us on the bench batch -- nearly every utterance then leaves partials
+//     (98 MB written + read per launch instead of ~30) and the per-query-block work that does not depend on the key count
+//     (fragments, transposes, the dQ hand-over) doubles.
 // N <= 1024; longer batches take the two-pass kernels.
-constexpr int FB_W = 4, FB_T = FB_W * 64, FB_KB = 4, FB_QT = 128, FB_KEYS = FB_W * FB_KB * 32, FB_MAXN = 2 * FB_KEYS;
+#ifndef DX_FB_KB
+#define DX_FB_KB 4
+#endif
+constexpr int FB_W = 4, FB_T = FB_W * 64, FB_KB = DX_FB_KB, FB_QT = 128, FB_KEYS = FB_W * FB_KB * 32, FB_MAXN = 1024, FB_PARTS = FB_MAXN / FB_KEYS;
 #ifndef DX_FB_LDT
 #define DX_FB_LDT 36
 #endif
@@ -768,15 +775,15 @@ __device__ __forceinline__ void dx_drop4x2(float* pm, const float* pr, float* x,
       : "v"(pr[0]), "v"(pr[1]), "v"(pr[2]), "v"(pr[3]), "v"(w), "v"(th8));
 }
 
-// workspace of the fused kernel behind the (B, H, N) floats of delta: B * H * 2 fp32 dQ partials of (N_pad x 16); nothing in it has to
-// survive a launch.  The B * H arrival counters live in a buffer of their own (`counters`): zero before the first launch, and the second
-// arrival of a pair puts its counter back to zero, so the same small buffer serves every shape and every later launch on the stream.
+// workspace of the fused kernel behind the (B, H, N) floats of delta: B * H * FB_PARTS fp32 dQ partials of (N_pad x 16); nothing in it has to
+// survive a launch.  The B * H arrival counters live in a buffer of their own (`counters`): zero before the first launch, and the last
+// arrival of a group puts its counter back to zero, so the same small buffer serves every shape and every later launch on the stream.
 __host__ __device__ static inline long fb_ws_floats(int B, int N, int H) {
   const long npad = (N + 31) & ~31;
-  return (long)B * H * 2 * npad * 16;
+  return (long)B * H * FB_PARTS * npad * 16;
 }
 
-__global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, float* ws) {   // grid: attn_grid(B, 2 H)
+__global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, float* ws) {   // grid: attn_grid(B, FB_PARTS * H)
   constexpr int DH = 16;
   typedef bf16_t TC;
   typedef bf16x8 frag_t;
@@ -792,14 +799,15 @@ __global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, f
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = a.H, N = a.N, E = a.E;
   int bi, inner_;
-  if (!attn_decode((int)blockIdx.x, 2 * H, a.B, bi, inner_)) return;
-  const int half = inner_ & 1, h = inner_ >> 1;
+  if (!attn_decode((int)blockIdx.x, FB_PARTS * H, a.B, bi, inner_)) return;
+  const int part = inner_ % FB_PARTS, h = inner_ / FB_PARTS;
   const int b = a.order ? a.order[bi] : bi;
   int len = (int)a.lengths[b];
   len = len < 0 ? 0 : (len > N ? N : len);
   const int nkb_all = (len + 31) >> 5, rows_live = nkb_all * 32;
-  const bool split = nkb_all > FB_KEYS / 32;                             // two workgroups share this (utterance, head)
-  if (half && !split) return;
+  const int nparts = nkb_all > 0 ? (nkb_all + FB_KEYS / 32 - 1) / (FB_KEYS / 32) : 1;   // workgroups that share this (utterance, head)
+  const bool split = nparts > 1;
+  if (part >= nparts) return;
   const long ld_g = 3L * E;
   const TC* base = reinterpret_cast<const TC*>(a.qkv) + (long)b * N * ld_g + h * DH;
   const TC* dO = reinterpret_cast<const TC*>(a.d_o) + (long)b * N * E + h * DH;
@@ -807,9 +815,9 @@ __global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, f
   TC* dQ = reinterpret_cast<TC*>(a.dqkv) + (long)b * N * ld_g + h * DH;
   const float* lse = a.lse + ((long)b * H + h) * N;
   const long npad = (N + 31) & ~31;
-  float* part = ws + (((long)b * H + h) * 2 + half) * npad * 16;        // split utterances: this workgroup's dQ partial [query][d]
+  float* pbuf = ws + (((long)b * H + h) * FB_PARTS + part) * npad * 16;   // split utterances: this workgroup's dQ partial [query][d]
   int* counter = a.counters + (b * H + h);
-  if (!half) {   // rows past the last live block: dQ | dK | dV are zero (this head's 16 columns of each)
+  if (part == 0) {   // rows past the last live block: dQ | dK | dV are zero (this head's 16 columns of each)
     const frag_t z = zero8<TC>();
     const int nz = (max(dx_fill_end(len, N), rows_live) - rows_live) * 6;   // (only below the fill end: nobody reads past it, dx_common.h)
     for (int c = tid; c < nz; c += FB_T) {
@@ -819,7 +827,7 @@ __global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, f
   }
   if (len == 0) return;
   // key blocks of this workgroup [kbA, kbB) and of this wave [kb0, kb0 + cnt): spread evenly over the waves that get any
-  const int kbA = split ? (half ? (nkb_all + 1) >> 1 : 0) : 0, kbB = split ? (half ? nkb_all : (nkb_all + 1) >> 1) : nkb_all;
+  const int kbA = (part * nkb_all) / nparts, kbB = ((part + 1) * nkb_all) / nparts;
   const int nkb = kbB - kbA;
   for (int c = tid; c < nkb * 64; c += FB_T) {
     const int r = c >> 1, hf = (c & 1) * 8, key = kbA * 32 + r;
@@ -974,7 +982,7 @@ __global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, f
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc4[e] += red[buf][ww][rhi * 4 + e][gg * 32 + qq];
         if (split) {
-          *reinterpret_cast<f32x4*>(part + (long)(qb + qq) * 16 + 4 * dg) = f32x4{acc4[0], acc4[1], acc4[2], acc4[3]};
+          *reinterpret_cast<f32x4*>(pbuf + (long)(qb + qq) * 16 + 4 * dg) = f32x4{acc4[0], acc4[1], acc4[2], acc4[3]};
         } else if (qb + qq < N) {
           bf16x4 o4;
 #pragma unroll
@@ -1002,7 +1010,7 @@ __global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, f
     }
   }
   if (!split) return;
-  // second arrival of the pair adds the two partials (keys 0.. first, then the upper half) and writes dQ
+  // the last arrival of the group adds the partials in key order and writes dQ
   // (hand-off recipe of the CDNA guide, section 6 G16: drain every wave's stores, ONE lane releases at agent scope, then the
   // ticket; the second arrival acquires once -- a __threadfence() per thread made this kernel 1.8x slower)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1010,24 +1018,24 @@ __global__ __launch_bounds__(FB_T, 2) void attn_bwd_fused16_kernel(AttnArgs a, f
   if (tid == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int second = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1;
-    if (second) {
+    const int last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nparts - 1;
+    if (last) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // both arrivals are in: zero again for the next launch
+      __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all arrivals are in: zero again for the next launch
     }
-    arrived = second;
+    arrived = last;
   }
   __syncthreads();
   if (!arrived) return;
-  const float* p0 = ws + (((long)b * H + h) * 2) * npad * 16;
-  const float* p1 = p0 + npad * 16;
+  const float* p0 = ws + (((long)b * H + h) * FB_PARTS) * npad * 16;
   for (int c = tid; c < rows_live * 4; c += FB_T) {
     const int qq = c >> 2, dg = c & 3;
     if (qq < N) {
-      const f32x4 x0 = *reinterpret_cast<const f32x4*>(p0 + (long)qq * 16 + 4 * dg), x1 = *reinterpret_cast<const f32x4*>(p1 + (long)qq * 16 + 4 * dg);
+      f32x4 x = *reinterpret_cast<const f32x4*>(p0 + (long)qq * 16 + 4 * dg);
+      for (int pp = 1; pp < nparts; ++pp) x += *reinterpret_cast<const f32x4*>(p0 + (long)pp * npad * 16 + (long)qq * 16 + 4 * dg);
       bf16x4 o4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o4[e] = (TC)((x0[e] + x1[e]) * a.scale);
+      for (int e = 0; e < 4; ++e) o4[e] = (TC)(x[e] * a.scale);
       *reinterpret_cast<bf16x4*>(dQ + (long)qq * ld_g + 4 * dg) = o4;
     }
   }
@@ -1059,7 +1067,7 @@ int launch_bwd(const AttnArgs& a0, int B, int dh, float* delta, int algo, hipStr
   }
   if (can_fuse && (algo == DX_ATTN_FUSED || algo == DX_ATTN_AUTO)) {
     if (!a.counters) { dx_set_error("dx_attention_bwd: the fused kernel needs the arrival counters (dx_attention_bwd_counters(B, H) ints, zeroed once)"); return DX_ERR_ARG; }
-    hipLaunchKernelGGL(attn_bwd_fused16_kernel, dim3(attn_grid(B, 2 * a.H)), dim3(FB_T), 0, s, a, delta + (long)B * a.H * a.N);
+    hipLaunchKernelGGL(attn_bwd_fused16_kernel, dim3(attn_grid(B, FB_PARTS * a.H)), dim3(FB_T), 0, s, a, delta + (long)B * a.H * a.N);
     DX_LAUNCH_CHECK();
     return DX_OK;
   }
