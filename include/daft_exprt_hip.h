@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DX_ABI_VERSION 11
+#define DX_ABI_VERSION 12
 
 enum { DX_F32 = 0, DX_BF16 = 1, DX_I64 = 2 };
 enum { DX_OK = 0, DX_ERR_ARG = -1, DX_ERR_SHAPE = -2, DX_ERR_DTYPE = -3, DX_ERR_LAUNCH = -4, DX_ERR_UNSUPPORTED = -5 };
@@ -93,6 +93,18 @@ int dx_conv1d(const void* x, int x_dtype, long ldx, const void* w_packed, int w_
 int dx_conv1d_wfrag(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const void* w_frag, const float* bias,
                     void* y, int y_dtype, long ldy, const void* relu_gate, int gate_dtype, const int64_t* mask_lengths,
                     const int64_t* skip_lengths, int B, int N, int Cin, int Cout, int taps, int flags, void* stream);
+
+/* The ReLU gate of the FF block as one BIT per element (ABI v12).  The data gradient of PositionWiseConvFF's second conv
+ * (model.py:220-237: conv k3 -> ReLU -> conv k3) is gated by `h > 0`, h = the ReLU output of the first conv: a (B, N, Cout) tensor
+ * that the gate would re-read in full.  Instead the forward conv leaves `bits` next to h and the data gradient reads those:
+ *   bits_out != NULL:  y = relu(conv_k3(x, w) + bias) as dx_conv1d_wfrag with DX_CONV_RELU, and bits_out = (y > 0);
+ *   bits_in  != NULL:  y = conv_k3(x, w) where bits_in, 0 elsewhere (the data gradient: w = the transposed / flipped copy, no bias).
+ * bf16 x / w / y, Cin = 128, taps = 3, Cout % 256 == 0 (the register-weights kernel); w_frag optional as in dx_conv1d_wfrag.
+ * bits: uint32 (B, Cout / 32, N); the bit order inside a word is private to the kernel pair (its own register order) -- only
+ * these two calls read or write it.  mask_lengths / skip_lengths as in dx_conv1d; rows at or past mask_lengths have no bit set. */
+int dx_conv1d_relu_bits(const void* x, long ldx, const void* w_packed, const void* w_frag, const float* bias, void* y, long ldy,
+                        uint32_t* bits_out, const uint32_t* bits_in, const int64_t* mask_lengths, const int64_t* skip_lengths,
+                        int B, int N, int Cout, void* stream);
 
 /* dx_conv1d with Cout = 128 and the following LayerNorm fused into its epilogue (a 128-row tile holds complete rows):
  *   s = dropout_pre(conv(x) + bias) + residual;  y = LN(s) * gamma + beta;  y = film[b,:128] * y + film[b,128:];

@@ -215,3 +215,45 @@ def test_batch_prep_equals_the_three_separate_launches():
         assert torch.equal(p0[0], r0[0]) and torch.equal(p2[0], r2[0]) and torch.equal(od, ro)
     a, b, c = ops.batch_prep(lt, N, plan=False, wide=True, order=False)
     assert a is None and c is None and torch.equal(b[0], r2[0])
+
+
+@pytest.mark.parametrize('B,N,Cout,frag', [(3, 301, 1024, True), (2, 128, 256, False), (5, 1000, 1024, True), (1, 7, 512, False)])
+def test_relu_bits_gate_equals_gating_on_the_activation(B, N, Cout, frag):
+    ''' dx_conv1d_relu_bits: the ReLU forward that also leaves one bit per element returns the SAME activation as the plain call, and
+        the data gradient gated by those bits is bit-equal to the one gated by the activation -- incl. mask_lengths (grouped steps: rows
+        at or past the hard sequence end are zero and carry no bit), skip_lengths (dead tiles) and values that round to bf16 zero '''
+    from daft_exprt import ops
+    from tests.util import drop_unwritten
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    x = (torch.randn(B, N, 128, generator=g) * (torch.rand(B, N, 1, generator=g) < 0.9)).to(dev).to(torch.bfloat16)   # some all-zero rows: h = relu(bias)
+    w = torch.randn(Cout, 128, 3, generator=g) / 20.
+    bias = torch.randn(Cout, generator=g) * 0.05
+    bias[::7] = 0.                                                   # with a zero row: exact zeros in front of the ReLU
+    lens = torch.randint(1, N + 1, (B,), generator=g)
+    lens[0] = N
+    lens, nmax = lens.to(dev), torch.clamp(lens + 1, max=N).to(dev)
+    wp = ops.pack_conv_weight(w.to(dev), torch.bfloat16)
+    wf = ops.pack_frag_major(wp) if frag else None
+    args = dict(out_dtype=torch.bfloat16, relu=True, skip_lengths=lens, mask_lengths=nmax, w_frag=wf)
+    assert ops.relu_bits_ok(x, wp, torch.bfloat16)
+    h0 = ops.conv1d(x, wp, bias.to(dev), **args)
+    h1, bits = ops.conv1d(x, wp, bias.to(dev), relu_bits=True, **args)
+    torch.cuda.synchronize()
+    assert bits.dtype == torch.int32 and tuple(bits.shape) == (B, Cout // 32, N)
+    a, b = drop_unwritten(h0.float().cpu(), lens.cpu()), drop_unwritten(h1.float().cpu(), lens.cpu())
+    assert torch.equal(a, b)
+    live = torch.arange(N)[None, :] < (lens.cpu()[:, None] + 2)
+    share = float((a[live] > 0).float().mean())
+    assert 0.2 < share < 0.8, share                                  # the gate is neither all open nor all closed
+    # data gradient of the 1024 -> 128 partner: dz (B, N, 128) x W2^T -> (B, N, Cout), gated
+    dz = torch.randn(B, N, 128, generator=g).to(dev).to(torch.bfloat16)
+    w2 = torch.randn(128, Cout, 3, generator=g) / 50.
+    w2t = ops.pack_conv_weight(w2.to(dev), torch.bfloat16, transpose_flip=True)
+    w2f = ops.pack_frag_major(w2t) if frag else None
+    d0 = ops.conv1d(dz, w2t, None, out_dtype=torch.bfloat16, relu_gate=h0, skip_lengths=lens, w_frag=w2f)
+    d1 = ops.conv1d(dz, w2t, None, out_dtype=torch.bfloat16, relu_gate=bits, skip_lengths=lens, w_frag=w2f)
+    torch.cuda.synchronize()
+    a, b = drop_unwritten(d0.float().cpu(), lens.cpu()), drop_unwritten(d1.float().cpu(), lens.cpu())
+    assert torch.equal(a[live], b[live]), float((a - b).abs().max())
+    assert float(a[live].abs().max()) > 0.

@@ -52,6 +52,8 @@ struct ConvArgs {
   LNEpi ln;
   const int* plan; int plan_tiles;     // balanced position tiles {b, n0, rows, 0} (dx_conv_tile_plan), ring kernels only
   const void* w_frag;                  // the same weights in MFMA-fragment order (dx_pack_frag_major): split-K kernel, or NULL
+  uint32_t* relu_bits;                 // conv_wreg_kernel<BITS>: sign bits of the ReLU output, (B, Cout / 32, N) words -- written (RELU) ...
+  const uint32_t* gate_bits;           // ... or read as the gate of the data gradient (GATE) instead of the activation itself
 };
 
 // Pipeline: the global loads of K-chunk k+1 are issued into registers (raw element type, converted only when they are
@@ -717,7 +719,10 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
 // MFMAs of the next tile, so no wave waits for another between tiles.  The live position tiles of the batch
 // (skip_lengths) are split evenly over the workgroups of a channel block; dead tiles are zero-filled in a second pass.
 constexpr int WR_THREADS = 512, WR_BN = 256, WR_BM = 128;
-template <typename TO, typename TG, int TAPS, bool RELU, bool GATE>
+// BITS (bf16 output only): the ReLU of the FF block's first conv also leaves ONE BIT per output element -- a 32-bit word per
+// (position, 32-channel block of a wave), bit layout = the wave's own post-swap register order -- and the data gradient of the second
+// conv gates with that word instead of re-reading the 2 KB activation row: 128 B instead of 2 KB per row of gate traffic.
+template <typename TO, typename TG, int TAPS, bool RELU, bool GATE, bool BITS = false>
 __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, int ngrp) {
   typedef bf16_t TC;
   constexpr int BM = WR_BM, HALO = TAPS / 2, AROWS = BM + TAPS - 1, CIN = 128, LDK = CIN + Pad<TC>::value, KCH = CIN / 8;
@@ -851,7 +856,12 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   u32x4_t gpre[2][2];
   auto gate_fetch = [&](u32x4_t* dst, const Epi& e, int row0) {
-    if constexpr (GATE && sizeof(TO) == 2) {
+    if constexpr (GATE && BITS) {
+      const int n = e.n0 + row0 + l31;
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<uint32_t*>(p.gate_bits) + ((size_t)e.cb * (Cout >> 5) + (co0 >> 5)) * N, 0, (uint32_t)((size_t)N * 4), 0x00020000);
+      dst[0][0] = __builtin_amdgcn_raw_buffer_load_b32(rb, n * 4, 0, 0);      // (rows outside [0, N): zero = gate closed; their stores are dropped)
+    } else if constexpr (GATE && sizeof(TO) == 2) {
       const int n = e.n0 + row0 + l31;
       const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<TG*>(G) + (size_t)e.cb * N * p.ldy, 0, (uint32_t)((size_t)N * p.ldy * sizeof(TG)), 0x00020000);
@@ -906,11 +916,31 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
           P[4 * h2 + 2 + k] = sw[1];
         }
       // now (P0, P1, P2, P3) = channel pairs (0,1)(2,3)(4,5)(6,7) + 8 g and (P4 .. P7) the same + 16
+      if constexpr (RELU && BITS) {   // bit k / 16 + k of a lane's word: low / high half of P[k] is non-zero (values are >= 0: + 0x7fff carries into bit 15)
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m |= (((P[k] + 0x7fff7fffu) >> (15 - k)) & (0x00010001u << k));
+        const uint32_t mp = (uint32_t)__shfl_xor((int)m, 32, 64);
+        uint32_t word = g ? (mp | (m << 8)) : (m | (mp << 8));      // lane group 0 in bits 0-7 / 16-23, group 1 in 8-15 / 24-31
+        if (zero_row) word = 0u;
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+            p.relu_bits + ((size_t)e.cb * (Cout >> 5) + (co0 >> 5)) * N, 0, (uint32_t)((size_t)N * 4), 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(word, rb, g ? (int)0xffffff00u : n * 4, 0, 0);   // one lane of the pair stores (the other one out of range)
+      }
+      uint32_t own = 0;
+      if constexpr (GATE && BITS) own = g ? (gw2[0][0] >> 8) : gw2[0][0];
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
         const uint32_t o = (eoff + 16 * h2 + 8 * g) * 2u;
         u32x4 w = {P[4 * h2], P[4 * h2 + 1], P[4 * h2 + 2], P[4 * h2 + 3]};
-        if (GATE) {   // gate > 0 on the packed bf16 bits: sign clear and magnitude non-zero  <=>  bits - 1 < 0x7fff (unsigned)
+        if constexpr (GATE && BITS) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = 4 * h2 + j;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)own, k, 1), hi = (uint32_t)__builtin_amdgcn_sbfe((int)own, 16 + k, 1);
+            w[j] &= (lo & 0x0000ffffu) | (hi & 0xffff0000u);
+          }
+        } else if (GATE) {   // gate > 0 on the packed bf16 bits: sign clear and magnitude non-zero  <=>  bits - 1 < 0x7fff (unsigned)
           const u32x4 gw = gw2[h2];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -1724,6 +1754,16 @@ bool try_weight_stationary(const ConvArgs& a, int B, int taps, hipStream_t s) {
     dim3 grid(ngrp * ztiles), block(WR_THREADS);
     const bool relu = a.flags & DX_CONV_RELU, gate = a.gate != nullptr;
     if ((size_t)a.N * a.ldy * 4 >= (1ull << 32) || (size_t)a.N * a.ldx * 2 >= (1ull << 32)) return false;   // 32-bit buffer offsets
+    if (a.relu_bits || a.gate_bits) {   // dx_conv1d_relu_bits: one bit per element written by the ReLU / read as the gate
+      if constexpr (sizeof(TO) == 2) {
+        if (taps != 3 || gate || (a.relu_bits != nullptr) == (a.gate_bits != nullptr) || (a.relu_bits && !relu) || (a.gate_bits && relu)) return false;
+        if (a.relu_bits) hipLaunchKernelGGL((conv_wreg_kernel<TO, TG, 3, true, false, true>), grid, block, 0, s, a, ngrp);
+        else hipLaunchKernelGGL((conv_wreg_kernel<TO, TG, 3, false, true, true>), grid, block, 0, s, a, ngrp);
+        return true;
+      } else {
+        return false;
+      }
+    }
 #define DX_WREG_LAUNCH(T, R, GT) hipLaunchKernelGGL((conv_wreg_kernel<TO, TG, T, R, GT>), grid, block, 0, s, a, ngrp)
     if (taps == 3) {
       if (relu && gate) DX_WREG_LAUNCH(3, true, true); else if (relu) DX_WREG_LAUNCH(3, true, false);
@@ -1871,6 +1911,25 @@ static int conv1d_impl(const void* x, int x_dtype, long ldx, const void* w_packe
   }
   dx_set_error("dx_conv1d: unsupported dtype combination x=%d w=%d y=%d gate=%d", x_dtype, w_dtype, y_dtype, gd);
   return DX_ERR_DTYPE;
+}
+
+extern "C" int dx_conv1d_relu_bits(const void* x, long ldx, const void* w_packed, const void* w_frag, const float* bias, void* y, long ldy,
+                                   uint32_t* bits_out, const uint32_t* bits_in, const int64_t* mask_lengths, const int64_t* skip_lengths,
+                                   int B, int N, int Cout, void* stream) {
+  DX_REQUIRE(x && w_packed && y, DX_ERR_ARG, "dx_conv1d_relu_bits: null pointer");
+  DX_REQUIRE((bits_out != nullptr) != (bits_in != nullptr), DX_ERR_ARG, "dx_conv1d_relu_bits: exactly one of bits_out (ReLU forward) / bits_in (gated data gradient)");
+  DX_REQUIRE(B > 0 && N > 0 && Cout > 0 && Cout % WR_BN == 0 && ldx % 8 == 0 && ldy % 8 == 0, DX_ERR_SHAPE,
+             "dx_conv1d_relu_bits: Cout %% 256 == 0 and row strides multiples of 8 (got B=%d N=%d Cout=%d ldx=%ld ldy=%ld)", B, N, Cout, ldx, ldy);
+  ConvArgs a{x, ldx, w_packed, bits_out ? bias : nullptr, y, ldy, nullptr, mask_lengths, skip_lengths, N, 128, Cout, bits_out ? DX_CONV_RELU : 0, B, LNEpi{}};
+  a.w_frag = w_frag;
+  a.relu_bits = bits_out;
+  a.gate_bits = bits_in;
+  if (!try_weight_stationary<bf16_t, bf16_t, bf16_t, bf16_t>(a, B, 3, (hipStream_t)stream)) {
+    dx_set_error("dx_conv1d_relu_bits: shape not taken by the register-weights kernel (N * ld beyond 32-bit buffer offsets?)");
+    return DX_ERR_UNSUPPORTED;
+  }
+  DX_LAUNCH_CHECK();
+  return DX_OK;
 }
 
 // ---- balanced position tiles (dx_conv_tile_plan) ----------------------------------------------------------------

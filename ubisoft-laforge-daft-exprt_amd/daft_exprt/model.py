@@ -546,8 +546,15 @@ class DaftExprt(nn.Module):
                                                   lp_copy=lp)
         ain = a_lp if lp else a
         # (grouped step: the FF hidden is the one unmasked tensor whose row AT the sequence end reaches valid outputs -- mask it there)
-        h = ops.conv1d(ain, W[f'{f_pre}.convs.0.conv.weight'], P[f'{f_pre}.convs.0.conv.bias'], out_dtype=cd, relu=True,
-                       skip_lengths=self._skip(lengths), mask_lengths=self._nmax(lengths), w_frag=W.get(f'F:{f_pre}.convs.0.conv.weight'))
+        # (training, bf16: the ReLU also leaves one bit per element -- the gate of the data gradient reads those instead of h, ops.conv1d)
+        hbits = None
+        wc0 = W[f'{f_pre}.convs.0.conv.weight']
+        if save and config.RELU_BITS and ops.relu_bits_ok(ain, wc0, cd):
+            h, hbits = ops.conv1d(ain, wc0, P[f'{f_pre}.convs.0.conv.bias'], out_dtype=cd, relu=True, relu_bits=True,
+                                  skip_lengths=self._skip(lengths), mask_lengths=self._nmax(lengths), w_frag=W.get(f'F:{f_pre}.convs.0.conv.weight'))
+        else:
+            h = ops.conv1d(ain, wc0, P[f'{f_pre}.convs.0.conv.bias'], out_dtype=cd, relu=True,
+                           skip_lengths=self._skip(lengths), mask_lengths=self._nmax(lengths), w_frag=W.get(f'F:{f_pre}.convs.0.conv.weight'))
         # second FF conv + Dropout + residual + LayerNorm + FiLM + mask in ONE launch
         nmha = f'{next_pre}.attention.multi_head_attention' if (next_pre is not None and lp) else None
         u, u_lp, s2, mean2, rstd2, qkv_next = ops.conv1d_ln(
@@ -559,6 +566,7 @@ class DaftExprt(nn.Module):
             s.pre, s.cfg, s.x, s.film, s.lengths = pre, cfg, xin, film, lengths
             s.qkv, s.o, s.lse, s.s1, s.mean1, s.rstd1, s.a, s.h, s.s2, s.mean2, s.rstd2 = qkv, o, lse, s1, mean1, rstd1, ain, h, s2, mean2, rstd2
             s.seeds, s.p_attn, s.p_conv = seeds, p_attn, p_conv
+            s.hbits = hbits
         if self._trace is not None:
             self._trace.append(('fft_block', pre, x, film, lengths, (a, u)))
         return u, u_lp, s, qkv_next
@@ -845,7 +853,7 @@ class DaftExprt(nn.Module):
         cap_in = ds2.clone() if self._trace_bwd is not None else None   # dL/d(s2 of this block): the residual gradient is updated in place below
         da = ds2
         self._wgrad(dz, s.h, G[f'{f_pre}.convs.2.conv.weight'], G[f'{f_pre}.convs.2.conv.bias'], s.lengths)
-        dh = ops.conv1d(dz, W[f'T:{f_pre}.convs.2.conv.weight'], None, out_dtype=cd, relu_gate=s.h, skip_lengths=self._skip(s.lengths),
+        dh = ops.conv1d(dz, W[f'T:{f_pre}.convs.2.conv.weight'], None, out_dtype=cd, relu_gate=s.hbits if s.hbits is not None else s.h, skip_lengths=self._skip(s.lengths),
                         w_frag=W.get(f'FT:{f_pre}.convs.2.conv.weight'))
         self._wgrad(dh, s.a, G[f'{f_pre}.convs.0.conv.weight'], G[f'{f_pre}.convs.0.conv.bias'], s.lengths)
         mha = f'{a_pre}.multi_head_attention'

@@ -97,9 +97,18 @@ def pack_conv_weight(w, dtype, transpose_flip=False, out=None):
 
 
 
+def relu_bits_ok(x, w_packed, out_dtype=None):
+    ''' the shapes `conv1d(..., relu_bits=True)` / a bit-mask `relu_gate` take: the register-weights kernel (dx_conv1d_relu_bits) '''
+    taps, Cout, Cin = w_packed.shape
+    return (x.is_cuda and taps == 3 and Cin == 128 and Cout % 256 == 0 and x.dtype == torch.bfloat16 and w_packed.dtype == torch.bfloat16
+            and (out_dtype or x.dtype) == torch.bfloat16 and x.stride(1) % 8 == 0)
+
+
 def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, mask_lengths=None,
-           transposed_out=False, out=None, accumulate=False, skip_lengths=None, w_frag=None, wide_plan=None):
+           transposed_out=False, out=None, accumulate=False, skip_lengths=None, w_frag=None, wide_plan=None, relu_bits=False):
     ''' x (B, N, Cin) [last dim contiguous]; w_packed (taps, Cout, Cin) -> (B, N, Cout) or (B, Cout, N).
+        relu_bits (with relu, shapes of `relu_bits_ok`): returns (y, bits) -- bits = int32 (B, Cout / 32, N), one bit per element of
+        y > 0; a later call passes it as `relu_gate` (an int32 tensor instead of the activation) and reads 1 / 16 of the gate bytes.
         w_frag + wide_plan: the same weights in fragment order (pack_frag_major) and the balanced tiles of the batch
         (conv_tile_plan(skip_lengths, N, halo=2, round_to=64)): the wide k = 3 GEMMs (bf16 in / out, Cin % 128 == 0,
         Cout % 256 == 0, nothing but bias / ReLU in the epilogue) then run on dx_conv1d_wide; w_frag alone with Cin = 128, k = 3:
@@ -120,6 +129,19 @@ def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, m
             H.check(H.lib().dx_conv1d_wide(H.ptr(x), x.stride(1), H.ptr(w_frag), H.ptr(bias), H.ptr(y), y.stride(1), H.ptr(skip_lengths),
                                            H.ptr(table), table.shape[0], 2, B, N, Cin, Cout, H.CONV_RELU if relu else 0, H.stream()))
         return y
+    gate_bits = relu_gate is not None and relu_gate.dtype == torch.int32
+    if relu_bits or gate_bits:
+        assert relu_bits_ok(x, w_packed, out_dtype) and out is None and not transposed_out and not accumulate and relu == bool(relu_bits) and \
+            (relu_gate is None or gate_bits), 'relu_bits / bit-mask gate: bf16 128 -> 256 k channels, k = 3, plain output'
+        y = _empty((B, N, Cout), dtype=torch.bfloat16, device=x.device)
+        bits = relu_gate if gate_bits else _empty((B, Cout // 32, N), dtype=torch.int32, device=x.device)
+        assert tuple(bits.shape) == (B, Cout // 32, N) and bits.is_contiguous()
+        frag = w_frag if (w_frag is not None and w_frag.dtype == torch.bfloat16 and w_frag.numel() == w_packed.numel()) else None
+        with _probe('conv_gemm', lambda: 2. * B * N * Cin * Cout * taps, N):
+            H.check(H.lib().dx_conv1d_relu_bits(H.ptr(x), x.stride(1), H.ptr(w_packed), H.ptr(frag), H.ptr(bias), H.ptr(y), y.stride(1),
+                                                None if gate_bits else H.ptr(bits), H.ptr(bits) if gate_bits else None,
+                                                H.ptr(mask_lengths), H.ptr(skip_lengths), B, N, Cout, H.stream()))
+        return (y, bits) if relu_bits else y
     if out is None:
         assert not accumulate
         out = _empty((B, Cout, N) if transposed_out else (B, N, Cout), dtype=out_dtype, device=x.device)
