@@ -667,7 +667,12 @@ static int wgrad_nsplit(int B, int N, int Cin, int Cout, int taps) {
   // how fast they finish alone but how little they slow the main stream down.  Measured per training step with the
   // 128 x 128 tiles (B = 48, T <= 1000): 64 -> 10.73 ms, 128 -> 10.46, 160 -> 10.45, 192 -> 10.30, 224 -> 10.35,
   // 256 -> 10.42, 320 -> 10.69; B = 128: 192 -> 22.1, 256 -> 22.5, 384 -> 23.2.  3/4 of the CUs, 8 waves each.
-  const int target = taps == 1 ? 64 : 192;   // k = 1: see launch_wgrad (24: +0.2 ms per step, 96 / 128: +0.02, 192: +0.05)
+  // Round 5 (split counts rounded to multiples of 8, 6.70 ms step): 128 -> +0.02 ms (16 instead of 24 splits of the FF gradients: 0.6 GB fewer
+  // partial tiles, less parallelism), 256 -> +0.13 ms (32 splits).
+#ifndef DX_WG_TARGET
+#define DX_WG_TARGET 192
+#endif
+  const int target = taps == 1 ? 64 : DX_WG_TARGET;   // k = 1: see launch_wgrad (24: +0.2 ms per step, 96 / 128: +0.02, 192: +0.05)
   const int tiles = dx_cdiv(Cout, WG_CO) * dx_cdiv(Cin, WG_CI);
   // every split costs one more partial tile to write and re-read: keep >= ~8 items (64 positions each) per workgroup,
   // 16 for the linear layers (a third of the MFMA work per item)
