@@ -120,6 +120,20 @@ int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_packed, int
                  int Cin, int taps, float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, const void* w_frag,
                  const void* w2_packed, const float* b2, void* y2, int n2, const DxStepScalars* step, void* stream);
 
+/* dx_conv1d_ln whose residual stream is re-derived instead of read (ABI v12).  In an FFT block the residual of the second LayerNorm
+ * is the OUTPUT of the first one, a = mask(LN1(s1)) (model.py:186-191 -> 226-235): with res_mean != NULL `residual` is s1 (the saved
+ * LayerNorm input of the launch that produced the stream), res_mean / res_rstd its row statistics, res_gamma / res_beta that
+ * LayerNorm's parameters, and the epilogue computes  a = (s1 - mean) * rstd * gamma + beta  (0 where n >= lengths[b]) itself -- so
+ * the producing launch may pass y = NULL and store only its bf16 copy and s1: 512 bytes per row less to write.  Split-K path only
+ * (bf16, taps = 3, plan + fragment-order weights, B * N <= 65536); y = NULL is accepted by every path of both entry points as long
+ * as y_lp is given.  res_mean = NULL: identical to dx_conv1d_ln. */
+int dx_conv1d_ln_vres(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const float* bias,
+                      const float* residual, const float* res_mean, const float* res_rstd, const float* res_gamma, const float* res_beta,
+                      const float* gamma, const float* beta, const float* film, long ldf,
+                      const int64_t* lengths, float* y, void* y_lp, float* s_out, float* mean, float* rstd, int B, int N,
+                      int Cin, int taps, float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, const void* w_frag,
+                      const void* w2_packed, const float* b2, void* y2, int n2, const DxStepScalars* step, void* stream);
+
 /* Data gradient of a conv / linear INTO a 128-channel residual stream, fused with the BACKWARD of the LayerNorm that
  * consumed that stream in the forward pass (autograd of model.py:189-191 resp. 226-235 + 259/262, i.e. what
  * dx_conv1d(..., ACCUMULATE) followed by dx_layernorm_bwd compute in two launches and two extra passes over the tensor):

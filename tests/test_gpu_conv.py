@@ -257,3 +257,48 @@ def test_relu_bits_gate_equals_gating_on_the_activation(B, N, Cout, frag):
     a, b = drop_unwritten(d0.float().cpu(), lens.cpu()), drop_unwritten(d1.float().cpu(), lens.cpu())
     assert torch.equal(a[live], b[live]), float((a - b).abs().max())
     assert float(a[live].abs().max()) > 0.
+
+
+@pytest.mark.parametrize('B,N,film', [(4, 515, True), (48, 1000, False), (3, 130, True)])
+def test_ln_fused_gemm_with_rederived_residual_equals_stored_residual(B, N, film):
+    ''' dx_conv1d_ln_vres: the FF LayerNorm-fused GEMM that re-derives its residual a = mask(LN1(s1)) from the saved LayerNorm input and
+        row statistics of the launch that produced the stream gives what the launch reading the stored fp32 `a` gives (same expression in
+        both epilogues: bit-equal), and the producer with store_y = False leaves the same bf16 copy, s1 and statistics '''
+    from daft_exprt import ops
+    from tests.util import drop_unwritten
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(N)
+    bf = torch.bfloat16
+    lens = torch.randint(1, N + 1, (B,), generator=g)
+    lens[0] = N
+    lens = lens.to(dev)
+    o = torch.randn(B, N, 128, generator=g).to(dev).to(bf)
+    x = torch.randn(B, N, 128, generator=g).to(dev)
+    wo = ops.pack_conv_weight((torch.randn(128, 128, generator=g) / 11.).to(dev), bf)
+    g1, b1 = (1. + 0.1 * torch.randn(128, generator=g)).to(dev), (0.1 * torch.randn(128, generator=g)).to(dev)
+    g2, b2 = (1. + 0.1 * torch.randn(128, generator=g)).to(dev), (0.1 * torch.randn(128, generator=g)).to(dev)
+    bo = (0.1 * torch.randn(128, generator=g)).to(dev)
+    kw = dict(save=True, p_pre=0.1, seed_pre=1234, lp_copy=True)
+    a, a_lp, s1, m1, r1 = ops.conv1d_ln(o, wo, bo, x, g1, b1, lens, **kw)
+    n_, a_lp2, s1b, m1b, r1b = ops.conv1d_ln(o, wo, bo, x, g1, b1, lens, store_y=False, **kw)
+    torch.cuda.synchronize()
+    assert n_ is None
+    for p, q in ((a_lp, a_lp2), (s1, s1b), (m1.view(B, N), m1b.view(B, N)), (r1.view(B, N), r1b.view(B, N))):
+        assert torch.equal(drop_unwritten(p.float().cpu(), lens.cpu()), drop_unwritten(q.float().cpu(), lens.cpu()))
+    h = torch.relu(torch.randn(B, N, 1024, generator=g)).to(dev).to(bf)
+    w2 = ops.pack_conv_weight((torch.randn(128, 1024, 3, generator=g) / 55.).to(dev), bf)
+    w2f = ops.pack_frag_major(w2)
+    wq = ops.pack_conv_weight((torch.randn(384, 128, generator=g) / 11.).to(dev), bf)
+    bq = (0.1 * torch.randn(384, generator=g)).to(dev)
+    fl = torch.randn(B, 256, generator=g).to(dev) if film else None
+    plan = ops.conv_tile_plan(lens, N)
+    assert ops.splitk_ln_ok(B, N, bf, w2, plan, w2f)
+    kw2 = dict(film=fl, save=True, p_pre=0.1, seed_pre=77, lp_copy=True, plan=plan, w_frag=w2f, w2_packed=wq, b2=bq)
+    ref = ops.conv1d_ln(h, w2, bo, a, g2, b2, lens, **kw2)
+    got = ops.conv1d_ln(h, w2, bo, s1, g2, b2, lens, residual_ln=(m1, r1, g1, b1), **kw2)
+    torch.cuda.synchronize()
+    assert ref[5] is not None and got[5] is not None
+    for k, (p, q) in enumerate(zip(ref, got)):
+        p, q = (t.view(B, N, -1) if t.dim() == 1 else t for t in (p, q))
+        p, q = drop_unwritten(p.float().cpu(), lens.cpu()), drop_unwritten(q.float().cpu(), lens.cpu())
+        assert torch.equal(p, q), (k, float((p - q).abs().max()))

@@ -39,6 +39,9 @@ struct LNEpi {
   const void* w2; void* y2;   // split-K kernel: y2 = y_lp . w2^T (+ b2), a 128 -> n2 k = 1 GEMM on the rows the epilogue has just produced
   const float* b2; int n2;    // (n2 = 128: output-projection data gradient behind the LayerNorm backward; 384: the next block's QKV projection)
   const DxStepScalars* step;  // NULL, or the device-side step block whose salt is added to seed_pre (captured steps)
+  // "virtual" residual (split-K forward kernel, dx_conv1d_ln_vres): `residual` is the saved INPUT s of the LayerNorm that produced the
+  // residual stream, and the epilogue re-applies that LayerNorm (+ mask) -- its fp32 output then never has to be stored (y = NULL there)
+  const float* res_mean; const float* res_rstd; const float* res_gamma; const float* res_beta;
 };
 
 struct ConvArgs {
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
         const int n = n0 + (c >> 4), cl = (c & 15) * 8;
         if (n >= N) continue;
         const size_t off = ((size_t)b * N + n) * BN + cl;
-        store8<float>(p.ln.y + off, z);
+        if (p.ln.y) store8<float>(p.ln.y + off, z);
         if (p.ln.y_lp) store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + off, z);
         if (p.ln.s_out) store8<float>(p.ln.s_out + off, z);
         if (p.ln.mean && cl == 0) { p.ln.mean[(size_t)b * N + n] = 0.f; p.ln.rstd[(size_t)b * N + n] = 0.f; }
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
             for (int c = ltid; c < cnt * (BN / 8); c += NTHREADS) {
               const int n = first + (c >> 4), cl = (c & 15) * 8;
               const size_t off = ((size_t)fb * N + n) * BN + cl;
-              store8<float>(p.ln.y + off, z);
+              if (LN == 2 || p.ln.y) store8<float>(p.ln.y + off, z);
               if (LN == 2 || p.ln.y_lp) store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + off, z);
               if (LN == 1) {
                 if (p.ln.s_out) store8<float>(p.ln.s_out + off, z);
@@ -637,7 +640,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = 0.f;
             }
-            store8<float>(p.ln.y + offl, v);
+            if (p.ln.y) store8<float>(p.ln.y + offl, v);       // (NULL: the consumer of the fp32 stream re-derives it, LNEpi::res_mean)
             if (p.ln.y_lp) store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + offl, v);
             continue;
           }
@@ -1307,6 +1310,9 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
     if (LN == 1 || LNFILM) bt_h = raw_load8<float>(p.ln.beta + cl_h);
     if (p.ln.film && (LN == 1 || LNFILM)) fg_h = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + cl_h);
     if (p.ln.film && LN == 1) fb_h = raw_load8<float>(p.ln.film + (size_t)b * p.ln.ldf + BN + cl_h);
+    const bool vres = LN == 1 && p.ln.res_mean != nullptr;
+    f32x8 rg_h = gm_h, rb_h = gm_h;
+    if (vres) { rg_h = raw_load8<float>(p.ln.res_gamma + cl_h); rb_h = raw_load8<float>(p.ln.res_beta + cl_h); }
 #pragma unroll
     for (int i = 0; i < MAXBLK / 2; ++i) {
       if (i * 64 >= h) break;                          // workgroup-uniform: the barriers below stay matched
@@ -1329,6 +1335,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
             pf_r[pass] = p.ln.rstd[rowg];
           } else {
             pf_a[pass] = raw_load8<float>(p.ln.residual + offl);
+            if (vres) { pf_m[pass] = p.ln.res_mean[rowg]; pf_r[pass] = p.ln.res_rstd[rowg]; }
           }
         }
       }
@@ -1394,7 +1401,12 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
               for (int e2 = 0; e2 < 8; ++e2) v[e2] = dx_keep_elem(key, (uint32_t)rowg * BN + cl + e2, th) ? v[e2] * sc : 0.f;
             }
             {
-              const f32x8 r = pf_a[pass];
+              f32x8 r = pf_a[pass];
+              if (vres) {   // the residual stream = mask(LayerNorm(s)) of the launch that produced s: same expression as its epilogue
+                const float rm = pf_m[pass], rr = pf_r[pass];
+#pragma unroll
+                for (int e2 = 0; e2 < 8; ++e2) r[e2] = n < len ? (r[e2] - rm) * rr * rg_h[e2] + rb_h[e2] : 0.f;
+              }
 #pragma unroll
               for (int e2 = 0; e2 < 8; ++e2) v[e2] += r[e2];
             }
@@ -1424,7 +1436,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
 #pragma unroll
               for (int e2 = 0; e2 < 8; ++e2) v[e2] = 0.f;
             }
-            store8<float>(p.ln.y + offl, v);
+            if (p.ln.y) store8<float>(p.ln.y + offl, v);
             if (p.ln.y_lp) store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + offl, v);
             if (gemm2) store8<bf16_t>(a2 + sr * A2_LD + cl, v);
           }
@@ -1521,7 +1533,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
         for (int c = tid; c < cntr * (BN / 8); c += SK_THREADS) {
           const int n = first + (c >> 4), cl = (c & 15) * 8;
           const size_t off = ((size_t)fb * N + n) * BN + cl;
-          store8<float>(p.ln.y + off, z);
+          if (LN == 2 || p.ln.y) store8<float>(p.ln.y + off, z);
           if (LN == 2 || p.ln.y_lp) store8<bf16_t>(reinterpret_cast<bf16_t*>(p.ln.y_lp) + off, z);
           if (LN == 1) {
             if (p.ln.s_out) store8<float>(p.ln.s_out + off, z);
@@ -2046,7 +2058,24 @@ extern "C" int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_
                             const int64_t* lengths, float* y, void* y_lp, float* s_out, float* mean, float* rstd, int B, int N,
                             int Cin, int taps, float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, const void* w_frag,
                             const void* w2_packed, const float* b2, void* y2, int n2, const DxStepScalars* step, void* stream) {
-  DX_REQUIRE(x && w_packed && residual && gamma && beta && y, DX_ERR_ARG, "dx_conv1d_ln: null pointer");
+  return dx_conv1d_ln_vres(x, x_dtype, ldx, w_packed, w_dtype, bias, residual, nullptr, nullptr, nullptr, nullptr, gamma, beta, film, ldf, lengths,
+                           y, y_lp, s_out, mean, rstd, B, N, Cin, taps, p_pre, seed_pre, plan, plan_tiles, w_frag, w2_packed, b2, y2, n2, step, stream);
+}
+
+extern "C" int dx_conv1d_ln_vres(const void* x, int x_dtype, long ldx, const void* w_packed, int w_dtype, const float* bias,
+                                 const float* residual, const float* res_mean, const float* res_rstd, const float* res_gamma, const float* res_beta,
+                                 const float* gamma, const float* beta, const float* film, long ldf,
+                                 const int64_t* lengths, float* y, void* y_lp, float* s_out, float* mean, float* rstd, int B, int N,
+                                 int Cin, int taps, float p_pre, uint64_t seed_pre, const int* plan, int plan_tiles, const void* w_frag,
+                                 const void* w2_packed, const float* b2, void* y2, int n2, const DxStepScalars* step, void* stream) {
+  DX_REQUIRE(x && w_packed && residual && gamma && beta && (y || y_lp), DX_ERR_ARG, "dx_conv1d_ln: null pointer");
+  DX_REQUIRE(y || (x_dtype == DX_BF16 && w_dtype == DX_BF16), DX_ERR_ARG, "dx_conv1d_ln: y = NULL (bf16 copy only) goes with bf16 operands");
+  if (res_mean) {
+    DX_REQUIRE(res_rstd && res_gamma && res_beta && lengths, DX_ERR_ARG, "dx_conv1d_ln_vres: res_mean / res_rstd / res_gamma / res_beta / lengths come together");
+    DX_REQUIRE(plan && w_frag && taps == 3 && Cin >= 256 && Cin % 128 == 0 && (long)B * N <= 256L * 256 && w_dtype == DX_BF16 && x_dtype == DX_BF16,
+               DX_ERR_UNSUPPORTED, "dx_conv1d_ln_vres: the re-derived residual exists on the split-K path only (bf16, taps = 3, plan + fragment-order "
+               "weights, Cin %% 128 == 0, B * N <= 65536)");
+  }
   DX_REQUIRE(!w_frag || plan, DX_ERR_ARG, "dx_conv1d_ln: fragment-order weights go with a tile plan");
   if (int rc = plan_check("dx_conv1d_ln", plan, plan_tiles, lengths, x_dtype, w_dtype, ldx, Cin, taps, B, N)) return rc;
   DX_REQUIRE(B > 0 && N > 0 && Cin > 0, DX_ERR_SHAPE, "dx_conv1d_ln: empty shape");
@@ -2057,6 +2086,7 @@ extern "C" int dx_conv1d_ln(const void* x, int x_dtype, long ldx, const void* w_
   ConvArgs a{x, ldx, w_packed, bias, nullptr, BN, nullptr, lengths, lengths, N, Cin, BN, 0, B,
              LNEpi{gamma, beta, residual, film, ldf, y, y_lp, s_out, mean, rstd, p_pre, seed_pre, 1}};
   a.plan = plan; a.plan_tiles = plan_tiles; a.w_frag = w_frag; a.ln.step = step;
+  a.ln.res_mean = res_mean; a.ln.res_rstd = res_rstd; a.ln.res_gamma = res_gamma; a.ln.res_beta = res_beta;
   if (y2) {   // second GEMM in the epilogue (the next block's QKV projection): only the split-K workgroups carry it (gate of launch_taps)
     DX_REQUIRE(w2_packed && (n2 == 128 || n2 == 384) && plan && w_frag && taps == 3 && Cin >= 256 && Cin % 128 == 0 && (long)B * N <= 256L * 256 &&
                w_dtype == DX_BF16 && x_dtype == DX_BF16, DX_ERR_UNSUPPORTED, "dx_conv1d_ln: y2 needs n2 in {128, 384} and the split-K path (bf16, "

@@ -15,6 +15,7 @@ the module attributes they exercise (`ops.USE_SPLITK`, `ops.USE_WIDE`, `ops.USE_
 | DX_SECTIONED_ADAM | auto | per-bucket Adam behind each bucket's all-reduce; auto = only with more than one rank |
 | DX_STEP_GRAPH | 0 | 1 / auto: `Trainer.step` replayed from a hipGraph (`train.CapturedStep`); DX_STEP_GRAPH_MAX (8) graphs kept |
 | DX_RELU_BITS | 1 | 0: the FF data gradient gates on the stored activation `h` instead of the one-bit-per-element mask its forward conv leaves (`dx_conv1d_relu_bits`); same result bit for bit, 2 KB instead of 128 B of gate bytes per row |
+| DX_VIRTUAL_RESIDUAL | 1 | 0: every LayerNorm-fused GEMM stores its fp32 output; 1: in a training FFT block the fp32 copy of the attention sub-layer's output is not stored -- its one reader (the residual add of the FF LayerNorm) re-derives it from the saved LayerNorm input (`dx_conv1d_ln_vres`) |
 | DX_POISON | 0 | 1: every buffer `ops` allocates is filled with NaN before the kernel that writes it runs (tests: no kernel may read rows it was not given) |
 """
 import os
@@ -33,6 +34,7 @@ STEP_GRAPH = os.environ.get('DX_STEP_GRAPH', '0')
 STEP_GRAPH_MAX = int(os.environ.get('DX_STEP_GRAPH_MAX', '8'))
 POISON = _flag('DX_POISON', '0')
 RELU_BITS = _flag('DX_RELU_BITS', '1')
+VIRTUAL_RESIDUAL = _flag('DX_VIRTUAL_RESIDUAL', '1')
 
 
 def force_dist():

@@ -540,10 +540,15 @@ class DaftExprt(nn.Module):
                              out_dtype=cd, skip_lengths=self._skip(lengths))
         o, lse = ops.attention_fwd(qkv, lengths, cfg['attn_nb_heads'], p_attn, seeds[0], need_lse=save, order=self._order(lengths))
         # out-projection + Dropout + residual + LayerNorm + mask in ONE launch (the GEMM tile holds complete 128-ch rows)
+        # (training, bf16, split-K FF kernel: the fp32 copy of `a` has ONE reader, the residual add of the FF LayerNorm, which re-derives it
+        #  from s1 and the row statistics -- ops.conv1d_ln `residual_ln`; `a` itself is then never stored)
+        wc2, plan = W[f'{f_pre}.convs.2.conv.weight'], self._plan(lengths, x.shape[1])
+        virt = bool(save and lp and config.VIRTUAL_RESIDUAL and self._trace is None and plan is not None and
+                    ops.splitk_ln_ok(x.shape[0], x.shape[1], cd, wc2, plan, W.get(f'F:{f_pre}.convs.2.conv.weight')))
         a, a_lp, s1, mean1, rstd1 = ops.conv1d_ln(o, W[f'{a_pre}.multi_head_attention.out_proj.weight'],
                                                   P[f'{a_pre}.multi_head_attention.out_proj.bias'], x, P[f'{a_pre}.layer_norm.weight'],
                                                   P[f'{a_pre}.layer_norm.bias'], lengths, save=save, p_pre=p_attn, seed_pre=seeds[1],
-                                                  lp_copy=lp)
+                                                  lp_copy=lp, store_y=not virt)
         ain = a_lp if lp else a
         # (grouped step: the FF hidden is the one unmasked tensor whose row AT the sequence end reaches valid outputs -- mask it there)
         # (training, bf16: the ReLU also leaves one bit per element -- the gate of the data gradient reads those instead of h, ops.conv1d)
@@ -558,8 +563,9 @@ class DaftExprt(nn.Module):
         # second FF conv + Dropout + residual + LayerNorm + FiLM + mask in ONE launch
         nmha = f'{next_pre}.attention.multi_head_attention' if (next_pre is not None and lp) else None
         u, u_lp, s2, mean2, rstd2, qkv_next = ops.conv1d_ln(
-            h, W[f'{f_pre}.convs.2.conv.weight'], P[f'{f_pre}.convs.2.conv.bias'], a, P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'],
-            lengths, film=film, save=save, p_pre=p_conv, seed_pre=seeds[2], lp_copy=lp, plan=self._plan(lengths, x.shape[1]),
+            h, wc2, P[f'{f_pre}.convs.2.conv.bias'], s1 if virt else a, P[f'{f_pre}.layer_norm.weight'], P[f'{f_pre}.layer_norm.bias'],
+            lengths, film=film, save=save, p_pre=p_conv, seed_pre=seeds[2], lp_copy=lp, plan=plan,
+            residual_ln=(mean1, rstd1, P[f'{a_pre}.layer_norm.weight'], P[f'{a_pre}.layer_norm.bias']) if virt else None,
             w_frag=W.get(f'F:{f_pre}.convs.2.conv.weight'), w2_packed=W[f'{nmha}.in_proj_weight'] if nmha else None,
             b2=P[f'{nmha}.in_proj_bias'] if nmha else None) + ((None,) if nmha is None else ())
         if save:

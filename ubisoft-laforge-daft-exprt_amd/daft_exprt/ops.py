@@ -158,34 +158,51 @@ def conv1d(x, w_packed, bias=None, out_dtype=None, relu=False, relu_gate=None, m
     return out
 
 
+def splitk_ln_ok(B, N, x_dtype, w_packed, plan, w_frag):
+    ''' does conv1d_ln on a (B, N, Cin) input of x_dtype with these weights run on the split-K workgroups (the path that can take
+        `residual_ln`)?  Mirrors the gate of `launch_taps` in csrc/conv_gemm.hip '''
+    Cin = w_packed.shape[2]
+    return (USE_SPLITK and plan is not None and w_frag is not None and x_dtype == torch.bfloat16 and w_packed.dtype == torch.bfloat16
+            and w_packed.shape[0] == 3 and Cin >= 256 and Cin % 128 == 0 and B * N <= 65536 and tuple(plan[1:]) == (B, N))
+
+
 def conv1d_ln(x, w_packed, bias, residual, gamma, beta, lengths, film=None, save=False, p_pre=0., seed_pre=0, lp_copy=False, plan=None,
-              w_frag=None, w2_packed=None, b2=None):
+              w_frag=None, w2_packed=None, b2=None, store_y=True, residual_ln=None):
     ''' conv / linear to 128 channels with the following LayerNorm (+dropout, residual, FiLM, mask) fused into the epilogue.
         plan: conv_tile_plan(lengths, N) of this batch (bf16 k = 3 GEMMs only); w_frag: the weights in fragment order
         (pack_frag_major) -> split-K workgroups on the plan's tiles.  Returns (y, y_lp, s_out, mean, rstd) -- and a sixth element with
         w2_packed (bf16 (1, n2, 128), n2 = 128 or 384; b2 fp32 (n2) or None): y_lp . w2^T + b2 (bf16), the k = 1 projection that reads
-        this output next, from the same launch when the split-K path takes it, else None (the caller launches it) '''
+        this output next, from the same launch when the split-K path takes it, else None (the caller launches it).
+        store_y = False (with lp_copy): the fp32 output is not stored (y = None) -- for a stream whose only fp32 reader re-derives it:
+        residual_ln = (mean, rstd, gamma, beta) of the LayerNorm that produced the residual stream, `residual` then being that
+        LayerNorm's saved INPUT (`splitk_ln_ok` shapes only, see dx_conv1d_ln_vres) '''
     B, N, Cin = x.shape
     taps, Cout, _ = w_packed.shape
     assert Cout == 128 and x.stride(2) == 1 and residual.is_contiguous()
+    assert store_y or lp_copy
     dev = x.device
-    y = _empty((B, N, 128), dtype=torch.float32, device=dev)
+    y = _empty((B, N, 128), dtype=torch.float32, device=dev) if store_y else None
     y_lp = _empty((B, N, 128), dtype=torch.bfloat16, device=dev) if lp_copy else None
     s_out = _empty((B, N, 128), dtype=torch.float32, device=dev) if save else None
     mean = _empty(B * N, dtype=torch.float32, device=dev) if save else None
     rstd = _empty(B * N, dtype=torch.float32, device=dev) if save else None
     pargs = _plan_args(plan, x, w_packed, B, N, w_frag=w_frag)
+    r_mean = r_rstd = r_gamma = r_beta = None
+    if residual_ln is not None:
+        assert splitk_ln_ok(B, N, x.dtype, w_packed, plan, w_frag), 'residual_ln: split-K path only'
+        r_mean, r_rstd, r_gamma, r_beta = residual_ln
     y2, n2 = None, 0
     if (w2_packed is not None and lp_copy and pargs[2] is not None and taps == 3 and Cin % 128 == 0 and B * N <= 65536
             and w2_packed.dtype == torch.bfloat16 and w2_packed.shape[0] == 1 and w2_packed.shape[2] == 128 and w2_packed.shape[1] in (128, 384)):
         n2 = w2_packed.shape[1]
         y2 = _empty((B, N, n2), dtype=torch.bfloat16, device=dev)
     with _probe('conv_gemm', lambda: 2. * B * N * Cin * Cout * taps + 2. * B * N * 128 * n2, N):
-        H.check(H.lib().dx_conv1d_ln(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(bias), H.ptr(residual),
-                                     H.ptr(gamma), H.ptr(beta), H.ptr(film), film.stride(0) if film is not None else 0, H.ptr(lengths),
-                                     H.ptr(y), H.ptr(y_lp), H.ptr(s_out), H.ptr(mean), H.ptr(rstd), B, N, Cin, taps, float(p_pre),
-                                     int(seed_pre), *pargs, H.ptr(w2_packed if y2 is not None else None),
-                                     H.ptr(b2 if y2 is not None else None), H.ptr(y2), n2, STEP_PTR, H.stream()))
+        H.check(H.lib().dx_conv1d_ln_vres(H.ptr(x), H.dt(x), x.stride(1), H.ptr(w_packed), H.dt(w_packed), H.ptr(bias), H.ptr(residual),
+                                          H.ptr(r_mean), H.ptr(r_rstd), H.ptr(r_gamma), H.ptr(r_beta),
+                                          H.ptr(gamma), H.ptr(beta), H.ptr(film), film.stride(0) if film is not None else 0, H.ptr(lengths),
+                                          H.ptr(y), H.ptr(y_lp), H.ptr(s_out), H.ptr(mean), H.ptr(rstd), B, N, Cin, taps, float(p_pre),
+                                          int(seed_pre), *pargs, H.ptr(w2_packed if y2 is not None else None),
+                                          H.ptr(b2 if y2 is not None else None), H.ptr(y2), n2, STEP_PTR, H.stream()))
     if w2_packed is not None:
         return y, y_lp, s_out, mean, rstd, y2
     return y, y_lp, s_out, mean, rstd
