@@ -451,7 +451,7 @@ extern "C" int dx_layernorm_bwd(const void* dy, int dy_dtype, const void* s_in, 
   DX_REQUIRE(B > 0 && N > 0, DX_ERR_SHAPE, "dx_layernorm_bwd: empty shape");
   DX_REQUIRE((film == nullptr) == (dfilm == nullptr), DX_ERR_ARG, "dx_layernorm_bwd: film and dfilm come together");
   // enough workgroups to fill 256 CUs, few enough that the per-channel atomics stay cheap
-  const int maxblk = 768;   // (dx_layernorm_bwd_ws_floats sizes the two-stage workspace for 768; 384 / 256 / 192 measured +0.01 / +0.15 / +0.18 ms per step)
+  const int maxblk = 768;   // (dx_layernorm_bwd_ws_floats sizes the two-stage workspace for 768; 384 / 256 / 192 measured +0.01 / +0.15 / +0.18 ms per step; round 5: 1536 / 3072 for C <= 256 only: +0.06 / +0.06 ms)
   int rpb = 32;
   while (rpb < 1024 && (long)dx_cdiv(N, rpb) * B > maxblk) rpb *= 2;
   LNBwdArgs a{dy, s_in, mean, rstd, gamma, beta, film, ldf, lengths, skip_lengths, ds, dx_pre, dx_pre_lp, dgamma, dbeta, dfilm, lddf, N, B, rpb,
