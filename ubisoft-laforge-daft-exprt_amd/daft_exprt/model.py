@@ -1165,6 +1165,8 @@ class DaftExprt(nn.Module):
         self._plans = {}
         self._hard = {}
         W = self._weights(need_dgrad=False)
+        self._prep(ref_lengths, mel_spec_refs.shape[2])      # tile plans + attention order of a lengths tensor from one launch (as in _forward)
+        self._prep(input_lengths, symbols.shape[1])
         _, films, _ = self._prosody_encoder_fwd(W, energy_refs, pitch_refs, mel_spec_refs, speaker_ids, ref_lengths, False, False)
         enc, _ = self._phoneme_encoder_fwd(W, symbols, films[0], input_lengths, False, False)
         y, _ = self._predictor_fwd(W, enc, films[1], input_lengths, False, False)
@@ -1177,6 +1179,7 @@ class DaftExprt(nn.Module):
             ops.prosody_control(energy, pitch, energy_factors.contiguous(), pitch_factors.contiguous(), dur_int, 1)
         output_lengths = self._last_totals
         T = int(output_lengths.max())   # the one host sync of the synthesis path: sizes the output
+        self._prep(output_lengths, T)
         dec_in, weights, _, _ = self._upsample_fwd(enc, dur, dur_int, energy, pitch, input_lengths, output_lengths, T, False)
         assert dec_in.size(1) == T   # model.py:914
         mel, _ = self._decoder_fwd(W, dec_in, films[2], output_lengths, False, False)
