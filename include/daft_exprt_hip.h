@@ -309,7 +309,7 @@ int dx_length_order(const int64_t* lengths, int B, int* order, void* stream);
  * nfeat (<= 3) device pointers: feat (B, N), w (128, 1, 3), bias (128).  base, pos_table, lengths may be NULL. */
 int dx_scalar_embed_fwd(const float* base, const float* const* feats, const float* const* ws,
                         const float* const* biases, int nfeat, const float* pos_table, const int64_t* lengths,
-                        float* out, void* out_lp /* optional bf16 copy of out, ABI v12 */, int B, int N, int C, void* stream);
+                        float* out, int B, int N, int C, void* stream);
 /* dbase = dout * mask (may be NULL); dws / dbiases are accumulated with atomics. */
 int dx_scalar_embed_bwd(const float* dout, const float* const* feats, int nfeat, const int64_t* lengths,
                         float* dbase, float* const* dws, float* const* dbiases, int B, int N, int C, void* stream);
@@ -317,7 +317,7 @@ int dx_scalar_embed_bwd(const float* dout, const float* const* feats, int nfeat,
 /* ---- K7/K8: out[b, n] = table[ids[b, n]] + pos_table[n] for n < lengths[b], else 0 (model.py:497-504; the
  * positional gather replaces the host loops of PositionalEncoding.forward, model.py:132-150). */
 int dx_embed_pos_fwd(const int64_t* ids, const float* table, const float* pos_table, const int64_t* lengths,
-                     float* out, void* out_lp /* optional bf16 copy of out, ABI v12 */, int B, int N, int C, void* stream);
+                     float* out, int B, int N, int C, void* stream);
 int dx_embed_pos_bwd(const int64_t* ids, const float* dout, const int64_t* lengths, float* dtable, int B, int N, int C,
                      void* stream);
 
@@ -405,8 +405,8 @@ int dx_gu_prepare(const float* enc, const float* dur_float, const float* energy,
                   int C, void* stream);
 int dx_gu_means(const int64_t* durations_int, float* means, int64_t* totals, int B, int L, void* stream);
 int dx_gu_upsample_fwd(const float* xp, const float* ranges, const float* means, const int64_t* in_lengths,
-                       const int64_t* out_lengths, const float* pos_table, float* weights, float* out,
-                       void* out_lp /* optional bf16 copy of out, ABI v12 */, int B, int L, int T, int C, void* stream);
+                       const int64_t* out_lengths, const float* pos_table, float* weights, float* out, int B,
+                       int L, int T, int C, void* stream);
 /* g = grad wrt `out`.  Outputs: dxp (grad wrt xp incl. the range path), drin (grad wrt rin), dr (B, L) grad wrt r_pre.
  * dw_ws (B, L, T) and dsum_ws (B, T) are fp32 workspaces. */
 int dx_gu_upsample_bwd(const float* g, const float* xp, const float* weights, const float* means,

@@ -25,7 +25,6 @@ struct ScalarEmbedArgs {
   const float* pos;           // (max_len, C) or null
   const int64_t* lengths;     // mask (rows n >= len -> 0) or null
   float* out;                 // (B, N, C)
-  bf16_t* out_lp;             // optional bf16 copy of out (MFMA operand of the first FFT block's QKV GEMM and its weight gradient)
   int N;
   long rows;
 };
@@ -48,7 +47,6 @@ __global__ __launch_bounds__(256) void scalar_embed_fwd_kernel(ScalarEmbedArgs a
     if (a.pos) v += a.pos[(long)n * C128 + c];
   }
   a.out[row * C128 + c] = v;
-  if (a.out_lp) a.out_lp[row * C128 + c] = (bf16_t)v;
 }
 
 struct ScalarEmbedBwdArgs {
@@ -110,7 +108,7 @@ __global__ __launch_bounds__(1024) void scalar_embed_bwd_kernel(ScalarEmbedBwdAr
 // ------------------------------------------------------------------ embedding + positional table
 __global__ __launch_bounds__(256) void embed_pos_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
                                                             const float* __restrict__ pos, const int64_t* __restrict__ lengths,
-                                                            float* __restrict__ out, bf16_t* __restrict__ out_lp, int N, long rows) {
+                                                            float* __restrict__ out, int N, long rows) {
   const int c = threadIdx.x & 127;
   const long row = (long)blockIdx.x * 2 + (threadIdx.x >> 7);
   if (row >= rows) return;
@@ -118,7 +116,6 @@ __global__ __launch_bounds__(256) void embed_pos_fwd_kernel(const int64_t* __res
   float v = 0.f;
   if (n < (int)lengths[b]) v = table[ids[row] * C128 + c] + pos[(long)n * C128 + c];
   out[row * C128 + c] = v;
-  if (out_lp) out_lp[row * C128 + c] = (bf16_t)v;
 }
 __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
                                                             const int64_t* __restrict__ lengths, float* __restrict__ dtable,
@@ -434,12 +431,12 @@ __global__ __launch_bounds__(256) void stack_kernel(float* __restrict__ y, Plane
 
 extern "C" int dx_scalar_embed_fwd(const float* base, const float* const* feats, const float* const* ws,
                                    const float* const* biases, int nfeat, const float* pos_table,
-                                   const int64_t* lengths, float* out, void* out_lp, int B, int N, int C, void* stream) {
+                                   const int64_t* lengths, float* out, int B, int N, int C, void* stream) {
   DX_REQUIRE(out && nfeat >= 0 && nfeat <= 3, DX_ERR_ARG, "dx_scalar_embed_fwd: bad arguments");
   DX_REQUIRE(C == C128, DX_ERR_UNSUPPORTED, "dx_scalar_embed_fwd: C=%d (only 128)", C);
   DX_REQUIRE(B > 0 && N > 0, DX_ERR_SHAPE, "dx_scalar_embed_fwd: empty shape");
   ScalarEmbedArgs a{};
-  a.base = base; a.nfeat = nfeat; a.pos = pos_table; a.lengths = lengths; a.out = out; a.out_lp = reinterpret_cast<bf16_t*>(out_lp); a.N = N; a.rows = (long)B * N;
+  a.base = base; a.nfeat = nfeat; a.pos = pos_table; a.lengths = lengths; a.out = out; a.N = N; a.rows = (long)B * N;
   for (int f = 0; f < nfeat; ++f) { a.feat[f] = feats[f]; a.w[f] = ws[f]; a.bias[f] = biases[f]; }
   hipLaunchKernelGGL(scalar_embed_fwd_kernel, dim3((unsigned)((a.rows + 1) / 2)), dim3(256), 0, (hipStream_t)stream, a);
   DX_LAUNCH_CHECK();
@@ -465,12 +462,12 @@ extern "C" int dx_scalar_embed_bwd(const float* dout, const float* const* feats,
 }
 
 extern "C" int dx_embed_pos_fwd(const int64_t* ids, const float* table, const float* pos_table, const int64_t* lengths,
-                                float* out, void* out_lp, int B, int N, int C, void* stream) {
+                                float* out, int B, int N, int C, void* stream) {
   DX_REQUIRE(ids && table && pos_table && lengths && out, DX_ERR_ARG, "dx_embed_pos_fwd: null pointer");
   DX_REQUIRE(C == C128, DX_ERR_UNSUPPORTED, "dx_embed_pos_fwd: C=%d (only 128)", C);
   const long rows = (long)B * N;
   hipLaunchKernelGGL(embed_pos_fwd_kernel, dim3((unsigned)((rows + 1) / 2)), dim3(256), 0, (hipStream_t)stream, ids, table,
-                     pos_table, lengths, out, reinterpret_cast<bf16_t*>(out_lp), N, rows);
+                     pos_table, lengths, out, N, rows);
   DX_LAUNCH_CHECK();
   return DX_OK;
 }

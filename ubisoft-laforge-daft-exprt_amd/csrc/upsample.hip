@@ -88,7 +88,6 @@ struct UpArgs {
   const float* pos;   // positional table or null
   float* weights;     // (B, L, T)
   float* out;         // (B, T, D): (x_up + pos) masked by out_len when pos != null, else raw x_up
-  bf16_t* out_lp;     // optional bf16 copy of out (MFMA operand of the first decoder block)
   int L, T;
 };
 constexpr int TT = 32;   // frames per workgroup
@@ -169,11 +168,6 @@ __global__ __launch_bounds__(256) void gu_upsample_fwd_kernel(UpArgs a) {
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[i] = acc[i];
-    }
-    if (a.out_lp) {
-      bf16_t* ol = a.out_lp + ((long)b * T + t) * D + cg * 16;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) ol[i] = (bf16_t)o[i];
     }
   }
 }
@@ -316,13 +310,13 @@ extern "C" int dx_gu_means(const int64_t* durations_int, float* means, int64_t* 
 }
 
 extern "C" int dx_gu_upsample_fwd(const float* xp, const float* ranges, const float* means, const int64_t* in_lengths,
-                                  const int64_t* out_lengths, const float* pos_table, float* weights, float* out, void* out_lp, int B,
+                                  const int64_t* out_lengths, const float* pos_table, float* weights, float* out, int B,
                                   int L, int T, int C, void* stream) {
   DX_REQUIRE(xp && ranges && means && in_lengths && weights && out, DX_ERR_ARG, "dx_gu_upsample_fwd: null pointer");
   DX_REQUIRE(!pos_table || out_lengths, DX_ERR_ARG, "dx_gu_upsample_fwd: pos_table needs out_lengths");
   DX_REQUIRE(C == D, DX_ERR_UNSUPPORTED, "dx_gu_upsample_fwd: C=%d (only 128)", C);
   DX_REQUIRE(B > 0 && L > 0 && T > 0, DX_ERR_SHAPE, "dx_gu_upsample_fwd: empty shape");
-  UpArgs a{xp, ranges, means, in_lengths, out_lengths, pos_table, weights, out, reinterpret_cast<bf16_t*>(out_lp), L, T};
+  UpArgs a{xp, ranges, means, in_lengths, out_lengths, pos_table, weights, out, L, T};
   hipLaunchKernelGGL(gu_upsample_fwd_kernel, dim3(dx_cdiv(T, TT), B), dim3(256), 0, (hipStream_t)stream, a);
   DX_LAUNCH_CHECK();
   return DX_OK;

@@ -610,16 +610,12 @@ class DaftExprt(nn.Module):
         l1, s.c1 = self._conv_ln_fwd(W, f'{pre}.convs.0', f'{pre}.convs.2', x, p_conv, wide, save, skip=skip)
         l2, s.c2 = self._conv_ln_fwd(W, f'{pre}.convs.4', f'{pre}.convs.6', l1, p_conv, wide, save, skip=skip)
         l3, s.c3 = self._conv_ln_fwd(W, f'{pre}.convs.8', f'{pre}.convs.10', l2, p_conv, torch.float32, save, skip=skip)
-        # (bf16 mode: the kernel that builds a stack's input also leaves its bf16 copy -- block 0 then reads its QKV operand like every other
-        #  block, and its QKV weight gradient joins the out-projection's in the paired ring launch instead of the register-staged kernel)
-        lp = self.cd == torch.bfloat16
         x0 = ops.scalar_embed_fwd([frames_energy, frames_pitch],
                                   [P[f'{pre}.energy_embedding.conv.weight'], P[f'{pre}.pitch_embedding.conv.weight']],
                                   [P[f'{pre}.energy_embedding.conv.bias'], P[f'{pre}.pitch_embedding.conv.bias']],
-                                  base=l3, pos_table=self._pos_table(), lengths=output_lengths, lp_copy=lp)
-        x0, x_lp = x0 if lp else (x0, None)
+                                  base=l3, pos_table=self._pos_table(), lengths=output_lengths)
         s.blocks = []
-        qkv = None
+        x_lp = qkv = None
         for blk in range(cfg['nb_blocks']):
             x0, x_lp, sb, qkv = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x0, None, output_lengths, cfg, train, save, x_lp, qkv,
                                                     f'{pre}.blocks.{blk + 1}' if blk + 1 < cfg['nb_blocks'] else None)
@@ -661,10 +657,8 @@ class DaftExprt(nn.Module):
     def _phoneme_encoder_fwd(self, W, symbols, film, input_lengths, train, save):
         ''' `model.py:490-509` '''
         cfg, pre = self.hp.phoneme_encoder, 'phoneme_encoder'
-        lp = self.cd == torch.bfloat16
-        x = ops.embed_pos_fwd(symbols, self._P[f'{pre}.symbols_embedding.weight'], self._pos_table(), input_lengths, lp_copy=lp)
-        x, x_lp = x if lp else (x, None)
-        blocks, qkv = [], None
+        x = ops.embed_pos_fwd(symbols, self._P[f'{pre}.symbols_embedding.weight'], self._pos_table(), input_lengths)
+        blocks, x_lp, qkv = [], None, None
         for blk in range(cfg['nb_blocks']):
             x, x_lp, sb, qkv = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x, film[:, blk, :], input_lengths, cfg, train, save, x_lp, qkv,
                                                    f'{pre}.blocks.{blk + 1}' if blk + 1 < cfg['nb_blocks'] else None)
@@ -699,10 +693,7 @@ class DaftExprt(nn.Module):
         GP = self._gu_params()
         xp, ranges, r_pre, rin = ops.gu_prepare(enc, durations_float, energies, pitch, input_lengths, GP, save=save)
         means, totals = ops.gu_means(durations_int)
-        lp = self.cd == torch.bfloat16
-        up = ops.gu_upsample_fwd(xp, ranges, means, input_lengths, T, output_lengths, self._pos_table(), lp_copy=lp)
-        dec_in, weights = up[0], up[1]
-        self._dec_in_lp = (dec_in, up[2]) if lp else None      # picked up by _decoder_fwd for this very tensor
+        dec_in, weights = ops.gu_upsample_fwd(xp, ranges, means, input_lengths, T, output_lengths, self._pos_table())
         s = None
         if save:
             s = _Saved()
@@ -713,9 +704,7 @@ class DaftExprt(nn.Module):
     def _decoder_fwd(self, W, x, film, output_lengths, train, save):
         ''' `model.py:689-710` (positional add + mask already applied by the upsampling kernel) '''
         cfg, pre, P = self.hp.frame_decoder, 'frame_decoder', self._P
-        hit = getattr(self, '_dec_in_lp', None)
-        blocks, x_lp, qkv = [], (hit[1] if (hit is not None and hit[0] is x) else None), None
-        self._dec_in_lp = None
+        blocks, x_lp, qkv = [], None, None
         for blk in range(cfg['nb_blocks']):
             x, x_lp, sb, qkv = self._fft_block_fwd(W, f'{pre}.blocks.{blk}', x, film[:, blk, :], output_lengths, cfg, train, save, x_lp, qkv,
                                                    f'{pre}.blocks.{blk + 1}' if blk + 1 < cfg['nb_blocks'] else None)

@@ -499,15 +499,13 @@ def attention_bwd(qkv, o, d_o, lse, lengths, nb_heads, p_drop=0., seed=0, order=
 
 
 # ----------------------------------------------------------------------------- pointwise / small heads
-def scalar_embed_fwd(feats, ws, biases, base=None, pos_table=None, lengths=None, lp_copy=False):
-    ''' lp_copy: also a bf16 copy of the result (returns (out, out_lp)): the operand of the first FFT block's QKV GEMM and weight gradient '''
+def scalar_embed_fwd(feats, ws, biases, base=None, pos_table=None, lengths=None):
     B, N = feats[0].shape
     C = ws[0].shape[0]
     out = _empty((B, N, C), dtype=torch.float32, device=feats[0].device)
-    out_lp = _empty((B, N, C), dtype=torch.bfloat16, device=feats[0].device) if lp_copy else None
     H.check(H.lib().dx_scalar_embed_fwd(H.ptr(base), _ptr_array(feats), _ptr_array(ws), _ptr_array(biases), len(feats),
-                                        H.ptr(pos_table), H.ptr(lengths), H.ptr(out), H.ptr(out_lp), B, N, C, H.stream()))
-    return (out, out_lp) if lp_copy else out
+                                        H.ptr(pos_table), H.ptr(lengths), H.ptr(out), B, N, C, H.stream()))
+    return out
 
 
 def scalar_embed_bwd(dout, feats, dws, dbiases, lengths=None, need_dbase=False):
@@ -518,14 +516,13 @@ def scalar_embed_bwd(dout, feats, dws, dbiases, lengths=None, need_dbase=False):
     return dbase
 
 
-def embed_pos_fwd(ids, table, pos_table, lengths, lp_copy=False):
+def embed_pos_fwd(ids, table, pos_table, lengths):
     B, N = ids.shape
     C = table.shape[1]
     assert pos_table.shape[1] == C and table.is_contiguous() and pos_table.is_contiguous()
     out = _empty((B, N, C), dtype=torch.float32, device=ids.device)
-    out_lp = _empty((B, N, C), dtype=torch.bfloat16, device=ids.device) if lp_copy else None
-    H.check(H.lib().dx_embed_pos_fwd(H.ptr(ids), H.ptr(table), H.ptr(pos_table), H.ptr(lengths), H.ptr(out), H.ptr(out_lp), B, N, C, H.stream()))
-    return (out, out_lp) if lp_copy else out
+    H.check(H.lib().dx_embed_pos_fwd(H.ptr(ids), H.ptr(table), H.ptr(pos_table), H.ptr(lengths), H.ptr(out), B, N, C, H.stream()))
+    return out
 
 
 def embed_pos_bwd(ids, dout, lengths, dtable):
@@ -716,15 +713,13 @@ def gu_means(durations_int):
     return means, totals
 
 
-def gu_upsample_fwd(xp, ranges, means, in_lengths, T, out_lengths=None, pos_table=None, lp_copy=False):
-    ''' returns (out, weights) -- (out, weights, out_lp) with lp_copy (bf16 copy of out for the first decoder block) '''
+def gu_upsample_fwd(xp, ranges, means, in_lengths, T, out_lengths=None, pos_table=None):
     B, L, C = xp.shape
     weights = _empty((B, L, T), dtype=torch.float32, device=xp.device)
     out = _empty((B, T, C), dtype=torch.float32, device=xp.device)
-    out_lp = _empty((B, T, C), dtype=torch.bfloat16, device=xp.device) if lp_copy else None
     H.check(H.lib().dx_gu_upsample_fwd(H.ptr(xp), H.ptr(ranges), H.ptr(means), H.ptr(in_lengths), H.ptr(out_lengths),
-                                       H.ptr(pos_table), H.ptr(weights), H.ptr(out), H.ptr(out_lp), B, L, T, C, H.stream()))
-    return (out, weights, out_lp) if lp_copy else (out, weights)
+                                       H.ptr(pos_table), H.ptr(weights), H.ptr(out), B, L, T, C, H.stream()))
+    return out, weights
 
 
 def gu_upsample_bwd(g, xp, weights, means, ranges, r_pre, w_range, in_lengths, out_lengths):
