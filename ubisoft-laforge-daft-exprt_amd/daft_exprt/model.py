@@ -201,6 +201,12 @@ class DaftExprt(nn.Module):
         self._plans = {}
         self._hard = {}
         self.attn_lpt = True           # see _order
+        # the local prosody predictor beside the decoder: in a teacher-forced step its forward feeds nothing but the loss and its backward
+        # needs nothing but the loss gradients, so both run on the weight-gradient stream (idle in the forward pass, a FIFO of launches
+        # that nobody waits for in the backward pass) while the launch stream goes on with upsampling and decoder -- ~30 phoneme-level
+        # launches of 5-20 us off the critical path.  False: in line, as before (tests compare the two)
+        self.overlap_predictor = True
+        self._pp_ev = None
         self._step_id, self._site, self._rank, self._capture_step0 = 0, 0, 0, 0
         self._seed_log = None
         self._trace = None    # tests set this to a list: every stage appends (kind, names, input, film, lengths, output)
@@ -733,16 +739,55 @@ class DaftExprt(nn.Module):
         emb, films, s_pe = self._prosody_encoder_fwd(W, frames_energy, frames_pitch, mel_specs, speaker_ids, output_lengths, train, save)
         logits, s_cls = self._classifier_fwd(emb)
         enc, s_enc = self._phoneme_encoder_fwd(W, symbols, films[0], input_lengths, train, save)
-        y, s_pp = self._predictor_fwd(W, enc, films[1], input_lengths, train, save)
+        beside = self._predictor_beside()
+        if beside:
+            main, side = torch.cuda.current_stream(), self.ensure_side_stream()
+            self._pp_ev[0].record(main)
+            side.wait_event(self._pp_ev[0])
+            with torch.cuda.stream(side):
+                y, s_pp = self._predictor_fwd(W, enc, films[1], input_lengths, train, save)
+                self._pp_ev[1].record(side)
+        else:
+            y, s_pp = self._predictor_fwd(W, enc, films[1], input_lengths, train, save)
         T = mel_specs.shape[2]
         dec_in, weights, _, s_gu = self._upsample_fwd(enc, durations_float, durations_int, symbols_energy, symbols_pitch,
                                                       input_lengths, output_lengths, T, save)
         mel, s_dec = self._decoder_fwd(W, dec_in, films[2], output_lengths, train, save)
+        if beside:
+            main.wait_event(self._pp_ev[1])
         dur, energy, pitch = ops.unstack(y, 3)
         if save:
             S.pe, S.cls, S.enc, S.pp, S.gu, S.dec, S.films, S.symbols, S.input_lengths, S.enc_out, S.x_mel = \
                 s_pe, s_cls, s_enc, s_pp, s_gu, s_dec, films, symbols, input_lengths, enc, mel_specs
         return (logits, films, (dur, energy, pitch), mel, weights), S
+
+    def _predictor_beside(self):
+        ''' may the predictor run on the weight-gradient stream beside the launch stream (see `overlap_predictor`)?  Not while a step is
+            being captured (the capture's fork bookkeeping is `_flush_wgrads`'s), not under a stage trace, not without that stream '''
+        ok = bool(self.overlap_predictor and config.WGRAD_SIDE_STREAM and ops.STEP_PTR is None and self._trace is None and
+                  self._trace_bwd is None and self._flat is not None and self._flat.is_cuda)
+        if ok and self._pp_ev is None:
+            self._pp_ev = [torch.cuda.Event() for _ in range(4)]
+        return ok
+
+    def _predictor_bwd(self, W, S, d_dur, d_energy, d_pitch, dfilm_pp, d_enc):
+        ''' backward of the local prosody predictor (`model.py:549-575`): parameter gradients, FiLM gradients into dfilm_pp; the gradient
+            wrt the encoder output is accumulated into d_enc when given, else returned '''
+        P, G = self._P, self._G
+        saved_pp, pp_x, pp_y = S.pp
+        L = S.symbols.shape[1]
+        dy = ops.stack([d_dur.float().contiguous(), d_energy.float().contiguous(), d_pitch.float().contiguous()])
+        ppn = 'prosody_predictor'
+        dx = ops.linear_small_bwd(dy, None, pp_x, P[f'{ppn}.projection.linear_layer.weight'],
+                                  G[f'{ppn}.projection.linear_layer.weight'], G[f'{ppn}.projection.linear_layer.bias'],
+                                  mask_lengths=S.input_lengths, N=L)
+        for blk in reversed(range(len(saved_pp))):
+            s1, s2 = saved_pp[blk]
+            dx = self._conv_ln_bwd(W, s2, dx, dfilm=dfilm_pp[:, blk, :])
+            if blk == 0 and d_enc is not None:
+                return self._conv_ln_bwd(W, s1, dx, dx_out=d_enc)
+            dx = self._conv_ln_bwd(W, s1, dx)
+        return dx
 
     # ------------------------------------------------------------------ backward building blocks
     def _wgrad(self, dy, x, dw, db, lengths=None):
@@ -973,6 +1018,16 @@ class DaftExprt(nn.Module):
         sizes = [B * nb * 2 * ch for nb, ch in layout]                  # the FiLM gradient accumulators of the three stacks: one buffer, one fill
         dfilm_all = zeros(sum(sizes))
         dfilms = [v.view(B, nb, 2 * ch) for v, (nb, ch) in zip(torch.split(dfilm_all, sizes), layout)]
+        # ---- local prosody predictor, on the weight-gradient stream beside everything up to the phoneme encoder (see `overlap_predictor`)
+        d_enc_pp, beside = None, d_dur is not None and self._side_stream is not None and self._predictor_beside()
+        if beside:
+            main, side = torch.cuda.current_stream(), self._side_stream
+            self._pp_ev[2].record(main)                                 # the loss gradients and the zeroed FiLM accumulators are in place
+            side.wait_event(self._pp_ev[2])
+            with torch.cuda.stream(side):
+                d_enc_pp = self._predictor_bwd(W, S, d_dur, d_energy, d_pitch, dfilms[1], None)
+                self._pp_ev[3].record(side)
+            self._wgrad_keep.append(d_enc_pp)                           # (read by the launch stream: stays allocated until the streams have joined)
         # ---- decoder
         blocks, dec_x = S.dec
         pre = 'frame_decoder'
@@ -1002,20 +1057,11 @@ class DaftExprt(nn.Module):
         d_enc = dxp
         done('gaussian_upsampling')
         # ---- local prosody predictor
-        saved_pp, pp_x, pp_y = S.pp
-        if d_dur is not None:
-            dy = ops.stack([d_dur.float().contiguous(), d_energy.float().contiguous(), d_pitch.float().contiguous()])
-            ppn = 'prosody_predictor'
-            dx = ops.linear_small_bwd(dy, None, pp_x, P[f'{ppn}.projection.linear_layer.weight'],
-                                      G[f'{ppn}.projection.linear_layer.weight'], G[f'{ppn}.projection.linear_layer.bias'],
-                                      mask_lengths=S.input_lengths, N=L)
-            for blk in reversed(range(len(saved_pp))):
-                s1, s2 = saved_pp[blk]
-                dx = self._conv_ln_bwd(W, s2, dx, dfilm=dfilms[1][:, blk, :])
-                if blk == 0:
-                    self._conv_ln_bwd(W, s1, dx, dx_out=d_enc)
-                else:
-                    dx = self._conv_ln_bwd(W, s1, dx)
+        if beside:
+            main.wait_event(self._pp_ev[3])
+            ops.add_(d_enc, d_enc_pp)
+        elif d_dur is not None:
+            self._predictor_bwd(W, S, d_dur, d_energy, d_pitch, dfilms[1], d_enc)
         done('prosody_predictor')
         # ---- phoneme encoder
         d_enc = self._fft_stack_bwd(W, S.enc, d_enc, dfilms[0])
