@@ -203,8 +203,10 @@ class DaftExprt(nn.Module):
         self.attn_lpt = True           # see _order
         # the local prosody predictor beside the decoder: in a teacher-forced step its forward feeds nothing but the loss and its backward
         # needs nothing but the loss gradients, so both run on the weight-gradient stream (idle in the forward pass, a FIFO of launches
-        # that nobody waits for in the backward pass) while the launch stream goes on with upsampling and decoder -- ~30 phoneme-level
-        # launches of 5-20 us off the critical path.  False: in line, as before (tests compare the two)
+        # that nobody waits for in the backward pass) while the launch stream goes on with upsampling and decoder.  The same holds for
+        # the speaker classifier (forward and backward) and for the launches of the backward pass that only produce parameter gradients
+        # (Gaussian upsampling's three, the symbol embedding's): ~45 launches of 5-30 us off the critical path, 6.51 -> 6.34 ms per
+        # step.  False: everything in line, as before (tests compare the two)
         self.overlap_predictor = True
         self._pp_ev = None
         self._step_id, self._site, self._rank, self._capture_step0 = 0, 0, 0, 0
@@ -737,11 +739,17 @@ class DaftExprt(nn.Module):
         W = self._weights(need_dgrad=save)
         S = _Saved() if save else None
         emb, films, s_pe = self._prosody_encoder_fwd(W, frames_energy, frames_pitch, mel_specs, speaker_ids, output_lengths, train, save)
-        logits, s_cls = self._classifier_fwd(emb)
-        enc, s_enc = self._phoneme_encoder_fwd(W, symbols, films[0], input_lengths, train, save)
         beside = self._predictor_beside()
-        if beside:
+        if beside:      # the speaker classifier feeds nothing but the loss either: the launch stream waits for it together with the predictor
             main, side = torch.cuda.current_stream(), self.ensure_side_stream()
+            self._pp_ev[7].record(main)
+            side.wait_event(self._pp_ev[7])
+            with torch.cuda.stream(side):
+                logits, s_cls = self._classifier_fwd(emb)
+        else:
+            logits, s_cls = self._classifier_fwd(emb)
+        enc, s_enc = self._phoneme_encoder_fwd(W, symbols, films[0], input_lengths, train, save)
+        if beside:
             self._pp_ev[0].record(main)
             side.wait_event(self._pp_ev[0])
             with torch.cuda.stream(side):
@@ -767,8 +775,30 @@ class DaftExprt(nn.Module):
         ok = bool(self.overlap_predictor and config.WGRAD_SIDE_STREAM and ops.STEP_PTR is None and self._trace is None and
                   self._trace_bwd is None and self._flat is not None and self._flat.is_cuda)
         if ok and self._pp_ev is None:
-            self._pp_ev = [torch.cuda.Event() for _ in range(4)]
+            self._pp_ev = [torch.cuda.Event() for _ in range(8)]
         return ok
+
+    def _classifier_bwd(self, S, d_spk, zeros):
+        ''' backward of the speaker classifier behind the gradient reversal (`model.py:27-38, 285-292`): parameter gradients; returns
+            d_emb = -lambda dL/d(classifier input) (zeros without a speaker loss) '''
+        hp, P, G = self.hp, self._P, self._G
+        emb, h1, h2 = S.cls
+        cl = 'speaker_classifier.classifier'
+        if d_spk is not None and self._fused_classifier():
+            d_emb = ops.classifier_bwd(d_spk.contiguous(), emb, h1, h2, P[f'{cl}.1.linear_layer.weight'], P[f'{cl}.3.linear_layer.weight'],
+                                       P[f'{cl}.5.linear_layer.weight'], float(hp.lambda_reversal), G[f'{cl}.1.linear_layer.weight'],
+                                       G[f'{cl}.1.linear_layer.bias'], G[f'{cl}.3.linear_layer.weight'], G[f'{cl}.3.linear_layer.bias'],
+                                       G[f'{cl}.5.linear_layer.weight'], G[f'{cl}.5.linear_layer.bias'])
+        elif d_spk is not None:
+            d_h2 = ops.linear_small_bwd(d_spk.contiguous(), None, h2, P[f'{cl}.5.linear_layer.weight'], G[f'{cl}.5.linear_layer.weight'],
+                                        G[f'{cl}.5.linear_layer.bias'])
+            d_h1 = ops.linear_small_bwd(d_h2, h2, h1, P[f'{cl}.3.linear_layer.weight'], G[f'{cl}.3.linear_layer.weight'],
+                                        G[f'{cl}.3.linear_layer.bias'], relu=True)
+            d_emb = ops.linear_small_bwd(d_h1, h1, emb, P[f'{cl}.1.linear_layer.weight'], G[f'{cl}.1.linear_layer.weight'],
+                                         G[f'{cl}.1.linear_layer.bias'], relu=True, dx_scale=-float(hp.lambda_reversal))
+        else:
+            d_emb = zeros(*emb.shape)
+        return d_emb
 
     def _predictor_bwd(self, W, S, d_dur, d_energy, d_pitch, dfilm_pp, d_enc):
         ''' backward of the local prosody predictor (`model.py:549-575`): parameter gradients, FiLM gradients into dfilm_pp; the gradient
@@ -1027,7 +1057,10 @@ class DaftExprt(nn.Module):
             with torch.cuda.stream(side):
                 d_enc_pp = self._predictor_bwd(W, S, d_dur, d_energy, d_pitch, dfilms[1], None)
                 self._pp_ev[3].record(side)
-            self._wgrad_keep.append(d_enc_pp)                           # (read by the launch stream: stays allocated until the streams have joined)
+                # the speaker classifier's backward needs the loss gradient only as well (its d_emb is consumed by the FiLM head far below)
+                d_emb_side = self._classifier_bwd(S, d_spk, zeros)
+                self._pp_ev[4].record(side)
+            self._wgrad_keep.append((d_enc_pp, d_emb_side))             # (read by the launch stream: stay allocated until the streams have joined)
         # ---- decoder
         blocks, dec_x = S.dec
         pre = 'frame_decoder'
@@ -1047,44 +1080,50 @@ class DaftExprt(nn.Module):
         dxp, drin, dr = ops.gu_upsample_bwd(d_dec, g.xp, g.weights, g.means, g.ranges, g.r_pre, GP['w_range'], g.input_lengths,
                                             g.output_lengths)
         gu = 'gaussian_upsampling'
-        ops.linear_small_bwd(dr.unsqueeze(2), None, g.rin, GP['w_range'], G[f'{gu}.projection.0.linear_layer.weight'],
-                             G[f'{gu}.projection.0.linear_layer.bias'], need_dx=False)
-        ops.scalar_embed_bwd(drin, [g.durations_float], [G[f'{gu}.duration_projection.conv.weight']],
-                             [G[f'{gu}.duration_projection.conv.bias']])
-        ops.scalar_embed_bwd(dxp, [g.energies, g.pitch],
-                             [G[f'{gu}.energy_projection.conv.weight'], G[f'{gu}.pitch_projection.conv.weight']],
-                             [G[f'{gu}.energy_projection.conv.bias'], G[f'{gu}.pitch_projection.conv.bias']])
+
+        def gu_param_grads():        # three launches that produce parameter gradients only: nothing downstream waits for them
+            ops.linear_small_bwd(dr.unsqueeze(2), None, g.rin, GP['w_range'], G[f'{gu}.projection.0.linear_layer.weight'],
+                                 G[f'{gu}.projection.0.linear_layer.bias'], need_dx=False)
+            ops.scalar_embed_bwd(drin, [g.durations_float], [G[f'{gu}.duration_projection.conv.weight']],
+                                 [G[f'{gu}.duration_projection.conv.bias']])
+            ops.scalar_embed_bwd(dxp, [g.energies, g.pitch],
+                                 [G[f'{gu}.energy_projection.conv.weight'], G[f'{gu}.pitch_projection.conv.weight']],
+                                 [G[f'{gu}.energy_projection.conv.bias'], G[f'{gu}.pitch_projection.conv.bias']])
+        if beside:
+            self._pp_ev[5].record(main)
+            side.wait_event(self._pp_ev[5])
+            with torch.cuda.stream(side):
+                gu_param_grads()
+            self._wgrad_keep.append((dxp, drin, dr))                    # read on the side stream; dxp is NOT modified below (the sum goes into d_enc_pp)
+        else:
+            gu_param_grads()
         d_enc = dxp
         done('gaussian_upsampling')
         # ---- local prosody predictor
         if beside:
             main.wait_event(self._pp_ev[3])
-            ops.add_(d_enc, d_enc_pp)
+            d_enc = ops.add_(d_enc_pp, dxp)                             # (into the predictor's buffer: the side stream may still be reading dxp)
         elif d_dur is not None:
             self._predictor_bwd(W, S, d_dur, d_energy, d_pitch, dfilms[1], d_enc)
         done('prosody_predictor')
         # ---- phoneme encoder
         d_enc = self._fft_stack_bwd(W, S.enc, d_enc, dfilms[0])
-        ops.embed_pos_bwd(S.symbols, d_enc, S.input_lengths, G['phoneme_encoder.symbols_embedding.weight'])
+        if beside:                                                      # a parameter gradient only: side stream
+            self._pp_ev[6].record(main)
+            side.wait_event(self._pp_ev[6])
+            with torch.cuda.stream(side):
+                ops.embed_pos_bwd(S.symbols, d_enc, S.input_lengths, G['phoneme_encoder.symbols_embedding.weight'])
+            self._wgrad_keep.append(d_enc)
+        else:
+            ops.embed_pos_bwd(S.symbols, d_enc, S.input_lengths, G['phoneme_encoder.symbols_embedding.weight'])
         done('phoneme_encoder')
         # ---- speaker classifier (+ gradient reversal, model.py:27-38)
         pe = S.pe
-        emb, h1, h2 = S.cls
-        cl = 'speaker_classifier.classifier'
-        if d_spk is not None and self._fused_classifier():
-            d_emb = ops.classifier_bwd(d_spk.contiguous(), emb, h1, h2, P[f'{cl}.1.linear_layer.weight'], P[f'{cl}.3.linear_layer.weight'],
-                                       P[f'{cl}.5.linear_layer.weight'], float(hp.lambda_reversal), G[f'{cl}.1.linear_layer.weight'],
-                                       G[f'{cl}.1.linear_layer.bias'], G[f'{cl}.3.linear_layer.weight'], G[f'{cl}.3.linear_layer.bias'],
-                                       G[f'{cl}.5.linear_layer.weight'], G[f'{cl}.5.linear_layer.bias'])
-        elif d_spk is not None:
-            d_h2 = ops.linear_small_bwd(d_spk.contiguous(), None, h2, P[f'{cl}.5.linear_layer.weight'], G[f'{cl}.5.linear_layer.weight'],
-                                        G[f'{cl}.5.linear_layer.bias'])
-            d_h1 = ops.linear_small_bwd(d_h2, h2, h1, P[f'{cl}.3.linear_layer.weight'], G[f'{cl}.3.linear_layer.weight'],
-                                        G[f'{cl}.3.linear_layer.bias'], relu=True)
-            d_emb = ops.linear_small_bwd(d_h1, h1, emb, P[f'{cl}.1.linear_layer.weight'], G[f'{cl}.1.linear_layer.weight'],
-                                         G[f'{cl}.1.linear_layer.bias'], relu=True, dx_scale=-float(hp.lambda_reversal))
+        if beside:
+            main.wait_event(self._pp_ev[4])
+            d_emb = d_emb_side
         else:
-            d_emb = zeros(*emb.shape)
+            d_emb = self._classifier_bwd(S, d_spk, zeros)
         done('speaker_classifier')
         # ---- FiLM head
         pre = 'prosody_encoder'
