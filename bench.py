@@ -358,7 +358,7 @@ def train_loop_bench(args, hp):
                       'roofline': None, 'cpu_baseline': None}))
 
 
-def secondary_train(dev, batch, accum, dtype, steps, warmup, pool=4, group=True):
+def secondary_train(dev, batch, accum, dtype, steps, warmup, pool=4, group=True, t_min=1, probe=0):
     ''' a second timing of the SAME train step under another schedule / arithmetic, reported as an extra object of the default line:
         `batch` utterances per micro-batch x `accum` micro-batches per optimizer step (the reference's own default is 16 x 3,
         hparams.py:66-67, README.md:180), operands `dtype` (fp32 = the exact-parity mode on v_mfma_f32_32x32x2_f32, peak 157.3 TFLOP/s).
@@ -381,7 +381,7 @@ def secondary_train(dev, batch, accum, dtype, steps, warmup, pool=4, group=True)
     for i in range(pool):
         micro = []
         for a in range(accum):
-            cb = synthetic_batch(hp, batch, seed=4321 + 1000 * i + 37 * a, t_min=1, t_max=1000, force_first_full=(a == 0))
+            cb = synthetic_batch(hp, batch, seed=4321 + 1000 * i + 37 * a, t_min=t_min, t_max=1000, force_first_full=(a == 0))
             inputs, targets, _ = model.parse_batch(dev, cb)
             micro.append((inputs, targets))
         groups.append(micro)
@@ -401,9 +401,25 @@ def secondary_train(dev, batch, accum, dtype, steps, warmup, pool=4, group=True)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     peak = PEAK_MFMA_BF16 if dtype == 'bf16' else 157.3e12
+    families = None
+    if probe and accum == 1:      # per-family HIP-event timing over `probe` extra (untimed) steps, as the headline's roofline object
+        from daft_exprt import ops
+        ops.PROBE = {}
+        for k in range(probe):
+            trainer.step(groups[k % pool], it + k)
+        torch.cuda.synchronize()
+        fam = {name: (sum(s_.elapsed_time(e_) for s_, e_, _, _ in recs), recs) for name, recs in ops.PROBE.items()}
+        ops.PROBE = None
+
+        def valid_frac(k, n_axis):
+            inp = groups[k % pool][0][0]
+            Tm, Lm = int(inp[8].shape[2]), int(inp[0].shape[1])
+            return float(inp[9].sum()) / (inp[9].numel() * Tm) if n_axis == Tm else float(inp[5].sum()) / (inp[5].numel() * Lm)
+        families = family_tables(fam, probe, valid_frac, peak)
     del trainer, model, groups
     torch.cuda.empty_cache()
-    return {'value': done_frames / elapsed, 'unit': 'mel-frames/s', 'ms_per_step': elapsed / steps * 1e3, 'steps': steps, 'warmup': warmup,
+    extra = {'families': families} if families is not None else {}
+    return {**extra, 'value': done_frames / elapsed, 'unit': 'mel-frames/s', 'ms_per_step': elapsed / steps * 1e3, 'steps': steps, 'warmup': warmup,
             'dtype': dtype, 'batch_size': batch, 'accumulation_steps': accum, 'utterances_per_optimizer_step': batch * accum,
             'valid_frames_per_step': done_frames / steps, 'grouped_micro_batches': bool(group and accum > 1),
             'whole_step': {'achieved': done_flops / elapsed / 1e12, 'unit': 'TFLOP/s (algorithmic 3*F_fwd)', 'peak': peak / 1e12,
@@ -518,6 +534,8 @@ def main():
     for w in range(args.warmup):
         trainer.step([batches[w % args.pool]], it + w)
     torch.cuda.synchronize()
+    if dist_on:
+        trainer.diag = []          # per step: (event behind the last backward kernel, event behind the last all-reduce), see the stderr line below
     barrier()
     t0 = time.perf_counter()
     done_frames, done_flops = 0, 0.
@@ -528,6 +546,22 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    if dist_on:
+        # per-rank diagnostics of the FIRST multi-GPU record: the imbalance term of the scaling prediction (this rank's padded
+        # sizes and valid frames: a rank whose T_max is larger runs a longer step and everyone waits for it in the collective) and the
+        # communication the backward pass did not hide (event behind the last backward kernel -> event behind the last all-reduce)
+        exposed = []
+        for e0, e1 in (trainer.diag or []):
+            try:
+                exposed.append(e0.elapsed_time(e1))
+            except Exception:   # noqa: BLE001
+                pass
+        trainer.diag = None
+        exposed.sort()
+        shapes = ', '.join(f'T_max {int(b[0][8].shape[2])} L_max {int(b[0][0].shape[1])} frames {f}' for b, f in zip(batches, frames))
+        print(f'[bench rank {rank}/{world}] local step {elapsed / args.steps * 1e3:.3f} ms; batches: {shapes}; last backward kernel -> end of the '
+              f'last all-reduce: median {exposed[len(exposed) // 2] if exposed else float("nan"):.3f} ms, max {exposed[-1] if exposed else float("nan"):.3f} ms '
+              f'over {len(exposed)} steps (negative = the collectives ended under the backward pass)', file=sys.stderr, flush=True)
     stats = torch.tensor([elapsed, float(done_frames), done_flops], dtype=torch.float64, device=dev)
     if dist_on:
         tmax = stats[:1].clone()
@@ -574,6 +608,17 @@ def main():
                     'whole_step': {'achieved': done_flops / elapsed / world / 1e12, 'unit': 'TFLOP/s per GPU (algorithmic 3*F_fwd)',
                                    'frac': done_flops / elapsed / world / peak},
                     'hbm': hbm_line(elapsed / args.steps * 1e3) if c2 else None}
+        if roofline['hbm'] and roofline['hbm'].get('bytes_per_step'):
+            # SURVEY 8d "algorithmic bytes (secondary)": inputs 328 B + mel out 320 B + alignments 4 L B per valid frame, parameters + Adam
+            # 28 B x params per optimizer step; DESIGN 4a adds what a training step must keep for its backward pass
+            fr, params = done_frames / args.steps / world, model.n_params
+            io = fr * (328 + 320) + sum(float((b[0][9] * b[0][5]).sum()) * 4. for b in batches) / len(batches)
+            alg = io + 28. * params
+            roofline['hbm']['algorithmic_bytes'] = {'io_plus_adam_bytes_per_step': alg, 'traffic_ratio': roofline['hbm']['bytes_per_step'] / alg,
+                                                    'with_saved_activations_bytes_per_step': alg + 2. * 28e3 * fr,
+                                                    'traffic_ratio_with_saved_activations': roofline['hbm']['bytes_per_step'] / (alg + 2. * 28e3 * fr),
+                                                    'note': 'SURVEY 8d: 328 + 320 + 4 L bytes per valid frame + 28 B x parameters (Adam); second '
+                                                            'figure adds ~28 KB per frame of saved activations written and read once (DESIGN 4a)'}
 
     if rank == 0:
         cpu = None
@@ -599,6 +644,10 @@ def main():
             seq = secondary_train(dev, 16, 3, 'bf16', steps=10, warmup=5, group=False)
             out['train_16x3']['sequential_passes'] = {k: seq[k] for k in ('value', 'ms_per_step', 'whole_step')}
             out['fp32'] = secondary_train(dev, 48, 1, 'fp32', steps=6, warmup=4)
+            # BASELINE configs[4] (C5): batch 256, 500 <= T <= 1000, adversarial classifier + gradient reversal live (iteration >= 10000)
+            out['c5'] = secondary_train(dev, 256, 1, 'bf16', steps=10, warmup=8, pool=2, t_min=500, probe=2)
+            out['c5']['workload'] = ('BASELINE configs[4]: long-utterance stress, batch 256, 500<=T<=1000 (utterance 0 = 1000 frames), 11 speakers, '
+                                     'adversarial speaker classifier + gradient reversal at full weight, full train step, bf16')
             sargs = argparse.Namespace(**vars(args))
             sargs.batch, sargs.steps, sargs.warmup, sargs.workload = 256, 10, 3, 'synth'
             out['synth'] = synth_bench(sargs, make_hparams(256, 'bf16'), dev, 0, 1, emit=False, cpu_steps=(1, 3))

@@ -157,9 +157,10 @@ def test_c2_training_pass_with_dropout_matches_oracle_with_the_same_masks(mode):
         with feed_masks(log, rows):
             ora = S._oracle_slice(hp, state, inputs, rows, 48, 20000, torch.bfloat16)
         # (sigma-path parameters: their gradients follow the alignments, which bf16 moves by ~20 % of their maximum with or without dropout
-        #  -- module docstring of test_gpu_parity_at_size.py, (iii); measured here 1.14x the dropout-free bound of 3.5 -> 6 for headroom.
+        #  -- module docstring of test_gpu_parity_at_size.py, (iii); measured here 1.14x the dropout-free bound of 3.5 with round 5's K-sum order
+        #  and 2.04x with round 6's (four K slices per tile instead of two: another rounding sequence in front of the same chaos) -> 8.
         #  The sharp bf16 statement is the stage-wise check above; the sharp end-to-end statement is the fp32 case.)
-        S._compare('bf16_emulated', hip, ora, what, sigma_factor=6.)
+        S._compare('bf16_emulated', hip, ora, what, sigma_factor=8.)
     else:
         with feed_masks(log, rows):
             ora = S._oracle_slice(hp, state, inputs, rows, 48, 20000)

@@ -586,8 +586,7 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
               s1 += v[e];
               s2 += v[e] * xh[e];
             }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            s1 = dx_row16_sum(s1); s2 = dx_row16_sum(s2);
             s1 *= 1.f / BN; s2 *= 1.f / BN;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = rstd * (v[e] - s1 - xh[e] * s2);
@@ -618,14 +617,12 @@ __global__ __launch_bounds__(RING ? 2 * NTHREADS : NTHREADS, RING ? 2 : ((sizeof
             float sum = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) sum += v[e];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            sum = dx_row16_sum(sum);
             const float mean = sum * (1.f / BN);
             float sq = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; sq += d * d; }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) sq += __shfl_xor(sq, o, 64);
+            sq = dx_row16_sum(sq);
             const float rstd = rsqrtf(sq * (1.f / BN) + 1e-5f);
             if (p.ln.mean && cl == 0) { p.ln.mean[rowg] = mean; p.ln.rstd[rowg] = rstd; }
             const f32x8 gm = gm_h, bt = bt_h;                      // (LN == 1: PFB is always true)
@@ -1085,6 +1082,17 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
 //     backward: dx_conv1d_lnbwd), the row-wise code of conv_gemm_kernel run by one 256-thread team.
 // The padding rows of the batch (an equal share per workgroup, as in the ring kernel) are zero-filled after the epilogue.
 constexpr int SK_THREADS = 256, SK_S = 4, SK_NB = 4, SK_MAXP = 5;
+// DX_SK_V: main loop of conv_sk_kernel.  1 = rounds 3-5 (K halves x channel halves, one shared activation ring, a workgroup barrier per
+// 32-channel chunk); 2 (round 6, default) = FOUR K slices, one per wave, every wave on its own -- see the comment in the kernel.
+#ifndef DX_SK_V
+#define DX_SK_V 2
+#endif
+#ifndef SK4_ABL
+#define SK4_ABL 0   // development ablations of the DX_SK_V == 2 main loop (wrong results): 1 no fragment loads, 2 no LDS-DMA, 4 no MFMAs, 8 no LDS reads, 16 no epilogue
+#endif
+constexpr int SK4_MAXNA = 6, SK4_S = 3, SK4_NPMAX = (SK4_MAXNA * 32 + 2 + 15) / 16, SK4_WAVE_EL = SK4_S * SK4_NPMAX * 512;
+template <int N>
+__device__ __forceinline__ void sk_wait_vmcnt_c() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ void sk_dma16(const void* gsrc, unsigned lds_dst) {   // one 1-KiB LDS-DMA piece (16 B per lane)
   unsigned keep;
@@ -1106,9 +1114,14 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
   typedef bf16x8 frag_t;
   constexpr int LN = LNM == 3 ? 2 : LNM;
   constexpr bool LNFILM = LNM == 2;
-  constexpr int TAPS = 3, HALO = 1, MAXBLK = 8, AROWS = 32 * MAXBLK + TAPS - 1, AR16 = (AROWS + 15) & ~15, STAGE_EL = AR16 * 32;
-  constexpr int STG_LD = BN + 4;
-  constexpr int RING_BYTES = SK_S * STAGE_EL * 2, XCH_BYTES = 4 * MAXBLK * 16 * 64 * 4, STG_BYTES = 64 * STG_LD * 4;
+  constexpr int TAPS = 3, HALO = 1, STG_LD = BN + 4, STG_BYTES = 64 * STG_LD * 4;
+#if DX_SK_V == 2
+  constexpr int MAXBLK = SK4_MAXNA;
+  constexpr int RING_BYTES = 4 * SK4_WAVE_EL * 2, XCH_BYTES = 24 * 4096;
+#else
+  constexpr int MAXBLK = 8, AROWS = 32 * MAXBLK + TAPS - 1, AR16 = (AROWS + 15) & ~15, STAGE_EL = AR16 * 32;
+  constexpr int RING_BYTES = SK_S * STAGE_EL * 2, XCH_BYTES = 4 * MAXBLK * 16 * 64 * 4;
+#endif
   constexpr int SMEM_BYTES = RING_BYTES > XCH_BYTES ? (RING_BYTES > STG_BYTES ? RING_BYTES : STG_BYTES) : (XCH_BYTES > STG_BYTES ? XCH_BYTES : STG_BYTES);
   __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
   TC* ring = reinterpret_cast<TC*>(smem);
@@ -1118,11 +1131,213 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, g = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wk = wave & 1, wc = wave >> 1;
   const int4 e = reinterpret_cast<const int4*>(p.plan)[blockIdx.x];
-  const int b = e.x, n0 = e.y, h = e.z, fill_per = e.w;
+  const int b = e.x, n0_tile = e.y, h_tile = e.z, fill_per = e.w;
   const int N = p.N, Cin = p.Cin;
   const int len = p.mask_len ? (int)p.mask_len[b] : N;
-
+  // a tile taller than the accumulators of the main loop hold (DX_SK_V == 2: 5 row blocks) is two workgroups' work: blockIdx.y = 1 takes the
+  // rows from 128 on (and exits at once for every other tile); the grid is (tiles, 2) there
+#if DX_SK_V == 2
+  const bool tall = h_tile > 32 * SK4_MAXNA;
+  if (blockIdx.y && !tall) return;
+  const int n0 = n0_tile + (int)blockIdx.y * 128, h = tall ? (blockIdx.y ? h_tile - 128 : 128) : h_tile;
+#else
+  const int n0 = n0_tile, h = h_tile;
+#endif
   if (h > 0) {
+    const TC* X = reinterpret_cast<const TC*>(p.x) + (size_t)b * N * p.ldx;
+    const int nk = Cin >> 5;
+#if DX_SK_V == 2
+    // ---- main loop, round 6.  The contraction (Cin x 3 taps) is split FOUR ways inside the workgroup: wave w takes the 32-channel
+    // chunks 4 s + w (s = "step") with all three taps, for ALL rows of the tile (<= 5 blocks of 32) and ALL 128 output channels:
+    // <= 5 x 4 MFMA tiles = 320 accumulator registers.  Nothing is shared between the waves until the end:
+    //   * the activation slab of a wave's chunk (<= 162 rows x 32 channels, <= 11 KiB) goes through the wave's OWN 3-stage LDS-DMA
+    //     ring -- there is no workgroup barrier in the loop, only the wave's own vmcnt waits (hand-counted below);
+    //   * the weight fragments (fragment order, dx_pack_frag_major: the four channel blocks of one (chunk, tap, k half) are 4 KiB
+    //     contiguous) come from L2 straight into registers, every fragment read by exactly ONE wave: 786 KB per workgroup as before;
+    //   * per (tap, k half) "sub-step" a wave reads NA activation fragments from LDS for 4 NA MFMAs (0.25 KB of LDS per MFMA; the
+    //     rounds 3-5 loop: 0.5), the fragments of the next sub-step are requested before the MFMAs of this one;
+    //   * after the last step the four partial tiles of every (row block, channel block) meet through LDS, two row blocks per pass;
+    //     local channel block j of wave w is block j ^ w, so that local 0 is the one the wave keeps (static register indices) and
+    //     the sum runs in the fixed order own + (w ^ 1) + (w ^ 2) + (w ^ 3): results stay run-to-run reproducible.
+    // Why: the rounds 3-5 loop (DX_SK_V == 1) ran the matrix pipe at ~36 % inside its compute phase and lost another 620 cycles per
+    // chunk to the hand-over (DMA wait + barrier): one wave per SIMD in lock step with three others exposes every latency.  Tiles of
+    // 129..160 rows (the balanced plan of a B = 48 batch: H = 124..135) also ran its 8-block code path: 48 MFMAs per chunk for 30.
+    f32x16 fin[SK4_MAXNA];
+    {
+      const int nblk = __builtin_amdgcn_readfirstlane((h + 31) >> 5);     // live 32-row blocks, 1 .. 6
+      const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem) +
+                                 (unsigned)(wave * SK4_WAVE_EL * 2);
+      const TC* ringw = ring + wave * SK4_WAVE_EL;
+      // LDS-DMA pieces: 16 rows x 64 B; lane -> row lane >> 2, slot lane & 3, which holds source chunk slot ^ ((row >> 2) & 3) (lds_at;
+      // (row >> 2) & 3 == (lane >> 4) & 3 for every piece).  Rows outside the utterance or past the halo read the zero page.
+      const int lr = lane >> 2, csrc = (lane & 3) ^ ((lane >> 4) & 3);
+      const TC* zp = reinterpret_cast<const TC*>(dx_zero_page);
+      asm volatile("" : "+s"(zp));                                        // (an SGPR pair, not a GOT load per piece)
+      const int rowoff0 = (n0 - HALO + lr) * (int)p.ldx + csrc * 8, ld16 = 16 * (int)p.ldx;   // elements from X; < 2^31 (plan_check: B * N * ldx)
+      const int rlo = n0 == 0 ? 1 : 0, rhi = min(h + TAPS - 1, N - n0 + HALO);
+      const TC* wl = reinterpret_cast<const TC*>(p.w_frag) + lane * 8;
+      auto mainloop = [&](auto na_tag, auto ks_tag) {
+        // KS K slices x (4 / KS) channel groups: wave = wk + KS wc takes the chunks KS s + wk and the channel blocks NCB wc + (j ^ wk),
+        // j = 0 .. NCB - 1 (NCB = KS): local block 0 is global block `wave`, the one the wave keeps after the exchange
+        constexpr int NA = decltype(na_tag)::value, KS = decltype(ks_tag)::value, NCB = KS;
+        constexpr int NP = (NA * 32 + TAPS - 1 + 15) / 16, STAGE_EL = NP * 512;
+        constexpr int RQ = NA * NCB >= 10 ? 3 : 6;                         // weight-fragment ring, in sub-steps (6 per step)
+        auto dist = [](int q) constexpr { return (NP + 5 - q) / 6; };      // pieces issued in sub-step q
+        auto first = [](int q) constexpr { int f = 0; for (int i = 0; i < q; ++i) f += (NP + 5 - i) / 6; return f; };
+        constexpr int QL = NP >= 6 ? 5 : NP - 1;                           // last sub-step that issues a piece
+        constexpr int P5 = NP - NP / 6;                                    // pieces issued before sub-step 5
+        static_assert(3 * STAGE_EL <= SK4_WAVE_EL, "ring stage");
+        const int skw = wave % KS, scw = wave / KS;
+        const int ns = nk / KS;                                             // steps (launcher: Cin % 128 == 0, Cin >= 256)
+        // every workgroup walks the steps in its own rotation (see DX_SK_V == 1: the workgroups of an XCD would otherwise ask its L2
+        // for the same weight lines at the same time)
+        const int soff = (int)((blockIdx.x >> 3) % (unsigned)ns);
+        auto kc_of = [&](int s) { int t = s + soff; if (t >= ns) t -= ns; return KS * t + skw; };
+        const int jx = skw * 512, jb = scw * NCB * 512;
+        f32x16 acc[NA][NCB];
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+          for (int j = 0; j < NCB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        frag_t bq[RQ][NCB], a[2][NA];
+        auto piece = [&](int t, int kc, int stg) {
+          // (laundered: as loop invariants hipcc keeps 2 NP hoisted pointers in registers -- and spills them; re-deriving one costs ~8 VALU)
+          int lrv = lr, ro = rowoff0;
+          asm volatile("" : "+v"(lrv), "+v"(ro));
+          const int r = t * 16 + lrv;
+          const bool ok = (unsigned)(r - rlo) < (unsigned)(rhi - rlo);
+          const TC* sp = (ok ? X : zp) + ((ok ? ro + t * ld16 : csrc * 8) + kc * 32);
+          sk_dma16(sp, __builtin_amdgcn_readfirstlane(ring_base + (unsigned)((stg * STAGE_EL + t * 512) * 2)));
+        };
+        auto load_b = [&](int kc, int q, frag_t* d) {
+          const TC* wq = wl + (size_t)kc * 12288 + q * 2048 + jb;
+#pragma unroll
+          for (int j = 0; j < NCB; ++j) d[j] = *reinterpret_cast<const frag_t*>(wq + ((j * 512) ^ jx));
+        };
+        auto read_a = [&](const TC* Ar, int q, frag_t* d) {
+          const int tap = q >> 1, half = q & 1;
+#pragma unroll
+          for (int i = 0; i < NA; ++i) d[i] = *reinterpret_cast<const frag_t*>(&Ar[lds_at(i * 32 + l31 + tap, half * 2 + g)]);
+        };
+        // prologue: the slabs of steps 0 and 1, the fragments of the first RQ sub-steps, then the first activation fragments
+#pragma unroll
+        for (int t = 0; t < NP; ++t) piece(t, kc_of(0), 0);
+#pragma unroll
+        for (int t = 0; t < NP; ++t) piece(t, kc_of(1), 1);
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) load_b(kc_of(0), q, bq[q]);
+        sk_wait_vmcnt_c<NP + NCB * RQ>();                                  // behind the slab of step 0: the slab of step 1, NCB RQ fragments
+        read_a(ringw, 0, a[0]);
+        int stg = 0;                                                        // ring stage of step s
+        for (int s = 0; s < ns; ++s) {
+          const int stg1 = stg + 1 == SK4_S ? 0 : stg + 1, stg2 = stg1 + 1 == SK4_S ? 0 : stg1 + 1;
+          const bool dma = s + 2 < ns, more = s + 1 < ns;
+          const int kc0 = kc_of(s), kc1 = kc_of(more ? s + 1 : s), kc2 = dma ? kc_of(s + 2) : 0;
+          const TC* Ar = ringw + stg * STAGE_EL;
+          const TC* An = ringw + stg1 * STAGE_EL;
+          auto sub = [&](auto q_tag) {
+            constexpr int Q = decltype(q_tag)::value, SL = Q % RQ;
+            if (Q < 5) { if (!(SK4_ABL & 8)) read_a(Ar, Q + 1, a[(Q + 1) & 1]); }
+            else if (more) {
+              // the slab of step s + 1 must have landed.  Behind its last piece in this wave's queue: the fragment loads of the rest
+              // of that step (s >= 1: NCB (6 - QL); s == 0: the prologue's NCB RQ), and of this step's sub-steps 0..4 (5 NCB) with
+              // the pieces issued beside them (P5, when step s + 2 exists).  hipcc does not see the pieces: its own waits are early.
+              if (SK4_ABL & 3) sk_wait_vmcnt_c<0>();
+              else if (s == 0) { if (dma) sk_wait_vmcnt_c<NCB * RQ + 5 * NCB + P5>(); else sk_wait_vmcnt_c<NCB * RQ + 5 * NCB>(); }
+              else { if (dma) sk_wait_vmcnt_c<NCB * (6 - QL) + 5 * NCB + P5>(); else sk_wait_vmcnt_c<NCB * (6 - QL) + 5 * NCB>(); }
+              if (!(SK4_ABL & 8)) read_a(An, 0, a[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int HALF = NA / 2;
+#pragma unroll
+            for (int i = 0; i < HALF; ++i)
+#pragma unroll
+              for (int j = 0; j < NCB; ++j) if (!(SK4_ABL & 4)) dx_mma(acc[i][j], a[Q & 1][i], bq[SL][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (dma && !(SK4_ABL & 2)) {
+#pragma unroll
+              for (int t = first(Q); t < first(Q) + dist(Q); ++t) piece(t, kc2, stg2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = HALF; i < NA; ++i)
+#pragma unroll
+              for (int j = 0; j < NCB; ++j) if (!(SK4_ABL & 4)) dx_mma(acc[i][j], a[Q & 1][i], bq[SL][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            // refill the slots just read with sub-step Q + RQ (UNCONDITIONAL: past the end it re-reads -- a load that may not execute
+            // makes hipcc assume the worst at every use, see DX_SK_V == 1)
+            if (!(SK4_ABL & 1)) load_b(Q + RQ < 6 ? kc0 : kc1, (Q + RQ) % 6, bq[SL]);
+          };
+          sub(std::integral_constant<int, 0>{});
+          sub(std::integral_constant<int, 1>{});
+          sub(std::integral_constant<int, 2>{});
+          sub(std::integral_constant<int, 3>{});
+          sub(std::integral_constant<int, 4>{});
+          sub(std::integral_constant<int, 5>{});
+          stg = stg1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                 // every wave is done with its ring: the exchange buffer reuses it
+        // ---- the K slices meet, two row blocks per pass: slot ((wave (KS - 1) + j - 1) * 2 + rbl) of 4 KiB = [register quad][lane][4];
+        // fixed order own + (wk ^ 1) [+ (wk ^ 2) + (wk ^ 3)]: results stay run-to-run reproducible
+#pragma unroll
+        for (int pp = 0; pp < (NA + 1) / 2; ++pp) {
+#pragma unroll
+          for (int rbl = 0; rbl < 2; ++rbl)
+            if (2 * pp + rbl < NA) {
+#pragma unroll
+              for (int j = 1; j < KS; ++j)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                  const f32x16& t = acc[2 * pp + rbl][j];
+                  *reinterpret_cast<f32x4*>(xch + ((((wave * (KS - 1) + j - 1) * 2 + rbl) * 4 + r4) * 64 + lane) * 4) =
+                      f32x4{t[4 * r4], t[4 * r4 + 1], t[4 * r4 + 2], t[4 * r4 + 3]};
+                }
+            }
+          __syncthreads();
+#pragma unroll
+          for (int rbl = 0; rbl < 2; ++rbl)
+            if (2 * pp + rbl < NA) {
+              f32x16 t = acc[2 * pp + rbl][0];
+#pragma unroll
+              for (int d = 1; d < KS; ++d)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                  const f32x4 v = *reinterpret_cast<const f32x4*>(xch + (((((wave ^ d) * (KS - 1) + d - 1) * 2 + rbl) * 4 + r4) * 64 + lane) * 4);
+#pragma unroll
+                  for (int e2 = 0; e2 < 4; ++e2) t[4 * r4 + e2] += v[e2];
+                }
+              fin[2 * pp + rbl] = t;
+            }
+          __syncthreads();
+        }
+#pragma unroll
+        for (int i = NA; i < SK4_MAXNA; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) fin[i][r] = 0.f;
+      };
+      constexpr std::integral_constant<int, 4> K4{};
+      constexpr std::integral_constant<int, 2> K2{};
+      if (nblk > 5) mainloop(std::integral_constant<int, 6>{}, K2);
+      else if (nblk == 5) mainloop(std::integral_constant<int, 5>{}, K2);
+      else if (nblk == 4) mainloop(std::integral_constant<int, 4>{}, K4);
+      else if (nblk == 3) mainloop(std::integral_constant<int, 3>{}, K4);
+      else if (nblk == 2) mainloop(std::integral_constant<int, 2>{}, K4);
+      else mainloop(std::integral_constant<int, 1>{}, K4);
+    }
+#define DX_SK_FIN(i) fin[i]
+    if (SK4_ABL & 16) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < SK4_MAXNA; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += fin[i][r];
+      if (t == 12345.678f) p.ln.y_lp ? (void)(reinterpret_cast<float*>(p.ln.y_lp)[tid] = t) : (void)0;
+      return;
+    }
+#else
     f32x16 acc[MAXBLK][2];
 #pragma unroll
     for (int i = 0; i < MAXBLK; ++i)
@@ -1130,8 +1345,6 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const TC* X = reinterpret_cast<const TC*>(p.x) + (size_t)b * N * p.ldx;
-    const int nk = Cin >> 5;
     const int nA = (h + TAPS - 1 + 15) >> 4;                       // 16-row pieces of the haloed activation tile
     const int mine = __builtin_amdgcn_readfirstlane(nA > wave ? (nA - wave + 3) >> 2 : 0);   // pieces wave, wave + 4, ... are this wave's
     const TC* src[SK_MAXP];
@@ -1271,6 +1484,8 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
         }
       __syncthreads();
     }
+#define DX_SK_FIN(i) acc[i][0]
+#endif
     // ---- LayerNorm epilogue (the PLAN epilogue of conv_gemm_kernel with one 256-thread team)
     constexpr int NCS = LNM == 2 ? 4 : (LNM == 3 ? 2 : 1);
     float csum[NCS][8];
@@ -1278,7 +1493,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
     for (int q = 0; q < NCS; ++q)
 #pragma unroll
       for (int e2 = 0; e2 < 8; ++e2) csum[q][e2] = 0.f;
-    const int cb = 2 * wc + wk;
+    const int cb = 2 * wc + wk;                        // == wave: the channel block whose complete rows this wave holds
     const float bv = p.bias ? p.bias[cb * 32 + l31] : 0.f;
     // second GEMM of the backward variant (LayerNorm backward -> output-projection data gradient, model.py:182-186): the rows this
     // epilogue writes as y_lp are the operand of a 128 -> 128 k = 1 GEMM that used to be the next launch (18 us for 3 us of work).
@@ -1288,6 +1503,14 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
     // wave, bias added in the store.
     constexpr int A2_LD = BN + 8, A2_OFF = 64 * 1024, NC2 = LN == 2 ? 1 : 3;
     static_assert(A2_OFF >= STG_BYTES && A2_OFF + 64 * A2_LD * 2 <= SMEM_BYTES, "second-GEMM operand tile must fit beside the staging buffer");
+    // LDS image of the second GEMM's output slab (64 rows x n2 <= 384 channels, bf16; 16 bytes of padding per row: conflict-free 16-byte
+    // writes from the MFMA layout) behind the operand tile -- where the workgroup's LDS has room for it (DX_SK_V == 2)
+    constexpr int Y2_LD = 384 + 8, Y2S_OFF = 82 * 1024;
+#ifndef DX_SK_Y2_STAGE
+#define DX_SK_Y2_STAGE 0   // measured (c2[3] frame-level launch, all outputs): 53.9 us with the image, 51.1 without -- the 8 us the QKV rows cost are their
+#endif                     // 23 MB in a write-bound epilogue, not the shape of the store instructions
+    constexpr bool Y2_STAGE = DX_SK_Y2_STAGE && Y2S_OFF >= A2_OFF + 64 * A2_LD * 2 && Y2S_OFF + 64 * Y2_LD * 2 <= SMEM_BYTES;
+    TC* y2s = reinterpret_cast<TC*>(smem + Y2S_OFF);
     const bool gemm2 = p.ln.y2 != nullptr;
     const int n2 = p.ln.n2, ncb2 = __builtin_amdgcn_readfirstlane(n2 >> 7);      // channel blocks per wave (1 or 3)
     TC* a2 = reinterpret_cast<TC*>(smem + A2_OFF);
@@ -1298,7 +1521,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
         if (c < ncb2) {
           const TC* w2 = reinterpret_cast<const TC*>(p.ln.w2) + (size_t)((c * 4 + wave) * 32 + l31) * BN + g * 8;
 #pragma unroll
-          for (int ks = 0; ks < 8; ++ks) w2f[c][ks] = *reinterpret_cast<const frag_t*>(w2 + ks * 16);
+          for (int ks = 0; ks < 8; ++ks) w2f[c][ks] = *reinterpret_cast<const frag_t*>(w2 + ((SK4_ABL & 128) ? 0 : ks * 16));
         }
     }
     // the per-channel operands of the row passes depend on (b, channel segment) only: loaded ONCE here.  Inside the passes they sat
@@ -1314,12 +1537,14 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
     f32x8 rg_h = gm_h, rb_h = gm_h;
     if (vres) { rg_h = raw_load8<float>(p.ln.res_gamma + cl_h); rb_h = raw_load8<float>(p.ln.res_beta + cl_h); }
 #pragma unroll
-    for (int i = 0; i < MAXBLK / 2; ++i) {
+    for (int i = 0; i < (MAXBLK + 1) / 2; ++i) {
       if (i * 64 >= h) break;                          // workgroup-uniform: the barriers below stay matched
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
+        if (2 * i + rb < MAXBLK) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) stage[(rb * 32 + dx_acc_row(r, g)) * STG_LD + cb * 32 + l31] = acc[2 * i + rb][0][r] + bv;
+          for (int r = 0; r < 16; ++r) stage[(rb * 32 + dx_acc_row(r, g)) * STG_LD + cb * 32 + l31] = DX_SK_FIN(2 * i + rb)[r] + bv;
+        }
       f32x8 pf_a[4], pf_b[4];
       float pf_m[4], pf_r[4];
 #pragma unroll
@@ -1379,8 +1604,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
               s1 += v[e2];
               s2 += v[e2] * xh[e2];
             }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            s1 = dx_row16_sum(s1); s2 = dx_row16_sum(s2);
             s1 *= 1.f / BN; s2 *= 1.f / BN;
 #pragma unroll
             for (int e2 = 0; e2 < 8; ++e2) v[e2] = rstd * (v[e2] - s1 - xh[e2] * s2);
@@ -1414,14 +1638,12 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
             float sum = 0.f;
 #pragma unroll
             for (int e2 = 0; e2 < 8; ++e2) sum += v[e2];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            sum = dx_row16_sum(sum);
             const float mean = sum * (1.f / BN);
             float sq = 0.f;
 #pragma unroll
             for (int e2 = 0; e2 < 8; ++e2) { const float d = v[e2] - mean; sq += d * d; }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) sq += __shfl_xor(sq, o, 64);
+            sq = dx_row16_sum(sq);
             const float rstd = rsqrtf(sq * (1.f / BN) + 1e-5f);
             if (p.ln.mean && cl == 0) { p.ln.mean[rowg] = mean; p.ln.rstd[rowg] = rstd; }
             const f32x8 gm = gm_h, bt = bt_h;
@@ -1447,38 +1669,82 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
       }
       __syncthreads();
       if (gemm2) {   // (the next iteration writes the image only behind its own barrier, i.e. after every wave has read it)
+        // all (channel block, row block) products of the slab at once: 2 NC2 independent accumulators, every operand fragment of the
+        // slab read from LDS ONCE (round 5 ran them one after the other: 8 dependent MFMAs per tile, the fragments re-read per channel block)
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        f32x16 d2[NC2][2];
+#pragma unroll
+        for (int c = 0; c < NC2; ++c)
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d2[c][rb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const frag_t x0 = *reinterpret_cast<const frag_t*>(a2 + l31 * A2_LD + ks * 16 + g * 8);
+          const frag_t x1 = *reinterpret_cast<const frag_t*>(a2 + (32 + l31) * A2_LD + ks * 16 + g * 8);
+#pragma unroll
+          for (int c = 0; c < NC2; ++c)
+            if (c < ncb2 && !(SK4_ABL & 64)) {
+              dx_mma(d2[c][0], w2f[c][ks], x0);
+              dx_mma(d2[c][1], w2f[c][ks], x1);
+            }
+        }
 #pragma unroll
         for (int c = 0; c < NC2; ++c) {
           if (c >= ncb2) break;
-          const int co2 = (c * 4 + wave) * 32 + 4 * g;            // this lane's channels: co2 + 8 j + 0..3
-          f32x4 bj4[4];                                           // bias of this lane's channels: requested in front of the MFMAs
+          const int cw = (c * 4 + wave) * 32;                     // this wave's 32 output channels of channel group c
+          f32x4 bj4[4];                                           // bias of the lane's channels cw + 4 g + 8 j + 0..3 (MFMA layout)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             bj4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.ln.b2) bj4[j] = *reinterpret_cast<const f32x4*>(p.ln.b2 + co2 + 8 * j);
+            if (p.ln.b2) bj4[j] = *reinterpret_cast<const f32x4*>(p.ln.b2 + cw + 4 * g + 8 * j);
           }
 #pragma unroll
           for (int rb = 0; rb < 2; ++rb) {
-            f32x16 d2;
+            // bf16 pairs, then two v_permlane32_swap per 16 channels (conv_wreg_kernel's epilogue): the lane ends up with channels
+            // cw + 8 g + 0..7 and cw + 16 + 8 g + 0..7 of its row -- two 16-byte stores instead of four 8-byte ones
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            uint32_t P[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d2[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-              const frag_t xr = *reinterpret_cast<const frag_t*>(a2 + (rb * 32 + l31) * A2_LD + ks * 16 + g * 8);
-              dx_mma(d2, w2f[c][ks], xr);
+            for (int k = 0; k < 8; ++k) {
+              const bf16x2 pr = {(bf16_t)(d2[c][rb][2 * k] + bj4[k >> 1][(2 * k) & 3]), (bf16_t)(d2[c][rb][2 * k + 1] + bj4[k >> 1][(2 * k + 1) & 3])};
+              P[k] = __builtin_bit_cast(uint32_t, pr);
             }
-            const int trow = i * 64 + rb * 32 + l31, n = n0 + trow;
-            if (trow < h && n < N) {
-              TC* yo = reinterpret_cast<TC*>(p.ln.y2) + ((size_t)b * N + n) * n2 + co2;
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const f32x4 bj = bj4[j];
-                bf16x4 o4;
+            for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-                for (int e2 = 0; e2 < 4; ++e2) o4[e2] = (TC)(d2[4 * j + e2] + bj[e2]);
-                *reinterpret_cast<bf16x4*>(yo + 8 * j) = o4;
+              for (int k = 0; k < 2; ++k) {
+                const u32x2 sw = __builtin_amdgcn_permlane32_swap(P[4 * h2 + k], P[4 * h2 + 2 + k], false, false);
+                P[4 * h2 + k] = sw[0];
+                P[4 * h2 + 2 + k] = sw[1];
+              }
+            if constexpr (Y2_STAGE) {   // the slab's rows leave through an LDS image: whole rows per store instruction (below)
+              TC* yl = y2s + (rb * 32 + l31) * Y2_LD + cw + 8 * g;
+              *reinterpret_cast<u32x4*>(yl) = u32x4{P[0], P[1], P[2], P[3]};
+              *reinterpret_cast<u32x4*>(yl + 16) = u32x4{P[4], P[5], P[6], P[7]};
+            } else {
+              const int trow = i * 64 + rb * 32 + l31, n = n0 + trow;
+              if (trow < h && n < N) {
+                TC* yo = reinterpret_cast<TC*>(p.ln.y2) + ((size_t)b * N + n) * n2 + cw + 8 * g;
+                *reinterpret_cast<u32x4*>(yo) = u32x4{P[0], P[1], P[2], P[3]};
+                *reinterpret_cast<u32x4*>(yo + 16) = u32x4{P[4], P[5], P[6], P[7]};
               }
             }
+          }
+        }
+        if constexpr (Y2_STAGE) {
+          // straight from the MFMA layout a store instruction wrote 32 bytes into each of 32 rows (768 bytes apart): measured 8 us of a
+          // 51 us launch for 23 MB.  From the image: 16 consecutive lanes = 256 contiguous bytes of one row.
+          __syncthreads();
+          const int segs = n2 >> 3;
+          for (int idx = tid; idx < 64 * segs; idx += SK_THREADS) {
+            const int row = idx / segs, seg = idx - row * segs;
+            const int trow = i * 64 + row, n = n0 + trow;
+            if (trow < h && n < N && !(SK4_ABL & 32))
+              *reinterpret_cast<u32x4*>(reinterpret_cast<TC*>(p.ln.y2) + ((size_t)b * N + n) * n2 + seg * 8) =
+                  *reinterpret_cast<const u32x4*>(y2s + row * Y2_LD + seg * 8);
           }
         }
       }
@@ -1499,10 +1765,11 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
       }
     }
   }
+#undef DX_SK_FIN
   // ---- padding fill: the batch's padding rows, flattened utterance by utterance, are split evenly over the workgroups; this one
   // owns [lo, hi).  Each wave finds the utterances its range touches with a wave scan over the lengths, and the 256 threads share
   // the 16-byte segments of those rows.
-  {
+  if (blockIdx.y == 0) {
     const long lo = (long)blockIdx.x * fill_per, hi = lo + fill_per;
     long carry = 0;
     for (int base = 0; base < p.B && carry < hi; base += 64) {
@@ -1804,7 +2071,8 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
       // 256 rows): measured 0.35 % of the B = 48 step faster than the ring kernel (frame level 46 vs 50 us, phoneme level 27 vs 33 us),
       // 2.5 % of the B = 256 step slower (several rounds of 256-row tiles: the ring kernel's two epilogue teams win there)
       if (a.plan && taps == 3 && a.w_frag && a.Cin >= 256 && a.Cin % 128 == 0 && (long)B * a.N <= 256L * 256) {
-        dim3 gridp((unsigned)a.plan_tiles);
+        // DX_SK_V == 2: tiles of more than 6 row blocks (possible when N > 192) are split between blockIdx.y = 0 and 1
+        dim3 gridp((unsigned)a.plan_tiles, (DX_SK_V == 2 && a.N > 32 * SK4_MAXNA) ? 2u : 1u);
         if (film) hipLaunchKernelGGL((conv_sk_kernel<LN>), gridp, dim3(SK_THREADS), 0, s, a);
         else hipLaunchKernelGGL((conv_sk_kernel<LNB>), gridp, dim3(SK_THREADS), 0, s, a);
         DX_LAUNCH_CHECK();

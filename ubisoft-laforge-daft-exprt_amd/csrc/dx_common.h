@@ -104,6 +104,22 @@ __device__ __forceinline__ int dx_acc_row(int r, int g) { return (r & 3) + 8 * (
 template <typename T>
 __device__ __forceinline__ float dx_to_f32(T v) { return (float)v; }
 
+// DPP moves inside the 16-lane rows of a wave (lanes 16 k .. 16 k + 15): v_add_f32_dpp, ~8 cycles -- a __shfl_xor compiles to
+// ds_bpermute_b32, a ~100-cycle round trip through the LDS crossbar that a kernel with ONE wave per SIMD cannot hide
+template <int CTRL>
+__device__ __forceinline__ float dx_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a row, every lane gets the total (a symmetric butterfly: the same bits in every lane):
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float dx_row16_sum(float v) {
+  v += dx_dpp<0xB1>(v);
+  v += dx_dpp<0x4E>(v);
+  v += dx_dpp<0x141>(v);
+  v += dx_dpp<0x140>(v);
+  return v;
+}
+
 __device__ __forceinline__ float dx_wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

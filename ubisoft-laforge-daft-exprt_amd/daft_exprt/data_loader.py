@@ -242,7 +242,16 @@ def group_micro_batches(micro_batches):
     cat = lambda idx, dim, size: torch.cat([_pad_to(i[idx], dim, size) for i in ins], 0).contiguous()
     inputs = (cat(0, 1, Lg), cat(1, 1, Lg), cat(2, 1, Lg), cat(3, 1, Lg), cat(4, 1, Lg), torch.cat([i[5] for i in ins]),
               cat(6, 1, Tg), cat(7, 1, Tg), cat(8, 2, Tg), torch.cat([i[9] for i in ins]), torch.cat([i[10] for i in ins]))
-    targets = (inputs[1], inputs[3], inputs[4], inputs[8], inputs[10])
+    # targets: parse_batch hands out views of the inputs (durations_float, symbols_energy, symbols_pitch, mel_specs, speaker_ids) -- then the
+    # group's targets are the group's inputs; a caller's own target tensors are concatenated like the inputs
+    tg = [mb[1] for mb in micro_batches]
+    TIDX = (1, 3, 4, 8, 10)
+    if all(t is None or all(x.data_ptr() == i[k].data_ptr() and x.shape == i[k].shape for x, k in zip(t, TIDX)) for t, i in zip(tg, ins)):
+        targets = tuple(inputs[k] for k in TIDX)
+    else:
+        assert all(t is not None for t in tg), 'group_micro_batches: targets given for some micro-batches only'
+        tcat = lambda j, dim, size: torch.cat([_pad_to(t[j], dim, size) for t in tg], 0).contiguous()
+        targets = (tcat(0, 1, Lg), tcat(1, 1, Lg), tcat(2, 1, Lg), tcat(3, 2, Tg), torch.cat([t[4] for t in tg]))
     dev = inputs[5].device
     nmax_in = torch.cat([torch.full((i[0].shape[0],), i[0].shape[1], dtype=torch.long, device=dev) for i in ins])
     nmax_out = torch.cat([torch.full((i[8].shape[0],), i[8].shape[2], dtype=torch.long, device=dev) for i in ins])
@@ -252,8 +261,9 @@ def group_micro_batches(micro_batches):
 
 
 def group_host_batches(batches):
-    ''' the same on collate outputs (13-tuples of host tensors): returns (13-tuple of the group, (nmax_in, nmax_out) host tensors);
-        `DaftExprt.parse_batch` + `bounds_from_nmax` finish the job on the device '''
+    ''' the same on collate outputs (13-tuples of host tensors): returns (13-tuple of the group, (nmax_in, nmax_out) host tensors, sizes);
+        `DaftExprt.parse_batch` and the clamp `skip = max(0, min(length, nmax - 2))` in `train()` finish the job on the device.
+        The caller checks `len(set(sizes)) == 1` (ragged micro-batches run one pass each, see `Trainer._grouped`) '''
     ins = [(b[:11], None) for b in batches]
     g = group_micro_batches(ins)
     dirs = [d for b in batches for d in b[11]]

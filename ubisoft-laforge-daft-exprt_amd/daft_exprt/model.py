@@ -763,6 +763,10 @@ class DaftExprt(nn.Module):
         mel, s_dec = self._decoder_fwd(W, dec_in, films[2], output_lengths, train, save)
         if beside:
             main.wait_event(self._pp_ev[1])
+            # allocated on the side stream, consumed on the launch stream (the loss, `last_outputs`, user code): tell the caching allocator
+            # (the saved activations stay in `_wgrad_keep` until the streams have joined at the end of the backward pass)
+            logits.record_stream(main)
+            y.record_stream(main)
         dur, energy, pitch = ops.unstack(y, 3)
         if save:
             S.pe, S.cls, S.enc, S.pp, S.gu, S.dec, S.films, S.symbols, S.input_lengths, S.enc_out, S.x_mel = \

@@ -133,6 +133,7 @@ class Trainer(object):
         self.sectioned = stream_ordered if mode == 'auto' else bool(int(mode))
         self._opt_stream = self._sec_event = None
         self._done = set()
+        self.diag = self._diag_comm = None          # a list: step_eager appends (event behind the last backward kernel, event behind the last all-reduce)
         # whole-step hipGraphs, keyed on the addresses and shapes of the step's input tensors (`CapturedStep`): one rank only -- a
         # captured RCCL collective is untested here -- and only with the whole-buffer optimizer
         # DX_STEP_GRAPH: 0 (default) = never, 1 = every repeating step is captured, auto = only steps small enough to be bound by the
@@ -157,19 +158,28 @@ class Trainer(object):
             self._opt_stream.wait_event(self._sec_event)      # the bucket's gradients are final on the stream that reported them
             if work is not None:
                 work.wait()                                    # stream-ordered: the optimizer stream waits for the collective
+            if self.diag is not None:                          # (bench.py --gpus N: when did this bucket's collective end?)
+                self._diag_comm = torch.cuda.Event(enable_timing=True)
+                self._diag_comm.record(self._opt_stream)
             self.optimizer.step_slice(off, n)
         self._done.add(name)
 
     def _grouped(self, micro_batches):
-        ''' the GroupedBatch of these micro-batches; resident batches (same tensors as a recent call) are grouped once '''
-        key = tuple(t.data_ptr() for mb in micro_batches for t in mb[0])
+        ''' the GroupedBatch of these micro-batches, or None when they cannot run as one pass (micro-batches of different sizes: the
+            group's per-utterance mean would weigh an utterance 1 / B_total instead of the reference's 1 / (accum B_k)).
+            Resident batches are grouped once: the cache is keyed on the address AND the version counter of every source tensor (inputs
+            and targets), so a caller that refills its staging buffers in place gets a fresh group '''
+        if len({mb[0][0].shape[0] for mb in micro_batches}) != 1:
+            return None
+        srcs = [t for mb in micro_batches for part in mb for t in part]
+        key = tuple((t.data_ptr(), t._version) for t in srcs)
         hit = self._groups.get(key)
-        if hit is not None and all(x is y for (a, _), (b, _) in zip(hit[0], micro_batches) for x, y in zip(a, b)):
+        if hit is not None and all(x is y for x, y in zip(hit[0], srcs)):
             return hit[1]
         g = group_micro_batches(micro_batches)
         if len(self._groups) >= 8:
             self._groups.pop(next(iter(self._groups)))
-        self._groups[key] = (list(micro_batches), g)     # (keeps the source tensors alive: their addresses are the key)
+        self._groups[key] = (srcs, g)     # (keeps the source tensors alive: their addresses are part of the key)
         return g
 
     def step(self, micro_batches, iteration):
@@ -179,7 +189,8 @@ class Trainer(object):
             The tensors may live in buffers a later call overwrites (captured steps reuse theirs): consume them -- or enqueue the
             copy that does -- before the next call. '''
         if self.group and len(micro_batches) > 1 and self.model.flat_parameters().is_cuda:
-            micro_batches = [self._grouped(micro_batches)]     # (outside a capture: the concatenation is input staging)
+            g = self._grouped(micro_batches)                   # (outside a capture: the concatenation is input staging)
+            micro_batches = [g] if g is not None else micro_batches
         if self.captured is not None and not self.reducer.active and not self.sectioned:
             return self.captured.step(micro_batches, iteration)
         return self.step_eager(micro_batches, iteration)
@@ -188,7 +199,8 @@ class Trainer(object):
         ''' the step as individual launches (also what a capture records) '''
         hp, model = self.hp, self.model
         if self.group and len(micro_batches) > 1 and model.flat_parameters().is_cuda:
-            micro_batches = [self._grouped(micro_batches)]
+            g = self._grouped(micro_batches)
+            micro_batches = [g] if g is not None else micro_batches     # ragged micro-batches: one pass each, as the reference
         accum = len(micro_batches)
         lr = update_learning_rate(hp, iteration)
         self.optimizer.param_groups[0]['lr'] = lr
@@ -212,6 +224,9 @@ class Trainer(object):
                                            bounds=mb.bounds if isinstance(mb, GroupedBatch) else None)
             total = terms if total is None else ops.add_(total, terms)
         main = torch.cuda.current_stream()
+        if self.diag is not None:                   # the last backward kernel of the launch stream is queued: an event behind it
+            bwd_end = torch.cuda.Event(enable_timing=True)
+            bwd_end.record(main)
         if self._sectioned_now:
             assert self._done == set(sec for sec, _, _ in self.reducer.buckets), 'a gradient bucket was never reported'
             main.wait_stream(self._opt_stream)      # every slice update (and with it every all-reduce) is behind us
@@ -219,7 +234,13 @@ class Trainer(object):
             gnorm_sq = self.optimizer.end_step()
         else:
             self.reducer.wait()
+            if self.diag is not None:
+                self._diag_comm = torch.cuda.Event(enable_timing=True)
+                self._diag_comm.record(main)        # (whole-buffer optimizer: the launch stream has waited for every collective)
             gnorm_sq = self.optimizer.step()
+        if self.diag is not None and self._diag_comm is not None:
+            self.diag.append((bwd_end, self._diag_comm))   # elapsed(bwd_end -> end of the last all-reduce) = communication the backward did not hide
+            self._diag_comm = None
         model.zero_grad()
         if accum > 1:
             ops.scale_(total, 1. / accum)
@@ -496,6 +517,9 @@ def train(gpu, hparams, log_file):
             held.append(batch)
             if len(held) == hparams.accumulation_steps:
                 merged, nmax, sizes = group_host_batches(held)
+                # (the train loader drops its last partial batch, data_loader.py:238; a ragged group would weigh utterances 1 / B_total
+                # instead of the reference's 1 / (accum B_k) -- ADVICE r5)
+                assert len(set(sizes)) == 1, f'micro-batches of different sizes {sizes}: set hparams.group_micro_batches = False'
                 held.clear()
                 yield merged, (nmax, sizes)
 
