@@ -2,7 +2,7 @@
 # Kernels of the built library that use scratch memory (register spills), from the code-object metadata of every csrc/*.o:
 #   tools/scratch_report.sh            -> one line per kernel with private_segment_fixed_size > 0 (nothing = no spills)
 L=/opt/rocm/lib/llvm/bin
-D=$(dirname "$0")/../ubisoft-laforge-daft-exprt_amd/csrc
+D=$(dirname "$0")/../ubisoft-laforge-daft-exprt_amd/build/obj
 T=$(mktemp -d)
 for o in $D/*.o; do
   f=$(basename $o .o)

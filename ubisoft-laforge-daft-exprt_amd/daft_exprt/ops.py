@@ -393,8 +393,17 @@ def wgrad_multi_ws_floats(shapes):
     return sum(H.lib().dx_conv1d_wgrad_ws_floats(*s) for s in shapes)
 
 
+_WS_FLOATS = {}
+
+
 def wgrad_ws_floats(B, N, Cin, Cout, taps):
-    return H.lib().dx_conv1d_wgrad_ws_floats(B, N, Cin, Cout, taps)
+    ''' (a pure function of the shape, asked four times per flush of an FFT block's weight gradients: remembered -- the phoneme-level
+        stretches of the backward pass are host-bound) '''
+    key = (B, N, Cin, Cout, taps)
+    v = _WS_FLOATS.get(key)
+    if v is None:
+        v = _WS_FLOATS[key] = H.lib().dx_conv1d_wgrad_ws_floats(B, N, Cin, Cout, taps)
+    return v
 
 
 
