@@ -451,6 +451,9 @@ def main():
     ap.add_argument('--pool', type=int, default=4, help='distinct synthetic batches cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-probe', action='store_true')
+    ap.add_argument('--cpu-utts', type=int, default=8, help='utterances of the bench batch the cpu_baseline leg steps through (48 = the whole batch, '
+                    '~20 s per step: BASELINE.md 4; the default keeps the default run within a few minutes)')
+    ap.add_argument('--cpu-steps', type=int, default=3, help='timed steps of the cpu_baseline leg (after 1 warm-up)')
     ap.add_argument('--graph', action='store_true', help='replay each resident batch\'s step as ONE captured hipGraph (train.CapturedStep) instead of '
                     'launching its ~300 kernels from the host (measured: a tie at B = 48, see DESIGN 5)')
     ap.add_argument('--no-secondary', action='store_true',
@@ -623,7 +626,7 @@ def main():
     if rank == 0:
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(hp, cpu_batches[0])
+            cpu = cpu_baseline(hp, cpu_batches[0], n_utt=args.cpu_utts, steps=args.cpu_steps)
         out = {'metric': 'training mel-frames/sec', 'value': done_frames / elapsed, 'unit': 'mel-frames/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',

@@ -4,7 +4,7 @@
 # kernel trace + step timeline, three separate PMC passes (FETCH_SIZE / WRITE_SIZE / MFMA busy: they do not fit the TCC
 # slots together, and gpurun refuses --pmc combined with the other trace domains), bench lines of C2 / C5 / C4.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -46,5 +46,7 @@ python bench.py --workload synth --batch 256 --steps 10 --warmup 3 > $OUT/${TAG}
 # hooks and the per-bucket optimizer cost before any byte crosses xGMI
 DX_FORCE_DIST=1 python bench.py --no-secondary --no-cpu-baseline 2> $OUT/bench_rccl.err | grep "^{" > $OUT/${TAG}_bench_one_rank_rccl.json
 grep "bench rank" $OUT/bench_rccl.err > $OUT/${TAG}_one_rank_rccl_reducer.txt
+# the CPU oracle on the WHOLE B = 48 bench batch, 1 warm-up + 5 timed steps (the default run keeps its 8-utterance sample)
+python bench.py --cpu-utts 48 --cpu-steps 5 --no-secondary --no-probe --steps 5 2>> $OUT/bench.err | python -c "import sys, json; d = json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(json.dumps(d['cpu_baseline'], indent=1))" > $OUT/${TAG}_cpu_baseline_full_batch.json
 cat $OUT/counters_summary.txt
 head -c 400 $OUT/${TAG}_bench.json; echo
