@@ -1066,30 +1066,21 @@ __global__ __launch_bounds__(WR_THREADS, 2) void conv_wreg_kernel(ConvArgs p, in
 // main loop runs at a third of the matrix rate: weights (24 KB per K chunk) and activations (8 KB) share one LDS ring filled by
 // LDS-DMA, whose issue -> landed latency is ~1 us under load, so the bytes a CU can have in flight (two ring stages) cap the
 // stream at ~30 GB/s per CU; 4 x 2 register blocking needs 0.75 KB of LDS fragments per MFMA on top.  Here
-//   * the workgroup is 4 waves, ONE per SIMD, with the full 512-register file each: wave (wk, wc) owns ALL rows of the tile
-//     (<= 8 blocks of 32) x the channel half wc (2 blocks of 32) for the K half wk (the 16-channel half wk of every 32-channel
-//     chunk, all taps): <= 8 x 2 MFMA tiles = 256 accumulator registers;
-//   * its weight fragments come straight from L2 into registers: the weights are stored in fragment order
-//     (dx_pack_frag_major: [chunk][tap][half][channel block][lane][8], a fragment is one contiguous KiB), every fragment is read by
-//     exactly ONE wave of the workgroup -- 786 KB per CU per launch (with the waves split rows x K instead, the two row halves
-//     fetched every fragment twice and the kernel sat on the ~13 TB/s L2 -> register ceiling of the chip) -- and a wave keeps
-//     4 chunks (24 KiB) in flight in 96 registers: the register file is the weight ring, LDS holds activations only;
-//   * the haloed activation tile (<= 258 rows x 32 channels per chunk, 17 KB) runs through a 4-stage LDS-DMA ring issued by the
-//     same waves (inline asm: hipcc would drain every counted load before the first LDS read that follows a DMA it knows of);
-//     the two channel halves read the same activation fragments: 0.5 KB of LDS per MFMA;
-//   * after the last chunk the two K halves swap one channel block per row block through LDS and add, which leaves wave
-//     (wk, wc) with the complete rows of channel block 2 wc + wk for the LayerNorm epilogues (forward LayerNorm: dx_conv1d_ln;
-//     backward: dx_conv1d_lnbwd), the row-wise code of conv_gemm_kernel run by one 256-thread team.
+//   * the workgroup is 4 waves, ONE per SIMD, with the full 512-register file each (accumulators in AGPRs), and the contraction
+//     is split between the waves (the comment inside the kernel has the details): the register file is the weight ring -- the
+//     weights are stored in fragment order (dx_pack_frag_major: a fragment is one contiguous KiB), come straight from L2 into
+//     registers, every fragment read by exactly ONE wave of the workgroup: 786 KB per CU per launch -- and LDS holds activations only;
+//   * the haloed activation slabs go through per-wave LDS-DMA rings issued by the waves themselves (inline asm: hipcc would drain
+//     every counted load before the first LDS read that follows a DMA it knows of);
+//   * after the last step the partial tiles of the K slices meet through LDS, which leaves wave w with the complete rows of channel
+//     block w for the LayerNorm epilogues (forward LayerNorm: dx_conv1d_ln; backward: dx_conv1d_lnbwd), the row-wise code of
+//     conv_gemm_kernel run by one 256-thread team.
 // The padding rows of the batch (an equal share per workgroup, as in the ring kernel) are zero-filled after the epilogue.
-constexpr int SK_THREADS = 256, SK_S = 4, SK_NB = 4, SK_MAXP = 5;
-// DX_SK_V: main loop of conv_sk_kernel.  1 = rounds 3-5 (K halves x channel halves, one shared activation ring, a workgroup barrier per
-// 32-channel chunk); 2 (round 6, default) = FOUR K slices, one per wave, every wave on its own -- see the comment in the kernel.
-#ifndef DX_SK_V
-#define DX_SK_V 2
-#endif
-#ifndef SK4_ABL
-#define SK4_ABL 0   // development ablations of the DX_SK_V == 2 main loop (wrong results): 1 no fragment loads, 2 no LDS-DMA, 4 no MFMAs, 8 no LDS reads, 16 no epilogue
-#endif
+// (Rounds 3-5 split the contraction two ways x two channel halves over ONE shared activation ring with a workgroup barrier per
+//  32-channel chunk: 36 % matrix-pipe issue inside its compute phase, 620 cycles of hand-over per chunk; same-box A/B against the
+//  loop below: 6.39 -> 6.27 ms per training step, DESIGN 5.  That loop, the main-loop ablation switches and an LDS-staged store of
+//  the second GEMM's rows (53.9 vs 51.1 us) were deleted after their measurements.)
+constexpr int SK_THREADS = 256;
 constexpr int SK4_MAXNA = 6, SK4_S = 3, SK4_NPMAX = (SK4_MAXNA * 32 + 2 + 15) / 16, SK4_WAVE_EL = SK4_S * SK4_NPMAX * 512;
 template <int N>
 __device__ __forceinline__ void sk_wait_vmcnt_c() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -1099,15 +1090,6 @@ __device__ __forceinline__ void sk_dma16(const void* gsrc, unsigned lds_dst) {  
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
-__device__ __forceinline__ void sk_wait_vmcnt(int n) {   // s_waitcnt vmcnt(n), n wave-uniform
-  switch (n) {
-#define DX_VMW(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
-    DX_VMW(18) DX_VMW(19) DX_VMW(20) DX_VMW(21) DX_VMW(22) DX_VMW(23) DX_VMW(24) DX_VMW(25) DX_VMW(26) DX_VMW(27) DX_VMW(28)
-#undef DX_VMW
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-}
-
 template <int LNM>
 __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
   typedef bf16_t TC;
@@ -1115,13 +1097,8 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
   constexpr int LN = LNM == 3 ? 2 : LNM;
   constexpr bool LNFILM = LNM == 2;
   constexpr int TAPS = 3, HALO = 1, STG_LD = BN + 4, STG_BYTES = 64 * STG_LD * 4;
-#if DX_SK_V == 2
   constexpr int MAXBLK = SK4_MAXNA;
   constexpr int RING_BYTES = 4 * SK4_WAVE_EL * 2, XCH_BYTES = 24 * 4096;
-#else
-  constexpr int MAXBLK = 8, AROWS = 32 * MAXBLK + TAPS - 1, AR16 = (AROWS + 15) & ~15, STAGE_EL = AR16 * 32;
-  constexpr int RING_BYTES = SK_S * STAGE_EL * 2, XCH_BYTES = 4 * MAXBLK * 16 * 64 * 4;
-#endif
   constexpr int SMEM_BYTES = RING_BYTES > XCH_BYTES ? (RING_BYTES > STG_BYTES ? RING_BYTES : STG_BYTES) : (XCH_BYTES > STG_BYTES ? XCH_BYTES : STG_BYTES);
   __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
   TC* ring = reinterpret_cast<TC*>(smem);
@@ -1134,20 +1111,15 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
   const int b = e.x, n0_tile = e.y, h_tile = e.z, fill_per = e.w;
   const int N = p.N, Cin = p.Cin;
   const int len = p.mask_len ? (int)p.mask_len[b] : N;
-  // a tile taller than the accumulators of the main loop hold (DX_SK_V == 2: 5 row blocks) is two workgroups' work: blockIdx.y = 1 takes the
+  // a tile taller than the accumulators of the main loop hold (6 row blocks) is two workgroups' work: blockIdx.y = 1 takes the
   // rows from 128 on (and exits at once for every other tile); the grid is (tiles, 2) there
-#if DX_SK_V == 2
   const bool tall = h_tile > 32 * SK4_MAXNA;
   if (blockIdx.y && !tall) return;
   const int n0 = n0_tile + (int)blockIdx.y * 128, h = tall ? (blockIdx.y ? h_tile - 128 : 128) : h_tile;
-#else
-  const int n0 = n0_tile, h = h_tile;
-#endif
   if (h > 0) {
     const TC* X = reinterpret_cast<const TC*>(p.x) + (size_t)b * N * p.ldx;
     const int nk = Cin >> 5;
-#if DX_SK_V == 2
-    // ---- main loop, round 6.  The contraction (Cin x 3 taps) is split FOUR ways inside the workgroup: wave w takes the 32-channel
+    // ---- main loop (round 6).  The contraction (Cin x 3 taps) is split FOUR ways inside the workgroup: wave w takes the 32-channel
     // chunks 4 s + w (s = "step") with all three taps, for ALL rows of the tile (<= 5 blocks of 32) and ALL 128 output channels:
     // <= 5 x 4 MFMA tiles = 320 accumulator registers.  Nothing is shared between the waves until the end:
     //   * the activation slab of a wave's chunk (<= 162 rows x 32 channels, <= 11 KiB) goes through the wave's OWN 3-stage LDS-DMA
@@ -1159,9 +1131,8 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
     //   * after the last step the four partial tiles of every (row block, channel block) meet through LDS, two row blocks per pass;
     //     local channel block j of wave w is block j ^ w, so that local 0 is the one the wave keeps (static register indices) and
     //     the sum runs in the fixed order own + (w ^ 1) + (w ^ 2) + (w ^ 3): results stay run-to-run reproducible.
-    // Why: the rounds 3-5 loop (DX_SK_V == 1) ran the matrix pipe at ~36 % inside its compute phase and lost another 620 cycles per
-    // chunk to the hand-over (DMA wait + barrier): one wave per SIMD in lock step with three others exposes every latency.  Tiles of
-    // 129..160 rows (the balanced plan of a B = 48 batch: H = 124..135) also ran its 8-block code path: 48 MFMAs per chunk for 30.
+    // Why: one wave per SIMD in lock step with three others (the rounds 3-5 loop: a workgroup barrier per chunk) exposes every latency.
+    // Tiles of 129..160 rows (the balanced plan of a B = 48 batch: H = 124..135) also ran that loop's 8-block code path: 48 MFMAs per chunk for 30.
     f32x16 fin[SK4_MAXNA];
     {
       const int nblk = __builtin_amdgcn_readfirstlane((h + 31) >> 5);     // live 32-row blocks, 1 .. 6
@@ -1189,8 +1160,10 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
         static_assert(3 * STAGE_EL <= SK4_WAVE_EL, "ring stage");
         const int skw = wave % KS, scw = wave / KS;
         const int ns = nk / KS;                                             // steps (launcher: Cin % 128 == 0, Cin >= 256)
-        // every workgroup walks the steps in its own rotation (see DX_SK_V == 1: the workgroups of an XCD would otherwise ask its L2
-        // for the same weight lines at the same time)
+        // every workgroup walks the steps in its own rotation: workgroup L runs on XCD L % 8, and the 32 workgroups of an XCD start within a
+        // microsecond of each other -- in the same order they would all ask the XCD's L2 for the same weight lines at the same time (one channel
+        // serves them one after the other: measured 30 GB/s per CU of L2 hits, a quarter of what the L2 delivers to CUs that read different
+        // lines).  The fp32 sums of different tiles then run in different step orders (each still fixed, so results stay reproducible)
         const int soff = (int)((blockIdx.x >> 3) % (unsigned)ns);
         auto kc_of = [&](int s) { int t = s + soff; if (t >= ns) t -= ns; return KS * t + skw; };
         const int jx = skw * 512, jb = scw * NCB * 512;
@@ -1239,24 +1212,23 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
           const TC* An = ringw + stg1 * STAGE_EL;
           auto sub = [&](auto q_tag) {
             constexpr int Q = decltype(q_tag)::value, SL = Q % RQ;
-            if (Q < 5) { if (!(SK4_ABL & 8)) read_a(Ar, Q + 1, a[(Q + 1) & 1]); }
+            if (Q < 5) read_a(Ar, Q + 1, a[(Q + 1) & 1]);
             else if (more) {
               // the slab of step s + 1 must have landed.  Behind its last piece in this wave's queue: the fragment loads of the rest
               // of that step (s >= 1: NCB (6 - QL); s == 0: the prologue's NCB RQ), and of this step's sub-steps 0..4 (5 NCB) with
               // the pieces issued beside them (P5, when step s + 2 exists).  hipcc does not see the pieces: its own waits are early.
-              if (SK4_ABL & 3) sk_wait_vmcnt_c<0>();
-              else if (s == 0) { if (dma) sk_wait_vmcnt_c<NCB * RQ + 5 * NCB + P5>(); else sk_wait_vmcnt_c<NCB * RQ + 5 * NCB>(); }
+              if (s == 0) { if (dma) sk_wait_vmcnt_c<NCB * RQ + 5 * NCB + P5>(); else sk_wait_vmcnt_c<NCB * RQ + 5 * NCB>(); }
               else { if (dma) sk_wait_vmcnt_c<NCB * (6 - QL) + 5 * NCB + P5>(); else sk_wait_vmcnt_c<NCB * (6 - QL) + 5 * NCB>(); }
-              if (!(SK4_ABL & 8)) read_a(An, 0, a[0]);
+              read_a(An, 0, a[0]);
             }
             __builtin_amdgcn_sched_barrier(0);
             constexpr int HALF = NA / 2;
 #pragma unroll
             for (int i = 0; i < HALF; ++i)
 #pragma unroll
-              for (int j = 0; j < NCB; ++j) if (!(SK4_ABL & 4)) dx_mma(acc[i][j], a[Q & 1][i], bq[SL][j]);
+              for (int j = 0; j < NCB; ++j) dx_mma(acc[i][j], a[Q & 1][i], bq[SL][j]);
             __builtin_amdgcn_sched_barrier(0);
-            if (dma && !(SK4_ABL & 2)) {
+            if (dma) {
 #pragma unroll
               for (int t = first(Q); t < first(Q) + dist(Q); ++t) piece(t, kc2, stg2);
             }
@@ -1264,11 +1236,12 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
 #pragma unroll
             for (int i = HALF; i < NA; ++i)
 #pragma unroll
-              for (int j = 0; j < NCB; ++j) if (!(SK4_ABL & 4)) dx_mma(acc[i][j], a[Q & 1][i], bq[SL][j]);
+              for (int j = 0; j < NCB; ++j) dx_mma(acc[i][j], a[Q & 1][i], bq[SL][j]);
             __builtin_amdgcn_sched_barrier(0);
             // refill the slots just read with sub-step Q + RQ (UNCONDITIONAL: past the end it re-reads -- a load that may not execute
-            // makes hipcc assume the worst at every use, see DX_SK_V == 1)
-            if (!(SK4_ABL & 1)) load_b(Q + RQ < 6 ? kc0 : kc1, (Q + RQ) % 6, bq[SL]);
+            // makes hipcc assume the worst at every use: with a condition around them it drained the whole queue, vmcnt(0), in front of the
+            // first MFMA that follows)
+            load_b(Q + RQ < 6 ? kc0 : kc1, (Q + RQ) % 6, bq[SL]);
           };
           sub(std::integral_constant<int, 0>{});
           sub(std::integral_constant<int, 1>{});
@@ -1328,164 +1301,6 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
       else mainloop(std::integral_constant<int, 1>{}, K4);
     }
 #define DX_SK_FIN(i) fin[i]
-    if (SK4_ABL & 16) {
-      float t = 0.f;
-#pragma unroll
-      for (int i = 0; i < SK4_MAXNA; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t += fin[i][r];
-      if (t == 12345.678f) p.ln.y_lp ? (void)(reinterpret_cast<float*>(p.ln.y_lp)[tid] = t) : (void)0;
-      return;
-    }
-#else
-    f32x16 acc[MAXBLK][2];
-#pragma unroll
-    for (int i = 0; i < MAXBLK; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int nA = (h + TAPS - 1 + 15) >> 4;                       // 16-row pieces of the haloed activation tile
-    const int mine = __builtin_amdgcn_readfirstlane(nA > wave ? (nA - wave + 3) >> 2 : 0);   // pieces wave, wave + 4, ... are this wave's
-    const TC* src[SK_MAXP];
-    unsigned dst[SK_MAXP];
-#pragma unroll
-    for (int t = 0; t < SK_MAXP; ++t) {
-      const int q = wave + 4 * t;
-      const int r = q * 16 + (lane >> 2);                          // row of the tile image this lane fills
-      const int c = (lane & 3) ^ ((r >> 2) & 3);                   // source chunk that belongs at position lane & 3 (lds_at)
-      const int n = n0 + r - HALO;
-      const TC* sp = reinterpret_cast<const TC*>(dx_zero_page) + c * 8;
-      if (q < nA && r < h + TAPS - 1 && n >= 0 && n < N) sp = X + (long)n * p.ldx + c * 8;
-      src[t] = sp;
-      dst[t] = (unsigned)(q * 512 * 2);
-    }
-    const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
-    auto issue_dma = [&](int kc, int buf) {
-#pragma unroll
-      for (int t = 0; t < SK_MAXP; ++t)
-        if (t < mine) sk_dma16(src[t] + kc * 32, __builtin_amdgcn_readfirstlane(ring_base + (unsigned)(buf * STAGE_EL * 2) + dst[t]));
-    };
-    // weight fragments of this wave: K half wk, channel blocks 2 wc + (j ^ wk) for the LOCAL index j -- local 0 is the block the
-    // wave keeps after the exchange (2 wc + wk), local 1 the one it hands to its partner: static register indices either way.
-    // Fragment (chunk kc, tap, half, block c) sits at ((kc * 3 + tap) * 2 + half) * 2048 + c * 512 elements.
-    const TC* wp = reinterpret_cast<const TC*>(p.w_frag) + (size_t)wk * 2048 + (size_t)(2 * wc) * 512 + lane * 8;
-    const int jflip = wk * 512;
-    frag_t bq[SK_NB][TAPS][2];
-    auto load_b = [&](int kc, int tap, frag_t* d) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) d[j] = *reinterpret_cast<const frag_t*>(wp + (size_t)(kc * 3 + tap) * 4096 + ((j * 512) ^ jflip));
-    };
-    const int nblk = __builtin_amdgcn_readfirstlane((h + 31) >> 5);   // live 32-row blocks
-    // Every workgroup walks the K chunks in its own rotation: workgroup L runs on XCD L % 8, and the 32 workgroups of an XCD
-    // start within a microsecond of each other -- in the same order they would all ask the XCD's L2 for the same weight lines
-    // at the same time (one channel serves them one after the other: measured 30 GB/s per CU of L2 hits, a quarter of what the
-    // L2 delivers to CUs that read different lines).  The fp32 sums of different tiles then run in different chunk orders
-    // (each still fixed, so results stay reproducible).
-    const int koff = (int)((blockIdx.x >> 3) % (unsigned)nk);
-    auto kc_of = [&](int it) { const int k = it + koff; return k >= nk ? k - nk : k; };
-    const bool counted = nk >= 8;                                      // the vmcnt arithmetic below holds (else: drain)
-#pragma unroll
-    for (int st = 0; st < SK_S - 1; ++st)
-      if (st < nk) issue_dma(kc_of(st), st);
-#pragma unroll
-    for (int nb = 0; nb < SK_NB; ++nb)
-#pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) load_b(kc_of(nb < nk ? nb : nk - 1), tap, bq[nb][tap]);
-    // one K chunk.  Memory operations of a wave in program order: [DMA pieces of chunk it + S - 1] [6 fragment loads of chunk
-    // it + NB] per iteration, so when the pieces of chunk `it` must have landed, 6 (S - 1) fragment loads and the DMA pieces of
-    // the (up to S - 2) iterations in between may still be in flight: 18 + mine * min(2, nk - 1 - it) (S = 4; prologue-issued
-    // chunks have more behind them: the count stays a lower bound).  The fragment loads are UNCONDITIONAL (past the last chunk they
-    // re-read it): hipcc counts them itself, and a load that may not execute makes it assume the worst at every use -- with
-    // `if (it + NB < nk)` around them it drained the whole queue (vmcnt(0)) in front of the first MFMA of every chunk.  It does
-    // not see the DMA pieces: its waits are early, never late.
-    auto chunk = [&](int it, auto slot_tag, auto na_tag) {
-      constexpr int U = decltype(slot_tag)::value, NA = decltype(na_tag)::value;
-      const int behind = nk - 1 - it;
-      if (counted) sk_wait_vmcnt(18 + mine * (behind > 2 ? 2 : behind));
-      else sk_wait_vmcnt(0);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const TC* Ar = ring + (it % SK_S) * STAGE_EL;
-      const int knext = kc_of(it + SK_NB < nk ? it + SK_NB : nk - 1);
-      frag_t a[2][NA];
-#pragma unroll
-      for (int i = 0; i < NA; ++i) a[0][i] = *reinterpret_cast<const frag_t*>(&Ar[lds_at(i * 32 + l31, wk * 2 + g)]);
-#pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) {
-        if (tap + 1 < TAPS) {                        // the next tap's activation fragments are requested before this tap's MFMAs
-#pragma unroll
-          for (int i = 0; i < NA; ++i) a[(tap + 1) & 1][i] = *reinterpret_cast<const frag_t*>(&Ar[lds_at(i * 32 + l31 + tap + 1, wk * 2 + g)]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (NA >= 4) {
-          // one wave per SIMD: a vector-memory instruction that finds the CU's request queue full stalls the wave, and MFMAs it has
-          // not issued yet with it.  The CU fetches ~25 B/clk from L2, a chunk is 8 KiB-instructions per wave for 24 MFMAs: spread
-          // the requests through the MFMA sequence (the matrix pipe works off what was issued while the next request waits)
-          // instead of issuing them in clusters between the taps.
-          constexpr int HALF = NA / 2;
-#pragma unroll
-          for (int i = 0; i < HALF; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) dx_mma(acc[i][j], a[tap & 1][i], bq[U][tap][j]);
-          __builtin_amdgcn_sched_barrier(0);
-          if (tap == 0) { if (it + SK_S - 1 < nk) issue_dma(kc_of(it + SK_S - 1), (it + SK_S - 1) % SK_S); }
-          else load_b(knext, tap - 1, bq[U][tap - 1]);          // the previous tap's slots: every MFMA that read them has been issued
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = HALF; i < NA; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) dx_mma(acc[i][j], a[tap & 1][i], bq[U][tap][j]);
-          __builtin_amdgcn_sched_barrier(0);
-          if (tap == TAPS - 1) load_b(knext, tap, bq[U][tap]);
-        } else {
-          if (tap == 0) { if (it + SK_S - 1 < nk) issue_dma(kc_of(it + SK_S - 1), (it + SK_S - 1) % SK_S); }
-#pragma unroll
-          for (int i = 0; i < NA; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) dx_mma(acc[i][j], a[tap & 1][i], bq[U][tap][j]);
-          __builtin_amdgcn_sched_barrier(0);
-          load_b(knext, tap, bq[U][tap]);              // refill the slots just read: chunk it + NB
-        }
-      }
-    };
-    auto mainloop = [&](auto na_tag) {               // nk % 4 == 0 (launcher): four chunks per trip, the fragment ring bq[] is indexed statically
-      for (int it = 0; it < nk; it += SK_NB) {
-        chunk(it, std::integral_constant<int, 0>{}, na_tag);
-        chunk(it + 1, std::integral_constant<int, 1>{}, na_tag);
-        chunk(it + 2, std::integral_constant<int, 2>{}, na_tag);
-        chunk(it + 3, std::integral_constant<int, 3>{}, na_tag);
-      }
-    };
-    if (nblk > 4) mainloop(std::integral_constant<int, 8>{});
-    else if (nblk > 2) mainloop(std::integral_constant<int, 4>{});
-    else if (nblk == 2) mainloop(std::integral_constant<int, 2>{});
-    else mainloop(std::integral_constant<int, 1>{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                   // the ring is dead: exchange / epilogue staging reuse it
-
-    // ---- the two K halves meet: wave (wk, wc) hands its partner (wk ^ 1, wc) the local-1 tiles and adds what it receives to its
-    // local-0 tiles: channel block cb = 2 wc + wk, complete (a + b == b + a: the order of the two halves does not matter)
-    {
-      float* mine_x = xch + (size_t)wave * (MAXBLK * 16 * 64) + lane;
-      const float* part_x = xch + (size_t)(wave ^ 1) * (MAXBLK * 16 * 64) + lane;
-#pragma unroll
-      for (int i = 0; i < MAXBLK; ++i)
-        if (i < nblk) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) mine_x[(i * 16 + r) * 64] = acc[i][1][r];
-        }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < MAXBLK; ++i)
-        if (i < nblk) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][0][r] += part_x[(i * 16 + r) * 64];
-        }
-      __syncthreads();
-    }
-#define DX_SK_FIN(i) acc[i][0]
-#endif
     // ---- LayerNorm epilogue (the PLAN epilogue of conv_gemm_kernel with one 256-thread team)
     constexpr int NCS = LNM == 2 ? 4 : (LNM == 3 ? 2 : 1);
     float csum[NCS][8];
@@ -1503,14 +1318,6 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
     // wave, bias added in the store.
     constexpr int A2_LD = BN + 8, A2_OFF = 64 * 1024, NC2 = LN == 2 ? 1 : 3;
     static_assert(A2_OFF >= STG_BYTES && A2_OFF + 64 * A2_LD * 2 <= SMEM_BYTES, "second-GEMM operand tile must fit beside the staging buffer");
-    // LDS image of the second GEMM's output slab (64 rows x n2 <= 384 channels, bf16; 16 bytes of padding per row: conflict-free 16-byte
-    // writes from the MFMA layout) behind the operand tile -- where the workgroup's LDS has room for it (DX_SK_V == 2)
-    constexpr int Y2_LD = 384 + 8, Y2S_OFF = 82 * 1024;
-#ifndef DX_SK_Y2_STAGE
-#define DX_SK_Y2_STAGE 0   // measured (c2[3] frame-level launch, all outputs): 53.9 us with the image, 51.1 without -- the 8 us the QKV rows cost are their
-#endif                     // 23 MB in a write-bound epilogue, not the shape of the store instructions
-    constexpr bool Y2_STAGE = DX_SK_Y2_STAGE && Y2S_OFF >= A2_OFF + 64 * A2_LD * 2 && Y2S_OFF + 64 * Y2_LD * 2 <= SMEM_BYTES;
-    TC* y2s = reinterpret_cast<TC*>(smem + Y2S_OFF);
     const bool gemm2 = p.ln.y2 != nullptr;
     const int n2 = p.ln.n2, ncb2 = __builtin_amdgcn_readfirstlane(n2 >> 7);      // channel blocks per wave (1 or 3)
     TC* a2 = reinterpret_cast<TC*>(smem + A2_OFF);
@@ -1521,7 +1328,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
         if (c < ncb2) {
           const TC* w2 = reinterpret_cast<const TC*>(p.ln.w2) + (size_t)((c * 4 + wave) * 32 + l31) * BN + g * 8;
 #pragma unroll
-          for (int ks = 0; ks < 8; ++ks) w2f[c][ks] = *reinterpret_cast<const frag_t*>(w2 + ((SK4_ABL & 128) ? 0 : ks * 16));
+          for (int ks = 0; ks < 8; ++ks) w2f[c][ks] = *reinterpret_cast<const frag_t*>(w2 + ks * 16);
         }
     }
     // the per-channel operands of the row passes depend on (b, channel segment) only: loaded ONCE here.  Inside the passes they sat
@@ -1685,7 +1492,7 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
           const frag_t x1 = *reinterpret_cast<const frag_t*>(a2 + (32 + l31) * A2_LD + ks * 16 + g * 8);
 #pragma unroll
           for (int c = 0; c < NC2; ++c)
-            if (c < ncb2 && !(SK4_ABL & 64)) {
+            if (c < ncb2) {
               dx_mma(d2[c][0], w2f[c][ks], x0);
               dx_mma(d2[c][1], w2f[c][ks], x1);
             }
@@ -1720,31 +1527,14 @@ __global__ __launch_bounds__(SK_THREADS, 1) void conv_sk_kernel(ConvArgs p) {
                 P[4 * h2 + k] = sw[0];
                 P[4 * h2 + 2 + k] = sw[1];
               }
-            if constexpr (Y2_STAGE) {   // the slab's rows leave through an LDS image: whole rows per store instruction (below)
-              TC* yl = y2s + (rb * 32 + l31) * Y2_LD + cw + 8 * g;
-              *reinterpret_cast<u32x4*>(yl) = u32x4{P[0], P[1], P[2], P[3]};
-              *reinterpret_cast<u32x4*>(yl + 16) = u32x4{P[4], P[5], P[6], P[7]};
-            } else {
-              const int trow = i * 64 + rb * 32 + l31, n = n0 + trow;
-              if (trow < h && n < N) {
-                TC* yo = reinterpret_cast<TC*>(p.ln.y2) + ((size_t)b * N + n) * n2 + cw + 8 * g;
-                *reinterpret_cast<u32x4*>(yo) = u32x4{P[0], P[1], P[2], P[3]};
-                *reinterpret_cast<u32x4*>(yo + 16) = u32x4{P[4], P[5], P[6], P[7]};
-              }
+            // (through an LDS image of the slab, whole rows per store instruction: measured 53.9 vs 51.1 us -- the 8 us the QKV rows cost are
+            //  their 23 MB in a write-bound epilogue, not the shape of the store instructions)
+            const int trow = i * 64 + rb * 32 + l31, n = n0 + trow;
+            if (trow < h && n < N) {
+              TC* yo = reinterpret_cast<TC*>(p.ln.y2) + ((size_t)b * N + n) * n2 + cw + 8 * g;
+              *reinterpret_cast<u32x4*>(yo) = u32x4{P[0], P[1], P[2], P[3]};
+              *reinterpret_cast<u32x4*>(yo + 16) = u32x4{P[4], P[5], P[6], P[7]};
             }
-          }
-        }
-        if constexpr (Y2_STAGE) {
-          // straight from the MFMA layout a store instruction wrote 32 bytes into each of 32 rows (768 bytes apart): measured 8 us of a
-          // 51 us launch for 23 MB.  From the image: 16 consecutive lanes = 256 contiguous bytes of one row.
-          __syncthreads();
-          const int segs = n2 >> 3;
-          for (int idx = tid; idx < 64 * segs; idx += SK_THREADS) {
-            const int row = idx / segs, seg = idx - row * segs;
-            const int trow = i * 64 + row, n = n0 + trow;
-            if (trow < h && n < N && !(SK4_ABL & 32))
-              *reinterpret_cast<u32x4*>(reinterpret_cast<TC*>(p.ln.y2) + ((size_t)b * N + n) * n2 + seg * 8) =
-                  *reinterpret_cast<const u32x4*>(y2s + row * Y2_LD + seg * 8);
           }
         }
       }
@@ -2071,8 +1861,8 @@ int launch_taps(const ConvArgs& a, int B, int taps, hipStream_t s) {
       // 256 rows): measured 0.35 % of the B = 48 step faster than the ring kernel (frame level 46 vs 50 us, phoneme level 27 vs 33 us),
       // 2.5 % of the B = 256 step slower (several rounds of 256-row tiles: the ring kernel's two epilogue teams win there)
       if (a.plan && taps == 3 && a.w_frag && a.Cin >= 256 && a.Cin % 128 == 0 && (long)B * a.N <= 256L * 256) {
-        // DX_SK_V == 2: tiles of more than 6 row blocks (possible when N > 192) are split between blockIdx.y = 0 and 1
-        dim3 gridp((unsigned)a.plan_tiles, (DX_SK_V == 2 && a.N > 32 * SK4_MAXNA) ? 2u : 1u);
+        // tiles of more than 6 row blocks (possible when N > 192) are split between blockIdx.y = 0 and 1
+        dim3 gridp((unsigned)a.plan_tiles, a.N > 32 * SK4_MAXNA ? 2u : 1u);
         if (film) hipLaunchKernelGGL((conv_sk_kernel<LN>), gridp, dim3(SK_THREADS), 0, s, a);
         else hipLaunchKernelGGL((conv_sk_kernel<LNB>), gridp, dim3(SK_THREADS), 0, s, a);
         DX_LAUNCH_CHECK();
