@@ -14,20 +14,20 @@ from tests.util import gradient_report, make_hparams, no_dropout
 DEV = 'cuda:0'
 
 
-def _hparams(mode, heads, ff, pre, pred):
+def _hparams(mode, heads, ff, pre, pred, kernels=(3, 3, 3)):
     hp = no_dropout(make_hparams(compute_dtype=mode, batch_size=4))
-    hp.prosody_encoder.update(attn_nb_heads=heads[0], conv_channels=pre)
-    hp.phoneme_encoder.update(attn_nb_heads=heads[1], conv_channels=ff)
-    hp.frame_decoder.update(attn_nb_heads=heads[2], conv_channels=ff)
+    hp.prosody_encoder.update(attn_nb_heads=heads[0], conv_channels=pre, conv_kernel=kernels[0])
+    hp.phoneme_encoder.update(attn_nb_heads=heads[1], conv_channels=ff, conv_kernel=kernels[1])
+    hp.frame_decoder.update(attn_nb_heads=heads[2], conv_channels=ff, conv_kernel=kernels[2])
     hp.local_prosody_predictor.update(conv_channels=pred)
     return hp
 
 
-def _run(mode, heads, ff, pre, pred):
+def _run(mode, heads, ff, pre, pred, kernels=(3, 3, 3)):
     from daft_exprt.data_loader import synthetic_batch
     from daft_exprt.loss import DaftExprtLoss
     from daft_exprt.model import DaftExprt
-    hp = _hparams(mode, heads, ff, pre, pred)
+    hp = _hparams(mode, heads, ff, pre, pred, kernels)
     state = fill_params(O.param_shapes(hp))
     model = DaftExprt(hp)
     model.load_state_dict(state)
@@ -66,6 +66,30 @@ def test_variant_architectures_match_the_oracle_fp32(heads, ff, pre, pred):
     assert worst[0][0] <= 1., worst[:5]
 
 
+@pytest.mark.parametrize('kernels', [(1, 1, 1), (3, 1, 3), (1, 3, 1)])
+def test_conv_kernel_1_matches_the_oracle_fp32(kernels):
+    ''' `conv_kernel` 1 (hparams.py:90-128 takes any odd size; model.py:75-94): the FF block's convolutions as linear layers, the
+        pre-net of the prosody encoder with one tap -- on the k = 1 GEMM kernels '''
+    (hp_p, hp_t, hp_g), (or_p, or_t, or_g) = _run('fp32', (8, 2, 2), 1024, 1024, 256, kernels)
+    for k in or_p:
+        a, b = hp_p[k].detach().float().cpu(), or_p[k].detach().float()
+        assert a.shape == b.shape
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-12))
+        assert err <= 2e-4, (k, err)
+    assert abs(float(hp_t[7]) - or_t) <= 1e-4 * abs(or_t), (float(hp_t[7]), or_t)
+    worst = gradient_report(hp_g, or_g, rel=2e-3, floor=2e-5)
+    assert worst[0][0] <= 1., worst[:5]
+
+
+def test_conv_kernel_1_runs_in_bf16():
+    (hp_p, hp_t, hp_g), (or_p, or_t, or_g) = _run('bf16', (8, 2, 2), 1024, 1024, 256, (1, 1, 1))
+    for k in or_p:
+        a, b = hp_p[k].detach().float().cpu(), or_p[k].detach().float()
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-12))
+        assert err <= 6e-2, (k, err)
+    assert abs(float(hp_t[7]) - or_t) <= 2e-2 * abs(or_t)
+
+
 def test_variant_architecture_runs_in_bf16():
     (hp_p, hp_t, hp_g), (or_p, or_t, or_g) = _run('bf16', (4, 1, 4), 512, 512, 128)
     for k in or_p:
@@ -83,5 +107,9 @@ def test_unsupported_architectures_say_so():
         DaftExprt(hp)
     hp = make_hparams()
     hp.prosody_encoder['hidden_embed_dim'] = 256
+    with pytest.raises(NotImplementedError):
+        DaftExprt(hp)
+    hp = make_hparams()
+    hp.frame_decoder['conv_kernel'] = 5
     with pytest.raises(NotImplementedError):
         DaftExprt(hp)
