@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DX_ABI_VERSION 12
+#define DX_ABI_VERSION 13
 
 enum { DX_F32 = 0, DX_BF16 = 1, DX_I64 = 2 };
 enum { DX_OK = 0, DX_ERR_ARG = -1, DX_ERR_SHAPE = -2, DX_ERR_DTYPE = -3, DX_ERR_LAUNCH = -4, DX_ERR_UNSUPPORTED = -5 };
@@ -303,16 +303,17 @@ int dx_attention_bwd(const void* qkv, const void* o, const void* d_o, int dtype,
  * kernels only use it as a launch order, so any batch order stays valid. */
 int dx_length_order(const int64_t* lengths, int B, int* order, void* stream);
 
-/* ---- K6: out = base + sum_f conv1d(1 -> 128, k=3)(feat_f) + pos_table[n], zero where n >= lengths[b].
+/* ---- K6: out = base + sum_f conv1d(1 -> 128, k = taps)(feat_f) + pos_table[n], zero where n >= lengths[b].
  * Energy / pitch embeddings + positional add + mask of the prosody encoder (model.py:400-414); the duration /
  * energy / pitch projections of the upsampler (model.py:618-628).  feats / ws / biases are HOST arrays of
- * nfeat (<= 3) device pointers: feat (B, N), w (128, 1, 3), bias (128).  base, pos_table, lengths may be NULL. */
+ * nfeat (<= 3) device pointers: feat (B, N), w (128, 1, taps), bias (128).  base, pos_table, lengths may be NULL.
+ * taps (ABI v13): 3 (the published conv_kernel) or 1. */
 int dx_scalar_embed_fwd(const float* base, const float* const* feats, const float* const* ws,
                         const float* const* biases, int nfeat, const float* pos_table, const int64_t* lengths,
-                        float* out, int B, int N, int C, void* stream);
+                        float* out, int B, int N, int C, int taps, void* stream);
 /* dbase = dout * mask (may be NULL); dws / dbiases are accumulated with atomics. */
 int dx_scalar_embed_bwd(const float* dout, const float* const* feats, int nfeat, const int64_t* lengths,
-                        float* dbase, float* const* dws, float* const* dbiases, int B, int N, int C, void* stream);
+                        float* dbase, float* const* dws, float* const* dbiases, int B, int N, int C, int taps, void* stream);
 
 /* ---- K7/K8: out[b, n] = table[ids[b, n]] + pos_table[n] for n < lengths[b], else 0 (model.py:497-504; the
  * positional gather replaces the host loops of PositionalEncoding.forward, model.py:132-150). */

@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     assert len(protos) >= 4
     for name, _, _ in protos:
         assert hasattr(lib, name), f'{name} declared in include/daft_exprt_hip.h but not exported'
-    assert lib.dx_abi_version() == 12
+    assert lib.dx_abi_version() == 13
     assert lib.dx_last_error() is not None
 
 

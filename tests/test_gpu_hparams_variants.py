@@ -66,10 +66,10 @@ def test_variant_architectures_match_the_oracle_fp32(heads, ff, pre, pred):
     assert worst[0][0] <= 1., worst[:5]
 
 
-@pytest.mark.parametrize('kernels', [(3, 1, 1), (3, 1, 3), (3, 3, 1)])
+@pytest.mark.parametrize('kernels', [(1, 1, 1), (3, 1, 3), (1, 3, 1)])
 def test_conv_kernel_1_matches_the_oracle_fp32(kernels):
-    ''' `conv_kernel` 1 in the phoneme encoder / frame decoder (hparams.py:90-128 takes any odd size; model.py:75-94): the FF block's
-        convolutions as linear layers, on the k = 1 GEMM kernels '''
+    ''' `conv_kernel` 1 (hparams.py:90-128 takes any odd size; model.py:75-94): the FF block's convolutions as linear layers, the
+        pre-net and the scalar embeddings of the prosody encoder with one tap -- on the k = 1 GEMM kernels '''
     (hp_p, hp_t, hp_g), (or_p, or_t, or_g) = _run('fp32', (8, 2, 2), 1024, 1024, 256, kernels)
     for k in or_p:
         a, b = hp_p[k].detach().float().cpu(), or_p[k].detach().float()
@@ -82,7 +82,7 @@ def test_conv_kernel_1_matches_the_oracle_fp32(kernels):
 
 
 def test_conv_kernel_1_runs_in_bf16():
-    (hp_p, hp_t, hp_g), (or_p, or_t, or_g) = _run('bf16', (8, 2, 2), 1024, 1024, 256, (3, 1, 1))
+    (hp_p, hp_t, hp_g), (or_p, or_t, or_g) = _run('bf16', (8, 2, 2), 1024, 1024, 256, (1, 1, 1))
     for k in or_p:
         a, b = hp_p[k].detach().float().cpu(), or_p[k].detach().float()
         err = float((a - b).abs().max() / (b.abs().max() + 1e-12))
@@ -113,7 +113,4 @@ def test_unsupported_architectures_say_so():
     hp.frame_decoder['conv_kernel'] = 5
     with pytest.raises(NotImplementedError):
         DaftExprt(hp)
-    hp = make_hparams()
-    hp.prosody_encoder['conv_kernel'] = 1
-    with pytest.raises(NotImplementedError):
-        DaftExprt(hp)
+

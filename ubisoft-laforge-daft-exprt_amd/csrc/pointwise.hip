@@ -19,7 +19,7 @@ constexpr int C128 = 128;
 struct ScalarEmbedArgs {
   const float* base;          // (B, N, C) or null
   const float* feat[3];       // (B, N) each
-  const float* w[3];          // (C, 1, 3) each
+  const float* w[3];          // (C, 1, taps) each
   const float* bias[3];       // (C) each
   int nfeat;
   const float* pos;           // (max_len, C) or null
@@ -27,6 +27,7 @@ struct ScalarEmbedArgs {
   float* out;                 // (B, N, C)
   int N;
   long rows;
+  int taps;                   // 3 ("same" padding, one halo row each side) or 1
 };
 
 __global__ __launch_bounds__(256) void scalar_embed_fwd_kernel(ScalarEmbedArgs a) {
@@ -40,9 +41,13 @@ __global__ __launch_bounds__(256) void scalar_embed_fwd_kernel(ScalarEmbedArgs a
     if (a.base) v = a.base[row * C128 + c];
     for (int f = 0; f < a.nfeat; ++f) {
       const float* ft = a.feat[f] + (long)b * a.N;
-      const float xm = n > 0 ? ft[n - 1] : 0.f, x0 = ft[n], xp = n + 1 < a.N ? ft[n + 1] : 0.f;
-      const float* w = a.w[f] + c * 3;
-      v += w[0] * xm + w[1] * x0 + w[2] * xp + a.bias[f][c];
+      if (a.taps == 3) {
+        const float xm = n > 0 ? ft[n - 1] : 0.f, x0 = ft[n], xp = n + 1 < a.N ? ft[n + 1] : 0.f;
+        const float* w = a.w[f] + c * 3;
+        v += w[0] * xm + w[1] * x0 + w[2] * xp + a.bias[f][c];
+      } else {
+        v += a.w[f][c] * ft[n] + a.bias[f][c];
+      }
     }
     if (a.pos) v += a.pos[(long)n * C128 + c];
   }
@@ -55,9 +60,10 @@ struct ScalarEmbedBwdArgs {
   int nfeat;
   const int64_t* lengths;     // the forward's mask or null
   float* dbase;               // (B, N, C) = dout * mask, or null
-  float* dw[3];               // (C,1,3) accumulated
+  float* dw[3];               // (C, 1, taps) accumulated
   float* dbias[3];            // (C) accumulated
   int N; int rows_per_block;
+  int taps;
 };
 
 constexpr int SE_MAX_ROWS = 1024;
@@ -100,8 +106,9 @@ __global__ __launch_bounds__(1024) void scalar_embed_bwd_kernel(ScalarEmbedBwdAr
     const int f = idx / (4 * C128), k = (idx / C128) & 3, ch = idx & (C128 - 1);
     const float t = ((red[0][f][k][ch] + red[1][f][k][ch]) + (red[2][f][k][ch] + red[3][f][k][ch])) +
                     ((red[4][f][k][ch] + red[5][f][k][ch]) + (red[6][f][k][ch] + red[7][f][k][ch]));
-    if (k < 3) atomicAdd(a.dw[f] + ch * 3 + k, t);
-    else atomicAdd(a.dbias[f] + ch, t);
+    if (k == 3) atomicAdd(a.dbias[f] + ch, t);
+    else if (a.taps == 3) atomicAdd(a.dw[f] + ch * 3 + k, t);
+    else if (k == 1) atomicAdd(a.dw[f] + ch, t);                 // one tap: the centre sum
   }
 }
 
@@ -431,12 +438,13 @@ __global__ __launch_bounds__(256) void stack_kernel(float* __restrict__ y, Plane
 
 extern "C" int dx_scalar_embed_fwd(const float* base, const float* const* feats, const float* const* ws,
                                    const float* const* biases, int nfeat, const float* pos_table,
-                                   const int64_t* lengths, float* out, int B, int N, int C, void* stream) {
+                                   const int64_t* lengths, float* out, int B, int N, int C, int taps, void* stream) {
   DX_REQUIRE(out && nfeat >= 0 && nfeat <= 3, DX_ERR_ARG, "dx_scalar_embed_fwd: bad arguments");
+  DX_REQUIRE(taps == 1 || taps == 3, DX_ERR_UNSUPPORTED, "dx_scalar_embed_fwd: taps=%d (only 1 and 3)", taps);
   DX_REQUIRE(C == C128, DX_ERR_UNSUPPORTED, "dx_scalar_embed_fwd: C=%d (only 128)", C);
   DX_REQUIRE(B > 0 && N > 0, DX_ERR_SHAPE, "dx_scalar_embed_fwd: empty shape");
   ScalarEmbedArgs a{};
-  a.base = base; a.nfeat = nfeat; a.pos = pos_table; a.lengths = lengths; a.out = out; a.N = N; a.rows = (long)B * N;
+  a.base = base; a.nfeat = nfeat; a.pos = pos_table; a.lengths = lengths; a.out = out; a.N = N; a.rows = (long)B * N; a.taps = taps;
   for (int f = 0; f < nfeat; ++f) { a.feat[f] = feats[f]; a.w[f] = ws[f]; a.bias[f] = biases[f]; }
   hipLaunchKernelGGL(scalar_embed_fwd_kernel, dim3((unsigned)((a.rows + 1) / 2)), dim3(256), 0, (hipStream_t)stream, a);
   DX_LAUNCH_CHECK();
@@ -444,12 +452,13 @@ extern "C" int dx_scalar_embed_fwd(const float* base, const float* const* feats,
 }
 
 extern "C" int dx_scalar_embed_bwd(const float* dout, const float* const* feats, int nfeat, const int64_t* lengths,
-                                   float* dbase, float* const* dws, float* const* dbiases, int B, int N, int C,
+                                   float* dbase, float* const* dws, float* const* dbiases, int B, int N, int C, int taps,
                                    void* stream) {
   DX_REQUIRE(dout && nfeat >= 0 && nfeat <= 3, DX_ERR_ARG, "dx_scalar_embed_bwd: bad arguments");
+  DX_REQUIRE(taps == 1 || taps == 3, DX_ERR_UNSUPPORTED, "dx_scalar_embed_bwd: taps=%d (only 1 and 3)", taps);
   DX_REQUIRE(C == C128, DX_ERR_UNSUPPORTED, "dx_scalar_embed_bwd: C=%d (only 128)", C);
   ScalarEmbedBwdArgs a{};
-  a.dout = dout; a.nfeat = nfeat; a.lengths = lengths; a.dbase = dbase; a.N = N;
+  a.dout = dout; a.nfeat = nfeat; a.lengths = lengths; a.dbase = dbase; a.N = N; a.taps = taps;
   // every workgroup ends with 512-1024 atomics on the same few addresses: few, fat workgroups
   // (same-address atomics serialise at ~50 ns each: ~256 workgroups keep that tail under the time the rows take to stream)
   int rpb = 64;

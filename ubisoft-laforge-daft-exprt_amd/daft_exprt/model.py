@@ -166,15 +166,13 @@ class DaftExprt(nn.Module):
                         (hparams.frame_decoder, 'frame_decoder')):
             # head sizes 16 and 64 (the published 8 / 2 heads) are the tuned attention kernels; 32 and 128 (4 heads / 1 head) run on
             # the same templates untuned (two-pass backward; the 128-wide head keeps one wave per SIMD)
-            # conv_kernel 1 in the phoneme encoder / frame decoder (their FF blocks as two linear layers) runs on the k = 1 GEMM kernels --
-            # generic tiles, LayerNorm-fused epilogues, k = 1 weight gradients -- untuned: the register-weights / split-K kernels are
-            # k = 3 only.  The prosody encoder stays at 3 (its scalar-embedding kernels are written for three taps), and 5 taps have no
-            # kernel (the dead-row contract of DESIGN 2 is derived for a halo of one row per conv)
-            kernels = (3,) if nm == 'prosody_encoder' else (1, 3)
-            if 128 % cfg['attn_nb_heads'] or 128 // cfg['attn_nb_heads'] not in (16, 32, 64, 128) or cfg['conv_kernel'] not in kernels:
+            # conv_kernel 1 (the FF blocks as two linear layers, the prosody encoder's pre-net and scalar embeddings with one tap) runs on
+            # the k = 1 GEMM kernels -- generic tiles, LayerNorm-fused epilogues, k = 1 weight gradients -- untuned: the register-weights
+            # / split-K / wide kernels are k = 3 only.  5 taps have no kernel (the dead-row contract of DESIGN 2 is derived for a halo of
+            # one row per conv)
+            if 128 % cfg['attn_nb_heads'] or 128 // cfg['attn_nb_heads'] not in (16, 32, 64, 128) or cfg['conv_kernel'] not in (1, 3):
                 raise NotImplementedError(f'{nm}: attention kernels exist for attn_nb_heads 8, 4, 2, 1 (head sizes 16 .. 128) and conv '
-                                          f'kernels for conv_kernel {" / ".join(map(str, kernels))}, got attn_nb_heads={cfg["attn_nb_heads"]}, '
-                                          f'conv_kernel={cfg["conv_kernel"]}')
+                                          f'kernels for conv_kernel 1 / 3, got attn_nb_heads={cfg["attn_nb_heads"]}, conv_kernel={cfg["conv_kernel"]}')
         self.cd = torch.bfloat16 if getattr(hparams, 'compute_dtype', 'bf16') == 'bf16' else torch.float32
         self._table = param_table(hparams)
         gen = torch.Generator().manual_seed(int(torch.initial_seed()) & 0x7fffffff)

@@ -510,18 +510,21 @@ def attention_bwd(qkv, o, d_o, lse, lengths, nb_heads, p_drop=0., seed=0, order=
 # ----------------------------------------------------------------------------- pointwise / small heads
 def scalar_embed_fwd(feats, ws, biases, base=None, pos_table=None, lengths=None):
     B, N = feats[0].shape
-    C = ws[0].shape[0]
+    C, taps = ws[0].shape[0], ws[0].shape[2]
+    assert all(tuple(w.shape) == (C, 1, taps) for w in ws)
     out = _empty((B, N, C), dtype=torch.float32, device=feats[0].device)
     H.check(H.lib().dx_scalar_embed_fwd(H.ptr(base), _ptr_array(feats), _ptr_array(ws), _ptr_array(biases), len(feats),
-                                        H.ptr(pos_table), H.ptr(lengths), H.ptr(out), B, N, C, H.stream()))
+                                        H.ptr(pos_table), H.ptr(lengths), H.ptr(out), B, N, C, taps, H.stream()))
     return out
 
 
 def scalar_embed_bwd(dout, feats, dws, dbiases, lengths=None, need_dbase=False):
     B, N, C = dout.shape
     dbase = _empty_like(dout) if need_dbase else None
+    taps = dws[0].shape[2]
+    assert all(tuple(w.shape) == (C, 1, taps) for w in dws)
     H.check(H.lib().dx_scalar_embed_bwd(H.ptr(dout), _ptr_array(feats), len(feats), H.ptr(lengths), H.ptr(dbase),
-                                        _ptr_array(dws), _ptr_array(dbiases), B, N, C, H.stream()))
+                                        _ptr_array(dws), _ptr_array(dbiases), B, N, C, taps, H.stream()))
     return dbase
 
 
