@@ -113,4 +113,12 @@ def test_unsupported_architectures_say_so():
     hp.frame_decoder['conv_kernel'] = 5
     with pytest.raises(NotImplementedError):
         DaftExprt(hp)
+    hp = make_hparams()
+    hp.gaussian_upsampling_module['conv_kernel'] = 1
+    with pytest.raises(NotImplementedError):
+        DaftExprt(hp)
+    hp = make_hparams()
+    hp.local_prosody_predictor['conv_kernel'] = 5
+    with pytest.raises(NotImplementedError):
+        DaftExprt(hp)
 

@@ -173,6 +173,10 @@ class DaftExprt(nn.Module):
             if 128 % cfg['attn_nb_heads'] or 128 // cfg['attn_nb_heads'] not in (16, 32, 64, 128) or cfg['conv_kernel'] not in (1, 3):
                 raise NotImplementedError(f'{nm}: attention kernels exist for attn_nb_heads 8, 4, 2, 1 (head sizes 16 .. 128) and conv '
                                           f'kernels for conv_kernel 1 / 3, got attn_nb_heads={cfg["attn_nb_heads"]}, conv_kernel={cfg["conv_kernel"]}')
+        if hparams.local_prosody_predictor['conv_kernel'] not in (1, 3):
+            raise NotImplementedError(f'local_prosody_predictor: conv kernels exist for conv_kernel 1 / 3, got {hparams.local_prosody_predictor["conv_kernel"]}')
+        if hparams.gaussian_upsampling_module['conv_kernel'] != 3:      # the upsampler's projection kernels (`dx_gu_prepare`, its backward) are three-tap
+            raise NotImplementedError(f'gaussian_upsampling_module: conv_kernel must be 3, got {hparams.gaussian_upsampling_module["conv_kernel"]}')
         self.cd = torch.bfloat16 if getattr(hparams, 'compute_dtype', 'bf16') == 'bf16' else torch.float32
         self._table = param_table(hparams)
         gen = torch.Generator().manual_seed(int(torch.initial_seed()) & 0x7fffffff)
