@@ -14,16 +14,16 @@ from tests.util import gradient_report, make_hparams, no_dropout
 DEV = 'cuda:0'
 
 
-def _hparams(mode, heads, ff, pre, pred, kernels=(3, 3, 3)):
+def _hparams(mode, heads, ff, pre, pred, kernels=(3, 3, 3, 3)):
     hp = no_dropout(make_hparams(compute_dtype=mode, batch_size=4))
     hp.prosody_encoder.update(attn_nb_heads=heads[0], conv_channels=pre, conv_kernel=kernels[0])
     hp.phoneme_encoder.update(attn_nb_heads=heads[1], conv_channels=ff, conv_kernel=kernels[1])
     hp.frame_decoder.update(attn_nb_heads=heads[2], conv_channels=ff, conv_kernel=kernels[2])
-    hp.local_prosody_predictor.update(conv_channels=pred)
+    hp.local_prosody_predictor.update(conv_channels=pred, conv_kernel=kernels[3] if len(kernels) > 3 else 3)
     return hp
 
 
-def _run(mode, heads, ff, pre, pred, kernels=(3, 3, 3)):
+def _run(mode, heads, ff, pre, pred, kernels=(3, 3, 3, 3)):
     from daft_exprt.data_loader import synthetic_batch
     from daft_exprt.loss import DaftExprtLoss
     from daft_exprt.model import DaftExprt
@@ -66,7 +66,7 @@ def test_variant_architectures_match_the_oracle_fp32(heads, ff, pre, pred):
     assert worst[0][0] <= 1., worst[:5]
 
 
-@pytest.mark.parametrize('kernels', [(1, 1, 1), (3, 1, 3), (1, 3, 1)])
+@pytest.mark.parametrize('kernels', [(1, 1, 1, 1), (3, 1, 3, 3), (1, 3, 1, 3), (3, 3, 3, 1)])   # prosody encoder, phoneme encoder, decoder, predictor
 def test_conv_kernel_1_matches_the_oracle_fp32(kernels):
     ''' `conv_kernel` 1 (hparams.py:90-128 takes any odd size; model.py:75-94): the FF block's convolutions as linear layers, the
         pre-net and the scalar embeddings of the prosody encoder with one tap -- on the k = 1 GEMM kernels '''
