@@ -114,6 +114,15 @@ def test_grouped_pass_matches_sequential_bf16():
             assert float((x - y).norm()) <= 2e-2 * float(x.norm()) + 1e-6, (float((x - y).norm()), float(x.norm()))
     assert torch.allclose(t_seq, t_grp, rtol=1e-2, atol=1e-5), (t_seq.tolist(), t_grp.tolist())
     assert float((g_seq - g_grp).norm()) <= 0.1 * float(g_seq.norm()), float((g_seq - g_grp).norm()) / float(g_seq.norm())
+    # control: the bf16-only kernels that take the bounds (bit-mask ReLU conv with mask_lengths, split-K LayerNorm GEMMs on the
+    # balanced plan, the wide plan built from the skip tensor) are not reached by the fp32 test above -- the SAME concatenation without
+    # the bounds must fail this test's own tolerance on the micro-batches whose longest utterance ends before the group does, and by a
+    # wide margin over what the grouped pass with bounds shows there
+    p_raw, _, _ = _grouped(model, mbs, weights, use_bounds=False)
+    rel = lambda x, y: float((x - y).norm()) / (float(x.norm()) + 1e-12)
+    for k in (1, 2):
+        e_grp, e_raw = rel(p_seq[k][0], p_grp[k][0]), rel(p_seq[k][0], p_raw[k][0])
+        assert e_raw > 2e-2 and e_raw > 4. * e_grp, (k, e_grp, e_raw)
 
 
 def test_trainer_step_grouped_equals_three_passes():

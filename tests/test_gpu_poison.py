@@ -52,12 +52,14 @@ def test_poisoned_buffers_do_not_reach_any_output(mode, dropout):
     assert float((g0 - g1).norm()) <= 1e-4 * float(g0.norm()), float((g0 - g1).norm()) / float(g0.norm())
 
 
-def test_poisoned_grouped_step():
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_poisoned_grouped_step(mode):
+    ''' (bf16: the kernels that take the bounds only in that mode -- bit-mask ReLU conv, split-K LayerNorm GEMMs, the wide plan: ADVICE r5) '''
     from daft_exprt.data_loader import group_micro_batches, synthetic_batch
     from daft_exprt.loss import DaftExprtLoss
     from daft_exprt.model import DaftExprt
     from tests.util import make_hparams, no_dropout
-    hp = no_dropout(make_hparams(compute_dtype='fp32', batch_size=4, accumulation_steps=3))
+    hp = no_dropout(make_hparams(compute_dtype=mode, batch_size=4, accumulation_steps=3))
     torch.manual_seed(3)
     model = DaftExprt(hp).to(DEV).train()
     mbs = []
