@@ -377,14 +377,25 @@ def secondary_train(dev, batch, accum, dtype, steps, warmup, pool=4, group=True,
     torch.manual_seed(hp.seed)
     model = DaftExprt(hp).to(dev).train()
     trainer = Trainer(model, hp, 1)
-    groups = []
+    groups, host0 = [], []
     for i in range(pool):
         micro = []
         for a in range(accum):
             cb = synthetic_batch(hp, batch, seed=4321 + 1000 * i + 37 * a, t_min=t_min, t_max=1000, force_first_full=(a == 0))
+            if i == 0:
+                host0.append(cb)
             inputs, targets, _ = model.parse_batch(dev, cb)
             micro.append((inputs, targets))
         groups.append(micro)
+    host_group_ms = None
+    if group and accum > 1:      # what train() pays on the HOST per optimizer step for the merge (pad + concatenate the collate outputs in the
+        from daft_exprt.data_loader import group_host_batches     # loader-consumer path, in front of the H2D copy): not part of the timing below
+        ts = []
+        for _ in range(8):       # (the first calls grow the host allocator's pools)
+            t0 = time.perf_counter()
+            group_host_batches(host0)
+            ts.append(time.perf_counter() - t0)
+        host_group_ms = sorted(ts[3:])[2] * 1e3
     frames = [sum(int(m[0][9].sum()) for m in g) for g in groups]
     flops = [3. * sum(f_fwd(int(t), int(l)) for m in g for t, l in zip(m[0][9].tolist(), m[0][5].tolist())) for g in groups]
     it = 20000
@@ -419,6 +430,8 @@ def secondary_train(dev, batch, accum, dtype, steps, warmup, pool=4, group=True,
     del trainer, model, groups
     torch.cuda.empty_cache()
     extra = {'families': families} if families is not None else {}
+    if host_group_ms is not None:
+        extra['host_grouping_ms_per_step'] = host_group_ms    # (the grouped figure excludes it, like the H2D copy; train() overlaps it with the previous step)
     return {**extra, 'value': done_frames / elapsed, 'unit': 'mel-frames/s', 'ms_per_step': elapsed / steps * 1e3, 'steps': steps, 'warmup': warmup,
             'dtype': dtype, 'batch_size': batch, 'accumulation_steps': accum, 'utterances_per_optimizer_step': batch * accum,
             'valid_frames_per_step': done_frames / steps, 'grouped_micro_batches': bool(group and accum > 1),
